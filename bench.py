@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py — body-pair interactions/second of the all-pairs step on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--bodies 1048576] [--precision f32|f32acc64]
+
+A "step" is one run_step of the whole system (samples/nbody.cc:51-89): all-pairs force + kick + drift on
+synthetic uniform-random bodies (nbody_amd.synthetic, seed 42) already resident in HBM.  N=1 runs BASELINE
+configs[2] (N=2^20, fp32, 1 GPU).  With --gpus P > 1 (launched by torch.distributed.run, one rank per GPU) the same
+N=2^20 bodies are sharded by index over the ranks with one in-place RCCL all-gather of positions per step
+(nbody_amd.distributed), i.e. STRONG scaling of the metric's own N; --bodies 4194304 gives configs[3].
+
+Rank 0 prints ONE JSON line.  `value` = N(N-1)*K / wall (max over ranks, barrier + synchronize on both sides).
+`roofline` prices the force kernel against the fp32 vector-FMA peak (157.3 TFLOP/s = the dense f32 MFMA peak in
+MI355X_MICROARCH.md; the kernel is VALU/rsqrt work and deliberately does not use MFMA) at 20 flop per pair, from
+the kernel's own duration measured with HIP events on the launch stream.  `cpu_baseline` times the reference's
+run_step (oracle/_ref, compiled from samples/nbody.cc) — or the oracle port when that build is absent — on a
+bounded sample of the same input, 1 thread, as the reference runs.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_PAIR = 20            # GPU Gems 3 ch.31 convention
+PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz
+
+
+def cpu_baseline(n_sample=16384, steps=2):
+    """Reference run_step on the first n_sample synthetic bodies, single thread (what samples/nbody.cc is)."""
+    import numpy as np
+    from nbody_amd import synthetic
+    from oracle import oracle as O
+    q, v, m = synthetic.bodies(n_sample)
+    s = O.System(n_sample)
+    s.q[:], s.v[:], s.m[:] = q, v, m
+    pairs = n_sample * (n_sample - 1) * steps
+    if O.have_reference():
+        kind = "reference"
+        # the reference hard-codes dt=60, eps=1e-3, G=6.674e-11 (nbody.cc:10-13): same arithmetic per pair
+        t0 = time.perf_counter()
+        O.ref_run_steps(s, 1, steps)
+        dt = time.perf_counter() - t0
+        what = "oracle/_ref run_step (samples/nbody.cc compiled in place)"
+    else:
+        kind = "port"
+        os.environ.setdefault("OMP_NUM_THREADS", "1")
+        p = O.make_params(dt=synthetic.DT, eps=synthetic.EPS, G=synthetic.G)
+        t0 = time.perf_counter()
+        O.run_steps(s, 1, steps, params=p, omp=False)
+        dt = time.perf_counter() - t0
+        what = "oracle/nbody_oracle.c run_step (bit-identical restatement)"
+    assert np.isfinite(s.q).all()
+    return {"value": pairs / dt, "unit": "pairs/s", "cores": 1, "kind": kind,
+            "sample": f"{what}, {steps} steps on the first {n_sample} bodies of the same synthetic input "
+                      f"({pairs:.3g} pairs, {dt:.1f} s)"}
+
+
+def load_traffic(n_bodies, world):
+    """HBM bytes per force-kernel launch from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json)."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        key = f"n{n_bodies}_p{world}"
+        return t.get(key, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--bodies", type=int, default=1 << 20)
+    ap.add_argument("--precision", choices=["f32", "f32acc64"], default="f32")
+    ap.add_argument("--targets-per-lane", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import nbody_amd  # noqa: F401
+    from nbody_amd import capi, synthetic
+    from nbody_amd.distributed import ShardedSystem, hip_compute, shard_range
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: nbody_amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    n = args.bodies
+    acc64 = args.precision == "f32acc64"
+    lo, hi = shard_range(n, rank, world)
+    pos, vel = synthetic.body4_f32(n, lo, hi)
+    if acc64:
+        q, v, m = synthetic.bodies(n, lo, hi)
+        import numpy as np
+        pos = np.concatenate([q.T, (synthetic.G * m)[:, None]], axis=1)
+        vel = np.concatenate([v.T, np.zeros((hi - lo, 1))], axis=1)
+    compute = hip_compute(acc64, args.targets_per_lane)
+    sysm = ShardedSystem(n, torch.from_numpy(pos), torch.from_numpy(vel), synthetic.EPS, synthetic.DT, device,
+                         compute=compute, acc64=acc64)
+
+    # --- kernel-only timing: HIP events on the stream the kernel is launched on (torch's current stream)
+    kern_ms = []
+
+    def timed_step():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        src, out = sysm.pos[sysm.cur], sysm.pos[sysm.cur ^ 1]
+        e0.record()
+        sysm.compute(src, out, sysm.vel, sysm.lo, sysm.n_tgt, sysm.eps2, sysm.dt, sysm.pos64, sysm.vel64)
+        e1.record()
+        sysm._exchange(out)
+        sysm.cur ^= 1
+        kern_ms.append((e0, e1))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        sysm.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        timed_step()
+    barrier()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([wall], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    k_ms = sum(a.elapsed_time(b) for a, b in kern_ms) / len(kern_ms)
+    assert torch.isfinite(sysm.positions).all(), "non-finite positions"
+
+    if rank == 0:
+        pairs_step = n * (n - 1)
+        value = pairs_step * args.steps / wall
+        # dominant kernel: this rank's force+kick-drift launch = n_tgt x N pair evaluations, 20 flop each
+        flops_launch = FLOP_PER_PAIR * sysm.n_tgt * (n - 1)
+        achieved = flops_launch / (k_ms * 1e-3) / 1e12
+        kname = capi.kernel_name_f32(n, sysm.n_tgt, acc64, args.targets_per_lane)
+        out = {
+            "metric": "body-pair interactions/sec",
+            "value": value,
+            "unit": "pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": wall / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32" if not acc64 else "f32 pair math / f64 accumulate",
+            "data": "synthetic",
+            "config": {"workload": f"N={n} synthetic uniform-random bodies (splitmix64 seed 42), all-pairs "
+                                   f"force + fused kick-drift, eps=1e-3, dt=1e-4", "bodies": n,
+                       "parallelism": f"index-sharded x{world}, 1 RCCL all-gather of float4 positions/step"
+                       if world > 1 else "single GPU"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": load_traffic(n, world),
+                         "kernel": kname, "kernel_ms": k_ms, "flop_per_pair": FLOP_PER_PAIR,
+                         "bound_detail": "compute roofline = fp32 vector-FMA peak 157.3 TFLOP/s (== dense f32 MFMA "
+                                         "peak); kernel is VALU + v_rsq_f32, MFMA deliberately unused"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

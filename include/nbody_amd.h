@@ -1,0 +1,168 @@
+/*
+ * nbody_amd.h — C-ABI of libnbody_amd.so, the MI355X (gfx950) drop-in for the reference's hot path:
+ * the all-pairs gravitational step `run_step` (samples/nbody.cc:51-89 ; hw5.cu:159-215 + 231-239).
+ *
+ * The reference has no FFI: its boundary is the CLI `prog <in> <out>` (samples/nbody.cc:91-94,145) whose
+ * main() calls run_step(step, n, qx,qy,qz, vx,vy,vz, m, type) once per step (nbody.cc:116,129).  This header
+ * is that call hoisted behind a C ABI (plain pointers and sizes, no C++/torch types), plus the scenario
+ * drivers that main() wraps around it (nbody.cc:106-138 ; hw5.cu:322-530) so that small systems need no
+ * host round trip per step.  bin/hw5 (csrc/main_hw5.cpp) is the CLI drop-in built on it; INTEGRATION.md
+ * shows the two-line change that makes the reference's own main() call it.
+ *
+ * Conventions
+ *  - every function returns int: 0 = NB_OK, <0 = nb_status error; no exception crosses the boundary;
+ *  - host arrays are caller-owned SoA `double[n]`, exactly run_step's vectors; the library copies and never
+ *    keeps a host pointer after return;
+ *  - the library owns device memory and its HIP stream; a context is bound to ONE GPU, is not thread-safe,
+ *    distinct contexts may be driven from distinct host threads (how hw5.cu uses its GPUs: hw5.cu:564-567);
+ *  - there is NO CPU fallback: without a HIP device nb_create fails with NB_ERR_NO_DEVICE.
+ */
+#ifndef NBODY_AMD_H
+#define NBODY_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NB_ABI_VERSION 1
+
+typedef enum nb_status {
+    NB_OK = 0,
+    NB_ERR_INVALID = -1,   /* bad argument (NULL, n <= 0, unknown enum, eps == 0 in an fp32 mode ...) */
+    NB_ERR_NO_DEVICE = -2, /* no usable HIP device / bad ordinal */
+    NB_ERR_HIP = -3,       /* a HIP call failed; nb_last_error() has the text */
+    NB_ERR_STATE = -4,     /* call sequence error (e.g. step before set_state) */
+    NB_ERR_NOMEM = -5,
+    NB_ERR_IO = -6
+} nb_status;
+
+/* arithmetic the step is computed in */
+typedef enum nb_precision {
+    NB_F64 = 0,      /* everything fp64 — the testcases (|q| ~ 3e20 m; fp32 cannot represent them) */
+    NB_F32 = 1,      /* fp32 state and pair arithmetic — large synthetic N */
+    NB_F32_ACC64 = 2 /* fp32 pair arithmetic, per-tile partial sums added into fp64; fp64 q,v masters */
+} nb_precision;
+
+/* param:: of the reference — samples/nbody.cc:9-20 ; hw5.cu:50-67 */
+typedef struct nb_config {
+    int32_t n;         /* bodies */
+    int32_t precision; /* nb_precision */
+    int32_t device;    /* HIP device ordinal */
+    int32_t reserved;
+    double G;   /* 6.674e-11 */
+    double eps; /* 1e-3  (Plummer softening; r2 + eps*eps) */
+    double dt;  /* 60 */
+} nb_config;
+
+/* scenario drivers — the loops main() runs around run_step */
+typedef enum nb_scenario_kind {
+    NB_SCN_MIN_DIST = 0,  /* Problem 1 monitor: min over steps of |q_planet - q_asteroid|   nbody.cc:114-122 */
+    NB_SCN_FIRST_HIT = 1, /* Problem 2: first step with d2 < R^2, stop there               nbody.cc:127-138;
+                             also records each watched device's missile-arrival step + a
+                             device-side snapshot of (q,v) at it                            hw5.cu:265-287 */
+    NB_SCN_MISSILE = 2    /* Problem 3, one device: hit test, then arrival -> cost, m[d]=0  hw5.cu:289-309 */
+} nb_scenario_kind;
+
+#define NB_MAX_WATCH 16
+
+typedef struct nb_scenario {
+    int32_t kind;        /* nb_scenario_kind */
+    int32_t first_step;  /* index of the state currently loaded (0 = the input); monitors run on it first */
+    int32_t last_step;   /* inclusive; reference: n_steps = 200000 */
+    int32_t planet;      /* body indices (file order) */
+    int32_t asteroid;
+    int32_t n_watch;               /* devices watched for missile arrival (FIRST_HIT: all; MISSILE: 1) */
+    int32_t watch[NB_MAX_WATCH];   /* their body indices */
+    int32_t sync_every;            /* host polls the hit flag every this many steps (hw5.cu:72: 2000); <=0 -> 2000 */
+    double planet_radius;          /* 1e7   nbody.cc:17 */
+    double missile_speed;          /* 1e6   nbody.cc:18 */
+} nb_scenario;
+
+typedef struct nb_scenario_result {
+    double min_dist2;                     /* MIN_DIST: min squared planet–asteroid distance (sqrt on the host) */
+    int32_t hit_step;                     /* FIRST_HIT / MISSILE: first hit step, -2 = none */
+    int32_t steps_done;                   /* index of the last state computed */
+    int32_t arrival_step[NB_MAX_WATCH];   /* per watched device, -2 = never (before the hit) */
+    double missile_cost[NB_MAX_WATCH];    /* 1e5 + 1e3*(arrival+1)*dt   hw5.cu:305 ; nbody.cc:19 */
+} nb_scenario_result;
+
+typedef struct nb_context nb_context;
+
+/* ---- lifecycle ---- */
+int nb_abi_version(void);
+int nb_device_count(int* count);
+int nb_config_default(nb_config* cfg); /* fills the reference's param:: values, F64, device 0 */
+int nb_create(nb_context** out, const nb_config* cfg);
+int nb_destroy(nb_context* ctx);
+const char* nb_strerror(int code);
+const char* nb_last_error(const nb_context* ctx); /* text of the last HIP failure on this context */
+
+/* ---- state: the seven vectors of run_step + the `type[j]=="device"` predicate (nbody.cc:62) ---- */
+int nb_set_state(nb_context* ctx, const double* qx, const double* qy, const double* qz, const double* vx,
+                 const double* vy, const double* vz, const double* m, const uint8_t* is_device /* may be NULL */);
+int nb_get_state(nb_context* ctx, double* qx, double* qy, double* qz, double* vx, double* vy, double* vz);
+int nb_set_mass(nb_context* ctx, int index, double m); /* e.g. Problem 1's m[device] = 0, nbody.cc:109-113 */
+
+/* ---- the hot path ---- */
+/* run_step(step, ...) for step = first_step .. first_step+count-1 (nbody.cc:51-89): accelerations from the old
+ * positions, v += a*dt, q += v*dt.  The step index feeds the device-mass law m0 + 0.5*m0*|sin(step*dt/6000)|. */
+int nb_step(nb_context* ctx, int first_step, int count);
+/* accelerations only (nbody.cc:56-74), no update; outputs double[n] each */
+int nb_accel(nb_context* ctx, int step, double* ax, double* ay, double* az);
+/* as nb_step, and reports the mean GPU time of one step's launches in milliseconds, measured with HIP events
+ * recorded on the context's own stream around the `count` steps */
+int nb_step_timed(nb_context* ctx, int first_step, int count, float* ms_per_step);
+
+/* ---- scenario drivers (monitors evaluated on the GPU, no per-step host round trip) ---- */
+int nb_run_scenario(nb_context* ctx, const nb_scenario* scn, nb_scenario_result* res);
+/* load the (q,v) snapshot that the last FIRST_HIT scenario on `src` took at watched device `watch_slot`'s
+ * missile arrival into `dst` (same n, precision F64, same GPU or not); hw5.cu:482-484 */
+int nb_restore_snapshot(nb_context* dst, nb_context* src, int watch_slot);
+
+/* ---- whole reference program: P1, P2, P3 (nbody.cc:106-146 ; hw5.cu:532-606) ---- */
+typedef struct nb_answer {
+    double min_dist;
+    int32_t hit_time_step;
+    int32_t gravity_device_id;
+    double missile_cost;
+} nb_answer;
+int nb_solve(int n, int planet, int asteroid, const double* qx, const double* qy, const double* qz,
+             const double* vx, const double* vy, const double* vz, const double* m, const uint8_t* is_device,
+             const int* devices /* HIP ordinals to spread scenarios over */, int n_devices, nb_answer* out);
+
+/* ---- raw launches on caller-owned HBM (device pointers + a hipStream_t as void*) ----
+ * For hosts that own device memory and the exchange step themselves (one process per GPU with
+ * torch.distributed/RCCL: bench.py, nbody_amd.distributed).  fp32 body record = float4 {x, y, z, G*m}.
+ *
+ *   src      float4[n_src]   all source bodies (the gathered array every rank holds)
+ *   tgt_off  first target index in src; targets are src[tgt_off .. tgt_off+n_tgt)
+ *   out      float4[n_src]   the OTHER (ping-pong) gathered array; only [tgt_off, tgt_off+n_tgt) is written
+ *   vel      float4[n_tgt]   this rank's velocities, in place ({vx,vy,vz,unused})
+ *   F32_ACC64 additionally keeps fp64 masters: pos64/vel64 = double4[n_tgt] ({x,y,z,G*m} / {vx,vy,vz,0})
+ */
+typedef struct nb_launch_f32 {
+    const void* src;
+    void* out;
+    void* vel;
+    void* pos64; /* NULL unless acc64 */
+    void* vel64; /* NULL unless acc64 */
+    void* acc;   /* nb_launch_accel_f32 only: float4[n_tgt] {ax,ay,az,0} (acc64: double4[n_tgt]) */
+    int64_t n_src;
+    int64_t tgt_off;
+    int64_t n_tgt;
+    float eps2;
+    float dt;
+    int32_t acc64;            /* 0 = NB_F32, 1 = NB_F32_ACC64 */
+    int32_t targets_per_lane; /* 0 = auto; 1, 2 or 4 */
+} nb_launch_f32;
+int nb_launch_step_f32(const nb_launch_f32* a, void* hip_stream);  /* force + fused kick-drift */
+int nb_launch_accel_f32(const nb_launch_f32* a, void* hip_stream); /* force only -> a->acc */
+/* name of the kernel symbol the two launches above resolve to for these arguments (for matching rocprofv3 rows) */
+const char* nb_kernel_name_f32(const nb_launch_f32* a, int accel_only);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBODY_AMD_H */

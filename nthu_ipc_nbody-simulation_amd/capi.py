@@ -1,0 +1,241 @@
+"""ctypes binding of libnbody_amd.so (include/nbody_amd.h).  No compute happens in Python and there is no
+fallback: a missing library raises at import of the symbol table, a missing GPU raises NBodyError(NB_ERR_NO_DEVICE)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+NB_OK = 0
+NB_ERR_INVALID, NB_ERR_NO_DEVICE, NB_ERR_HIP, NB_ERR_STATE, NB_ERR_NOMEM, NB_ERR_IO = -1, -2, -3, -4, -5, -6
+NB_F64, NB_F32, NB_F32_ACC64 = 0, 1, 2
+NB_SCN_MIN_DIST, NB_SCN_FIRST_HIT, NB_SCN_MISSILE = 0, 1, 2
+NB_MAX_WATCH = 16
+
+_dp = C.POINTER(C.c_double)
+_u8p = C.POINTER(C.c_uint8)
+
+
+class NbConfig(C.Structure):
+    _fields_ = [("n", C.c_int32), ("precision", C.c_int32), ("device", C.c_int32), ("reserved", C.c_int32),
+                ("G", C.c_double), ("eps", C.c_double), ("dt", C.c_double)]
+
+
+class NbScenario(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("first_step", C.c_int32), ("last_step", C.c_int32), ("planet", C.c_int32),
+                ("asteroid", C.c_int32), ("n_watch", C.c_int32), ("watch", C.c_int32 * NB_MAX_WATCH),
+                ("sync_every", C.c_int32), ("planet_radius", C.c_double), ("missile_speed", C.c_double)]
+
+
+class NbScenarioResult(C.Structure):
+    _fields_ = [("min_dist2", C.c_double), ("hit_step", C.c_int32), ("steps_done", C.c_int32),
+                ("arrival_step", C.c_int32 * NB_MAX_WATCH), ("missile_cost", C.c_double * NB_MAX_WATCH)]
+
+
+class NbAnswer(C.Structure):
+    _fields_ = [("min_dist", C.c_double), ("hit_time_step", C.c_int32), ("gravity_device_id", C.c_int32),
+                ("missile_cost", C.c_double)]
+
+
+class NbLaunchF32(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("out", C.c_void_p), ("vel", C.c_void_p), ("pos64", C.c_void_p),
+                ("vel64", C.c_void_p), ("acc", C.c_void_p), ("n_src", C.c_int64), ("tgt_off", C.c_int64),
+                ("n_tgt", C.c_int64), ("eps2", C.c_float), ("dt", C.c_float), ("acc64", C.c_int32),
+                ("targets_per_lane", C.c_int32)]
+
+
+# every symbol include/nbody_amd.h declares: (restype, argtypes)
+SYMBOLS = {
+    "nb_abi_version": (C.c_int, []),
+    "nb_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "nb_config_default": (C.c_int, [C.POINTER(NbConfig)]),
+    "nb_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(NbConfig)]),
+    "nb_destroy": (C.c_int, [C.c_void_p]),
+    "nb_strerror": (C.c_char_p, [C.c_int]),
+    "nb_last_error": (C.c_char_p, [C.c_void_p]),
+    "nb_set_state": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _u8p]),
+    "nb_get_state": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _dp, _dp]),
+    "nb_set_mass": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
+    "nb_step": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "nb_accel": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp]),
+    "nb_step_timed": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "nb_run_scenario": (C.c_int, [C.c_void_p, C.POINTER(NbScenario), C.POINTER(NbScenarioResult)]),
+    "nb_restore_snapshot": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "nb_solve": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _u8p,
+                           C.POINTER(C.c_int), C.c_int, C.POINTER(NbAnswer)]),
+    "nb_launch_step_f32": (C.c_int, [C.POINTER(NbLaunchF32), C.c_void_p]),
+    "nb_launch_accel_f32": (C.c_int, [C.POINTER(NbLaunchF32), C.c_void_p]),
+    "nb_kernel_name_f32": (C.c_char_p, [C.POINTER(NbLaunchF32), C.c_int]),
+}
+
+
+class NBodyError(RuntimeError):
+    def __init__(self, code, where, detail=""):
+        self.code = code
+        msg = f"{where}: {_strerror(code)} ({code})"
+        if detail:
+            msg += f" — {detail}"
+        super().__init__(msg)
+
+
+def library_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libnbody_amd.so")
+
+
+_lib = None
+
+
+def lib():
+    """Load libnbody_amd.so.  Raises if it has not been built (`make` / __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise ImportError(f"{path} not built — run `make` (there is no CPU fallback)")
+        L = C.CDLL(path)
+        for name, (res, args) in SYMBOLS.items():
+            f = getattr(L, name)  # AttributeError if the ABI lost a symbol
+            f.restype, f.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def _strerror(code):
+    try:
+        return lib().nb_strerror(code).decode()
+    except Exception:  # pragma: no cover
+        return "error"
+
+
+def _check(rc, where, ctx=None):
+    if rc != NB_OK:
+        detail = lib().nb_last_error(ctx).decode() if ctx else ""
+        raise NBodyError(rc, where, detail)
+
+
+def device_count():
+    n = C.c_int(0)
+    lib().nb_device_count(C.byref(n))
+    return n.value
+
+
+def _d(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_dp)
+
+
+class Context:
+    """One nb_context: a system of n bodies resident on one GPU."""
+
+    def __init__(self, n, precision=NB_F64, device=0, G=None, eps=None, dt=None):
+        cfg = NbConfig()
+        _check(lib().nb_config_default(C.byref(cfg)), "nb_config_default")
+        cfg.n, cfg.precision, cfg.device = n, precision, device
+        if G is not None:
+            cfg.G = G
+        if eps is not None:
+            cfg.eps = eps
+        if dt is not None:
+            cfg.dt = dt
+        self.cfg, self.n = cfg, n
+        self._h = C.c_void_p()
+        rc = lib().nb_create(C.byref(self._h), C.byref(cfg))
+        if rc != NB_OK:
+            h, self._h = self._h, C.c_void_p()
+            detail = lib().nb_last_error(h).decode() if h else ""
+            if h:
+                lib().nb_destroy(h)
+            raise NBodyError(rc, "nb_create", detail)
+
+    def close(self):
+        if self._h:
+            lib().nb_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_state(self, q, v, m, is_device=None):
+        """q, v: (3, n) arrays (rows = the reference's qx,qy,qz / vx,vy,vz vectors); m: (n,)."""
+        keep = [_d(q[0]), _d(q[1]), _d(q[2]), _d(v[0]), _d(v[1]), _d(v[2]), _d(m)]
+        dev = None
+        if is_device is not None:
+            dev_arr = np.ascontiguousarray(is_device, dtype=np.uint8)
+            dev = dev_arr.ctypes.data_as(_u8p)
+        _check(lib().nb_set_state(self._h, *[p for _, p in keep], dev), "nb_set_state", self._h)
+
+    def get_state(self):
+        q = np.empty((3, self.n))
+        v = np.empty((3, self.n))
+        ptrs = [q[k].ctypes.data_as(_dp) for k in range(3)] + [v[k].ctypes.data_as(_dp) for k in range(3)]
+        _check(lib().nb_get_state(self._h, *ptrs), "nb_get_state", self._h)
+        return q, v
+
+    def set_mass(self, index, m):
+        _check(lib().nb_set_mass(self._h, index, m), "nb_set_mass", self._h)
+
+    def step(self, first_step, count=1):
+        _check(lib().nb_step(self._h, first_step, count), "nb_step", self._h)
+
+    def step_timed(self, first_step, count):
+        ms = C.c_float()
+        _check(lib().nb_step_timed(self._h, first_step, count, C.byref(ms)), "nb_step_timed", self._h)
+        return ms.value
+
+    def accel(self, step):
+        a = np.empty((3, self.n))
+        _check(lib().nb_accel(self._h, step, *[a[k].ctypes.data_as(_dp) for k in range(3)]), "nb_accel", self._h)
+        return a
+
+    def run_scenario(self, kind, planet, asteroid, first_step=0, last_step=200000, watch=(), sync_every=2000,
+                     planet_radius=1e7, missile_speed=1e6):
+        s = NbScenario()
+        s.kind, s.first_step, s.last_step, s.planet, s.asteroid = kind, first_step, last_step, planet, asteroid
+        s.n_watch = len(watch)
+        for k, w in enumerate(watch):
+            s.watch[k] = w
+        s.sync_every, s.planet_radius, s.missile_speed = sync_every, planet_radius, missile_speed
+        r = NbScenarioResult()
+        _check(lib().nb_run_scenario(self._h, C.byref(s), C.byref(r)), "nb_run_scenario", self._h)
+        return dict(min_dist2=r.min_dist2, hit_step=r.hit_step, steps_done=r.steps_done,
+                    arrival_step=list(r.arrival_step[:len(watch)]), missile_cost=list(r.missile_cost[:len(watch)]))
+
+    def restore_snapshot_from(self, src, slot):
+        _check(lib().nb_restore_snapshot(self._h, src._h, slot), "nb_restore_snapshot", self._h)
+
+
+def solve(n, planet, asteroid, q, v, m, is_device, devices=None):
+    """The whole reference program (P1, P2, P3) on the GPU: nb_solve."""
+    keep = [_d(q[0]), _d(q[1]), _d(q[2]), _d(v[0]), _d(v[1]), _d(v[2]), _d(m)]
+    dev_arr = np.ascontiguousarray(is_device, dtype=np.uint8)
+    ans = NbAnswer()
+    gpus, ng = None, 0
+    if devices:
+        gpus = (C.c_int * len(devices))(*devices)
+        ng = len(devices)
+    rc = lib().nb_solve(n, planet, asteroid, *[p for _, p in keep], dev_arr.ctypes.data_as(_u8p), gpus, ng,
+                        C.byref(ans))
+    _check(rc, "nb_solve")
+    return ans.min_dist, ans.hit_time_step, ans.gravity_device_id, ans.missile_cost
+
+
+def launch_f32(src_ptr, out_ptr, n_src, tgt_off, n_tgt, eps2, dt, stream, vel_ptr=0, pos64_ptr=0, vel64_ptr=0,
+               acc_ptr=0, acc64=False, targets_per_lane=0, accel_only=False):
+    """Raw launch on caller-owned device memory (pointers as ints, e.g. torch.Tensor.data_ptr())."""
+    a = NbLaunchF32(src_ptr, out_ptr or None, vel_ptr or None, pos64_ptr or None, vel64_ptr or None,
+                    acc_ptr or None, n_src, tgt_off, n_tgt, eps2, dt, int(acc64), targets_per_lane)
+    f = lib().nb_launch_accel_f32 if accel_only else lib().nb_launch_step_f32
+    _check(f(C.byref(a), C.c_void_p(stream)), "nb_launch_accel_f32" if accel_only else "nb_launch_step_f32")
+
+
+def kernel_name_f32(n_src, n_tgt, acc64=False, targets_per_lane=0, accel_only=False):
+    a = NbLaunchF32(None, None, None, None, None, None, n_src, 0, n_tgt, 1.0, 1.0, int(acc64), targets_per_lane)
+    return lib().nb_kernel_name_f32(C.byref(a), int(accel_only)).decode()

@@ -1,0 +1,48 @@
+// main_hw5.cpp — the drop-in CLI:  hw5 <input> <output>   (samples/nbody.cc:91-94,145 ; hw5.cu:532-535,606,618)
+//
+// Same argv, same input and output formats, same three answers; all arithmetic runs on the MI355X through the
+// C ABI of libnbody_amd (nb_solve).  NB_DEVICES=0,1,... (optional) spreads the independent scenarios P1, P2 and
+// the per-device P3 runs over several GPUs, as the reference does over its two (hw5.cu:564-567,587-588).
+#include <cstdio>
+#include <cstdlib>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/nbody_amd.h"
+#include "nbody_io.h"
+
+int main(int argc, char** argv) {
+    if (argc != 3) {
+        throw std::runtime_error("must supply 2 arguments");  // uncaught -> abort, like the reference
+    }
+    nbio::Input in;
+    if (!nbio::read_input(argv[1], in)) {
+        fprintf(stderr, "hw5: cannot read %s\n", argv[1]);
+        return 1;
+    }
+    std::vector<int> gpus;
+    if (const char* env = getenv("NB_DEVICES")) {
+        std::string s(env);
+        size_t pos = 0;
+        while (pos < s.size()) {
+            size_t e = s.find(',', pos);
+            if (e == std::string::npos) e = s.size();
+            if (e > pos) gpus.push_back(atoi(s.substr(pos, e - pos).c_str()));
+            pos = e + 1;
+        }
+    }
+    nb_answer ans{};
+    int rc = nb_solve(in.n, in.planet, in.asteroid, in.qx.data(), in.qy.data(), in.qz.data(), in.vx.data(),
+                      in.vy.data(), in.vz.data(), in.m.data(), in.is_device.data(),
+                      gpus.empty() ? nullptr : gpus.data(), (int)gpus.size(), &ans);
+    if (rc != NB_OK) {
+        fprintf(stderr, "hw5: nb_solve failed: %s\n", nb_strerror(rc));
+        return 2;
+    }
+    if (!nbio::write_output(argv[2], ans.min_dist, ans.hit_time_step, ans.gravity_device_id, ans.missile_cost)) {
+        fprintf(stderr, "hw5: cannot write %s\n", argv[2]);
+        return 1;
+    }
+    return 0;
+}

@@ -1,0 +1,664 @@
+// nbody_capi.cpp — implementation of the C ABI in include/nbody_amd.h on top of the gfx950 kernels.
+//
+// Host-side equivalents of the reference's orchestration:
+//   nb_step          <- run_step call sites               samples/nbody.cc:116,129
+//   nb_run_scenario  <- P1/P2 loops, t_problem_12/_3      samples/nbody.cc:114-138 ; hw5.cu:366-404,489-508
+//   nb_solve         <- main()                            samples/nbody.cc:91-146 ; hw5.cu:532-606
+// There is no CPU compute path here: every entry point needs a HIP device and fails loudly without one.
+#include "../../include/nbody_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <thread>
+#include <vector>
+
+#include "nbody_kernels.h"
+
+using namespace nbk;
+
+struct nb_context {
+    nb_config cfg;
+    int n = 0;
+    int n_cus = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool have_state = false;
+    char err[512] = {0};
+
+    // F64: SoA planes in HBM, exactly run_step's vectors: q[3][n] (ping-pong), v[3][n], m[n], coef[n]
+    double* q[2] = {nullptr, nullptr};
+    int cur = 0;
+    double* v = nullptr;
+    double* m = nullptr;
+    double* coef = nullptr;
+    double* acc = nullptr;  // [3][n] scratch for nb_accel
+    F64Monitor* mon = nullptr;
+    F64Monitor* mon_host = nullptr;  // pinned
+    double* snap_q = nullptr;        // [NB_MAX_WATCH? n_watch][3][n]
+    double* snap_v = nullptr;
+    int snap_slots = 0;
+    int split = 1;
+    std::vector<double> m_host;
+    std::vector<uint8_t> dev_host;
+
+    // F32 / F32_ACC64: float4 {x,y,z,G*m} ping-pong, float4 velocities, optional double4 masters
+    float4* pos[2] = {nullptr, nullptr};
+    float4* vel = nullptr;
+    double4* pos64 = nullptr;
+    double4* vel64 = nullptr;
+    void* acc32 = nullptr;
+};
+
+namespace {
+
+int fail_hip(nb_context* c, hipError_t e, const char* what) {
+    if (c) snprintf(c->err, sizeof c->err, "%s: %s", what, hipGetErrorString(e));
+    return NB_ERR_HIP;
+}
+
+#define NB_HIP(ctx, call)                                        \
+    do {                                                         \
+        hipError_t e_ = (call);                                  \
+        if (e_ != hipSuccess) return fail_hip(ctx, e_, #call);   \
+    } while (0)
+
+int bind(nb_context* c) {
+    if (!c) return NB_ERR_INVALID;
+    NB_HIP(c, hipSetDevice(c->cfg.device));
+    return NB_OK;
+}
+
+// |sin(step*dt/6000)| with glibc, the value samples/nbody.cc:15,63 feeds gravity_device_mass
+double fst_of(int step, double dt) { return std::fabs(std::sin(step * dt / 6000)); }
+
+template <class T>
+void free_dev(T*& p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+void release(nb_context* c) {
+    free_dev(c->q[0]); free_dev(c->q[1]); free_dev(c->v); free_dev(c->m); free_dev(c->coef); free_dev(c->acc);
+    free_dev(c->mon); free_dev(c->snap_q); free_dev(c->snap_v);
+    free_dev(c->pos[0]); free_dev(c->pos[1]); free_dev(c->vel); free_dev(c->pos64); free_dev(c->vel64);
+    free_dev(c->acc32);
+    if (c->mon_host) (void)hipHostFree(c->mon_host);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+}
+
+F64Args base_args(nb_context* c, int step) {
+    F64Args a{};
+    a.qin = c->q[c->cur];
+    a.qout = c->q[c->cur ^ 1];
+    a.v = c->v;
+    a.m = c->m;
+    a.coef = c->coef;
+    a.mon = c->mon;
+    a.n = c->n;
+    a.step = step;
+    a.do_update = 1;
+    a.fst = fst_of(step, c->cfg.dt);
+    a.G = c->cfg.G;
+    a.eps2 = c->cfg.eps * c->cfg.eps;
+    a.dt = c->cfg.dt;
+    a.scn.kind = -1;
+    return a;
+}
+
+int step_f64(nb_context* c, int first_step, int count) {
+    for (int s = 0; s < count; ++s) {
+        F64Args a = base_args(c, first_step + s);
+        NB_HIP(c, (hipError_t)launch_f64(a, c->split, c->stream));
+        c->cur ^= 1;
+    }
+    return NB_OK;
+}
+
+F32Args f32_args(nb_context* c) {
+    F32Args a{};
+    a.src = c->pos[c->cur];
+    a.out = c->pos[c->cur ^ 1];
+    a.vel = c->vel;
+    a.pos64 = c->pos64;
+    a.vel64 = c->vel64;
+    a.acc = c->acc32;
+    a.n_src = c->n;
+    a.tgt_off = 0;
+    a.n_tgt = c->n;
+    a.eps2 = (float)(c->cfg.eps * c->cfg.eps);
+    a.dt = (float)c->cfg.dt;
+    return a;
+}
+
+int step_f32(nb_context* c, int count) {
+    const bool acc64 = c->cfg.precision == NB_F32_ACC64;
+    const int R = auto_targets_per_lane(c->n, c->n_cus);
+    for (int s = 0; s < count; ++s) {
+        F32Args a = f32_args(c);
+        NB_HIP(c, (hipError_t)launch_f32(a, R, acc64, false, c->stream));
+        c->cur ^= 1;
+    }
+    return NB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nb_abi_version(void) { return NB_ABI_VERSION; }
+
+int nb_device_count(int* count) {
+    if (!count) return NB_ERR_INVALID;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    *count = (e == hipSuccess) ? n : 0;
+    return (e == hipSuccess && n > 0) ? NB_OK : NB_ERR_NO_DEVICE;
+}
+
+int nb_config_default(nb_config* cfg) {
+    if (!cfg) return NB_ERR_INVALID;
+    memset(cfg, 0, sizeof *cfg);
+    cfg->precision = NB_F64;
+    cfg->device = 0;
+    cfg->G = 6.674e-11;  // samples/nbody.cc:13
+    cfg->eps = 1e-3;     // :12
+    cfg->dt = 60;        // :11
+    return NB_OK;
+}
+
+const char* nb_strerror(int code) {
+    switch (code) {
+        case NB_OK: return "ok";
+        case NB_ERR_INVALID: return "invalid argument";
+        case NB_ERR_NO_DEVICE: return "no usable HIP device (this library has no CPU fallback)";
+        case NB_ERR_HIP: return "HIP runtime error (see nb_last_error)";
+        case NB_ERR_STATE: return "call sequence error (state not set?)";
+        case NB_ERR_NOMEM: return "out of memory";
+        case NB_ERR_IO: return "I/O error";
+    }
+    return "unknown error";
+}
+
+const char* nb_last_error(const nb_context* ctx) { return ctx ? ctx->err : "null context"; }
+
+int nb_create(nb_context** out, const nb_config* cfg) {
+    if (!out || !cfg || cfg->n <= 0) return NB_ERR_INVALID;
+    if (cfg->precision < NB_F64 || cfg->precision > NB_F32_ACC64) return NB_ERR_INVALID;
+    if (cfg->precision != NB_F64 && !(cfg->eps > 0)) return NB_ERR_INVALID;  // fp32 kernels evaluate the self pair
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return NB_ERR_NO_DEVICE;
+    if (cfg->device < 0 || cfg->device >= ndev) return NB_ERR_NO_DEVICE;
+    nb_context* c = new (std::nothrow) nb_context();
+    if (!c) return NB_ERR_NOMEM;
+    c->cfg = *cfg;
+    c->n = cfg->n;
+    *out = c;  // returned even on failure so the caller can read nb_last_error, then nb_destroy
+    NB_HIP(c, hipSetDevice(cfg->device));
+    hipDeviceProp_t prop;
+    NB_HIP(c, hipGetDeviceProperties(&prop, cfg->device));
+    c->n_cus = prop.multiProcessorCount;
+    NB_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    NB_HIP(c, hipEventCreate(&c->ev0));
+    NB_HIP(c, hipEventCreate(&c->ev1));
+    const size_t n = (size_t)c->n;
+    if (cfg->precision == NB_F64) {
+        NB_HIP(c, hipMalloc(&c->q[0], 3 * n * sizeof(double)));
+        NB_HIP(c, hipMalloc(&c->q[1], 3 * n * sizeof(double)));
+        NB_HIP(c, hipMalloc(&c->v, 3 * n * sizeof(double)));
+        NB_HIP(c, hipMalloc(&c->m, n * sizeof(double)));
+        NB_HIP(c, hipMalloc(&c->coef, n * sizeof(double)));
+        NB_HIP(c, hipMalloc(&c->acc, 3 * n * sizeof(double)));
+        NB_HIP(c, hipMalloc(&c->mon, sizeof(F64Monitor)));
+        NB_HIP(c, hipHostMalloc(&c->mon_host, sizeof(F64Monitor)));
+        c->split = auto_split_f64(c->n, c->n_cus);
+    } else {
+        NB_HIP(c, hipMalloc(&c->pos[0], n * sizeof(float4)));
+        NB_HIP(c, hipMalloc(&c->pos[1], n * sizeof(float4)));
+        NB_HIP(c, hipMalloc(&c->vel, n * sizeof(float4)));
+        NB_HIP(c, hipMalloc(&c->acc32, n * sizeof(double4)));
+        if (cfg->precision == NB_F32_ACC64) {
+            NB_HIP(c, hipMalloc(&c->pos64, n * sizeof(double4)));
+            NB_HIP(c, hipMalloc(&c->vel64, n * sizeof(double4)));
+        }
+    }
+    return NB_OK;
+}
+
+int nb_destroy(nb_context* ctx) {
+    if (!ctx) return NB_ERR_INVALID;
+    (void)hipSetDevice(ctx->cfg.device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    release(ctx);
+    delete ctx;
+    return NB_OK;
+}
+
+int nb_set_state(nb_context* c, const double* qx, const double* qy, const double* qz, const double* vx,
+                 const double* vy, const double* vz, const double* m, const uint8_t* is_device) {
+    if (!c || !qx || !qy || !qz || !vx || !vy || !vz || !m) return NB_ERR_INVALID;
+    if (int rc = bind(c)) return rc;
+    const size_t n = (size_t)c->n;
+    c->m_host.assign(m, m + n);
+    c->dev_host.assign(n, 0);
+    if (is_device) c->dev_host.assign(is_device, is_device + n);
+    if (c->cfg.precision == NB_F64) {
+        std::vector<double> coef(n);
+        for (size_t i = 0; i < n; ++i) coef[i] = c->dev_host[i] ? 0.5 : 0.0;  // nbody.cc:15
+        double* q = c->q[0];
+        c->cur = 0;
+        const size_t B = n * sizeof(double);
+        NB_HIP(c, hipMemcpyAsync(q, qx, B, hipMemcpyHostToDevice, c->stream));
+        NB_HIP(c, hipMemcpyAsync(q + n, qy, B, hipMemcpyHostToDevice, c->stream));
+        NB_HIP(c, hipMemcpyAsync(q + 2 * n, qz, B, hipMemcpyHostToDevice, c->stream));
+        NB_HIP(c, hipMemcpyAsync(c->v, vx, B, hipMemcpyHostToDevice, c->stream));
+        NB_HIP(c, hipMemcpyAsync(c->v + n, vy, B, hipMemcpyHostToDevice, c->stream));
+        NB_HIP(c, hipMemcpyAsync(c->v + 2 * n, vz, B, hipMemcpyHostToDevice, c->stream));
+        NB_HIP(c, hipMemcpyAsync(c->m, m, B, hipMemcpyHostToDevice, c->stream));
+        NB_HIP(c, hipMemcpyAsync(c->coef, coef.data(), B, hipMemcpyHostToDevice, c->stream));
+        NB_HIP(c, hipStreamSynchronize(c->stream));  // host buffers are the caller's: done with them on return
+    } else {
+        for (size_t i = 0; i < n; ++i)
+            if (c->dev_host[i]) return NB_ERR_INVALID;  // the device-mass law needs fp64 state (SURVEY A-4)
+        std::vector<float4> p(n), v(n);
+        for (size_t i = 0; i < n; ++i) {
+            // G*m folded in fp64, rounded once (keeps G*m ~ 1e-10*m away from fp32 underflow)
+            p[i] = make_float4((float)qx[i], (float)qy[i], (float)qz[i], (float)(c->cfg.G * m[i]));
+            v[i] = make_float4((float)vx[i], (float)vy[i], (float)vz[i], 0.f);
+        }
+        c->cur = 0;
+        NB_HIP(c, hipMemcpyAsync(c->pos[0], p.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+        NB_HIP(c, hipMemcpyAsync(c->vel, v.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+        if (c->cfg.precision == NB_F32_ACC64) {
+            std::vector<double4> p64(n), v64(n);
+            for (size_t i = 0; i < n; ++i) {
+                p64[i] = make_double4(qx[i], qy[i], qz[i], c->cfg.G * m[i]);
+                v64[i] = make_double4(vx[i], vy[i], vz[i], 0.0);
+            }
+            NB_HIP(c, hipMemcpyAsync(c->pos64, p64.data(), n * sizeof(double4), hipMemcpyHostToDevice, c->stream));
+            NB_HIP(c, hipMemcpyAsync(c->vel64, v64.data(), n * sizeof(double4), hipMemcpyHostToDevice, c->stream));
+            NB_HIP(c, hipStreamSynchronize(c->stream));
+        }
+        NB_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    c->have_state = true;
+    return NB_OK;
+}
+
+int nb_get_state(nb_context* c, double* qx, double* qy, double* qz, double* vx, double* vy, double* vz) {
+    if (!c || !qx || !qy || !qz || !vx || !vy || !vz) return NB_ERR_INVALID;
+    if (!c->have_state) return NB_ERR_STATE;
+    if (int rc = bind(c)) return rc;
+    const size_t n = (size_t)c->n;
+    if (c->cfg.precision == NB_F64) {
+        const double* q = c->q[c->cur];
+        const size_t B = n * sizeof(double);
+        NB_HIP(c, hipMemcpyAsync(qx, q, B, hipMemcpyDeviceToHost, c->stream));
+        NB_HIP(c, hipMemcpyAsync(qy, q + n, B, hipMemcpyDeviceToHost, c->stream));
+        NB_HIP(c, hipMemcpyAsync(qz, q + 2 * n, B, hipMemcpyDeviceToHost, c->stream));
+        NB_HIP(c, hipMemcpyAsync(vx, c->v, B, hipMemcpyDeviceToHost, c->stream));
+        NB_HIP(c, hipMemcpyAsync(vy, c->v + n, B, hipMemcpyDeviceToHost, c->stream));
+        NB_HIP(c, hipMemcpyAsync(vz, c->v + 2 * n, B, hipMemcpyDeviceToHost, c->stream));
+        NB_HIP(c, hipStreamSynchronize(c->stream));
+    } else if (c->cfg.precision == NB_F32_ACC64) {
+        std::vector<double4> p(n), v(n);
+        NB_HIP(c, hipMemcpyAsync(p.data(), c->pos64, n * sizeof(double4), hipMemcpyDeviceToHost, c->stream));
+        NB_HIP(c, hipMemcpyAsync(v.data(), c->vel64, n * sizeof(double4), hipMemcpyDeviceToHost, c->stream));
+        NB_HIP(c, hipStreamSynchronize(c->stream));
+        for (size_t i = 0; i < n; ++i) {
+            qx[i] = p[i].x; qy[i] = p[i].y; qz[i] = p[i].z;
+            vx[i] = v[i].x; vy[i] = v[i].y; vz[i] = v[i].z;
+        }
+    } else {
+        std::vector<float4> p(n), v(n);
+        NB_HIP(c, hipMemcpyAsync(p.data(), c->pos[c->cur], n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+        NB_HIP(c, hipMemcpyAsync(v.data(), c->vel, n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+        NB_HIP(c, hipStreamSynchronize(c->stream));
+        for (size_t i = 0; i < n; ++i) {
+            qx[i] = p[i].x; qy[i] = p[i].y; qz[i] = p[i].z;
+            vx[i] = v[i].x; vy[i] = v[i].y; vz[i] = v[i].z;
+        }
+    }
+    return NB_OK;
+}
+
+int nb_set_mass(nb_context* c, int index, double m) {
+    if (!c || index < 0 || index >= c->n) return NB_ERR_INVALID;
+    if (!c->have_state) return NB_ERR_STATE;
+    if (c->cfg.precision != NB_F64) return NB_ERR_INVALID;
+    if (int rc = bind(c)) return rc;
+    c->m_host[index] = m;
+    NB_HIP(c, hipMemcpyAsync(c->m + index, &c->m_host[index], sizeof(double), hipMemcpyHostToDevice, c->stream));
+    NB_HIP(c, hipStreamSynchronize(c->stream));
+    return NB_OK;
+}
+
+int nb_step(nb_context* c, int first_step, int count) {
+    if (!c || count < 0) return NB_ERR_INVALID;
+    if (!c->have_state) return NB_ERR_STATE;
+    if (int rc = bind(c)) return rc;
+    int rc = (c->cfg.precision == NB_F64) ? step_f64(c, first_step, count) : step_f32(c, count);
+    if (rc) return rc;
+    NB_HIP(c, hipStreamSynchronize(c->stream));
+    return NB_OK;
+}
+
+int nb_step_timed(nb_context* c, int first_step, int count, float* ms_per_step) {
+    if (!c || count <= 0 || !ms_per_step) return NB_ERR_INVALID;
+    if (!c->have_state) return NB_ERR_STATE;
+    if (int rc = bind(c)) return rc;
+    NB_HIP(c, hipEventRecord(c->ev0, c->stream));
+    int rc = (c->cfg.precision == NB_F64) ? step_f64(c, first_step, count) : step_f32(c, count);
+    if (rc) return rc;
+    NB_HIP(c, hipEventRecord(c->ev1, c->stream));
+    NB_HIP(c, hipEventSynchronize(c->ev1));
+    float ms = 0;
+    NB_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    *ms_per_step = ms / count;
+    return NB_OK;
+}
+
+int nb_accel(nb_context* c, int step, double* ax, double* ay, double* az) {
+    if (!c || !ax || !ay || !az) return NB_ERR_INVALID;
+    if (!c->have_state) return NB_ERR_STATE;
+    if (int rc = bind(c)) return rc;
+    const size_t n = (size_t)c->n;
+    if (c->cfg.precision == NB_F64) {
+        F64Args a = base_args(c, step);
+        a.acc_out = c->acc;
+        NB_HIP(c, (hipError_t)launch_f64(a, c->split, c->stream));
+        const size_t B = n * sizeof(double);
+        NB_HIP(c, hipMemcpyAsync(ax, c->acc, B, hipMemcpyDeviceToHost, c->stream));
+        NB_HIP(c, hipMemcpyAsync(ay, c->acc + n, B, hipMemcpyDeviceToHost, c->stream));
+        NB_HIP(c, hipMemcpyAsync(az, c->acc + 2 * n, B, hipMemcpyDeviceToHost, c->stream));
+        NB_HIP(c, hipStreamSynchronize(c->stream));
+    } else {
+        const bool acc64 = c->cfg.precision == NB_F32_ACC64;
+        F32Args a = f32_args(c);
+        NB_HIP(c, (hipError_t)launch_f32(a, auto_targets_per_lane(c->n, c->n_cus), acc64, true, c->stream));
+        if (acc64) {
+            std::vector<double4> h(n);
+            NB_HIP(c, hipMemcpyAsync(h.data(), c->acc32, n * sizeof(double4), hipMemcpyDeviceToHost, c->stream));
+            NB_HIP(c, hipStreamSynchronize(c->stream));
+            for (size_t i = 0; i < n; ++i) { ax[i] = h[i].x; ay[i] = h[i].y; az[i] = h[i].z; }
+        } else {
+            std::vector<float4> h(n);
+            NB_HIP(c, hipMemcpyAsync(h.data(), c->acc32, n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+            NB_HIP(c, hipStreamSynchronize(c->stream));
+            for (size_t i = 0; i < n; ++i) { ax[i] = h[i].x; ay[i] = h[i].y; az[i] = h[i].z; }
+        }
+    }
+    return NB_OK;
+}
+
+int nb_run_scenario(nb_context* c, const nb_scenario* s, nb_scenario_result* res) {
+    if (!c || !s || !res) return NB_ERR_INVALID;
+    if (c->cfg.precision != NB_F64) return NB_ERR_INVALID;
+    if (!c->have_state) return NB_ERR_STATE;
+    if (s->kind < NB_SCN_MIN_DIST || s->kind > NB_SCN_MISSILE) return NB_ERR_INVALID;
+    if (s->n_watch < 0 || s->n_watch > NB_MAX_WATCH) return NB_ERR_INVALID;
+    if (s->planet < 0 || s->planet >= c->n || s->asteroid < 0 || s->asteroid >= c->n) return NB_ERR_INVALID;
+    if (s->last_step < s->first_step) return NB_ERR_INVALID;
+    for (int k = 0; k < s->n_watch; ++k)
+        if (s->watch[k] < 0 || s->watch[k] >= c->n) return NB_ERR_INVALID;
+    if (int rc = bind(c)) return rc;
+
+    const size_t n = (size_t)c->n;
+    F64Scenario sc{};
+    sc.kind = s->kind;
+    sc.planet = s->planet;
+    sc.asteroid = s->asteroid;
+    sc.n_watch = (s->kind == NB_SCN_MIN_DIST) ? 0 : s->n_watch;
+    for (int k = 0; k < sc.n_watch; ++k) sc.watch[k] = s->watch[k];
+    sc.destroy_on_arrival = (s->kind == NB_SCN_MISSILE);
+    sc.R2 = s->planet_radius * s->planet_radius;            // nbody.cc:134
+    sc.missile_dstep = s->missile_speed * c->cfg.dt;        // hw5.cu:274
+
+    const bool want_snap = (s->kind == NB_SCN_FIRST_HIT) && sc.n_watch > 0;
+    if (want_snap && c->snap_slots < sc.n_watch) {
+        free_dev(c->snap_q);
+        free_dev(c->snap_v);
+        NB_HIP(c, hipMalloc(&c->snap_q, (size_t)sc.n_watch * 3 * n * sizeof(double)));
+        NB_HIP(c, hipMalloc(&c->snap_v, (size_t)sc.n_watch * 3 * n * sizeof(double)));
+        c->snap_slots = sc.n_watch;
+    }
+
+    F64Monitor* mh = c->mon_host;
+    mh->min_d2 = std::numeric_limits<double>::infinity();
+    mh->hit_step = -2;
+    for (int k = 0; k < MAX_WATCH; ++k) mh->arrival_step[k] = -2;
+    NB_HIP(c, hipMemcpyAsync(c->mon, mh, sizeof(F64Monitor), hipMemcpyHostToDevice, c->stream));
+    NB_HIP(c, hipStreamSynchronize(c->stream));
+
+    const int sync_every = s->sync_every > 0 ? s->sync_every : 2000;  // hw5.cu:72
+    const bool can_stop = s->kind != NB_SCN_MIN_DIST;
+    bool stopped = false;
+    int step = s->first_step + 1;
+    for (; step <= s->last_step; ++step) {
+        F64Args a = base_args(c, step);
+        a.scn = sc;
+        a.snap_q = want_snap ? c->snap_q : nullptr;
+        a.snap_v = want_snap ? c->snap_v : nullptr;
+        NB_HIP(c, (hipError_t)launch_f64(a, c->split, c->stream));
+        c->cur ^= 1;
+        if (can_stop && (step % sync_every == sync_every - 1)) {  // hw5.cu:398-402
+            NB_HIP(c, hipMemcpyAsync(&mh->hit_step, &c->mon->hit_step, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            NB_HIP(c, hipStreamSynchronize(c->stream));
+            if (mh->hit_step != -2) {
+                stopped = true;
+                break;
+            }
+        }
+    }
+    if (!stopped) {  // monitor of the final state (index last_step): nbody.cc's loop runs step <= n_steps
+        F64Args a = base_args(c, s->last_step + 1);
+        a.scn = sc;
+        a.do_update = 0;
+        a.snap_q = want_snap ? c->snap_q : nullptr;
+        a.snap_v = want_snap ? c->snap_v : nullptr;
+        NB_HIP(c, (hipError_t)launch_f64(a, c->split, c->stream));
+    }
+    NB_HIP(c, hipMemcpyAsync(mh, c->mon, sizeof(F64Monitor), hipMemcpyDeviceToHost, c->stream));
+    NB_HIP(c, hipStreamSynchronize(c->stream));
+
+    memset(res, 0, sizeof *res);
+    res->min_dist2 = mh->min_d2;
+    res->hit_step = mh->hit_step;
+    res->steps_done = stopped ? step : s->last_step;
+    for (int k = 0; k < NB_MAX_WATCH; ++k) {
+        res->arrival_step[k] = (k < sc.n_watch) ? mh->arrival_step[k] : -2;
+        res->missile_cost[k] = (res->arrival_step[k] != -2)
+                                   ? 1e5 + 1e3 * ((res->arrival_step[k] + 1) * c->cfg.dt)  // hw5.cu:305 ; nbody.cc:19
+                                   : 0.0;
+    }
+    return NB_OK;
+}
+
+int nb_restore_snapshot(nb_context* dst, nb_context* src, int slot) {
+    if (!dst || !src || slot < 0 || slot >= src->snap_slots) return NB_ERR_INVALID;
+    if (dst->n != src->n || dst->cfg.precision != NB_F64 || src->cfg.precision != NB_F64) return NB_ERR_INVALID;
+    const size_t n = (size_t)src->n;
+    std::vector<double> q(3 * n), v(3 * n);
+    if (int rc = bind(src)) return rc;
+    NB_HIP(src, hipMemcpy(q.data(), src->snap_q + (size_t)slot * 3 * n, 3 * n * sizeof(double), hipMemcpyDeviceToHost));
+    NB_HIP(src, hipMemcpy(v.data(), src->snap_v + (size_t)slot * 3 * n, 3 * n * sizeof(double), hipMemcpyDeviceToHost));
+    return nb_set_state(dst, q.data(), q.data() + n, q.data() + 2 * n, v.data(), v.data() + n, v.data() + 2 * n,
+                        src->m_host.data(), src->dev_host.data());
+}
+
+// ---------------------------------------------------------------- whole program
+int nb_solve(int n, int planet, int asteroid, const double* qx, const double* qy, const double* qz,
+             const double* vx, const double* vy, const double* vz, const double* m, const uint8_t* is_device,
+             const int* devices, int n_devices, nb_answer* out) {
+    if (n <= 0 || !qx || !qy || !qz || !vx || !vy || !vz || !m || !out) return NB_ERR_INVALID;
+    if (planet < 0 || planet >= n || asteroid < 0 || asteroid >= n) return NB_ERR_INVALID;
+    int ndev_gpu = 0;
+    if (nb_device_count(&ndev_gpu) != NB_OK) return NB_ERR_NO_DEVICE;
+    std::vector<int> gpus;
+    if (devices && n_devices > 0) gpus.assign(devices, devices + n_devices);
+    else gpus.push_back(0);
+    for (int g : gpus)
+        if (g < 0 || g >= ndev_gpu) return NB_ERR_NO_DEVICE;
+
+    std::vector<int> dev_idx;
+    for (int i = 0; i < n; ++i)
+        if (is_device && is_device[i]) dev_idx.push_back(i);
+    if ((int)dev_idx.size() > NB_MAX_WATCH) return NB_ERR_INVALID;
+
+    const int n_steps = 200000;  // nbody.cc:10
+    auto make_ctx = [&](int gpu, nb_context** c) -> int {
+        nb_config cfg;
+        nb_config_default(&cfg);
+        cfg.n = n;
+        cfg.device = gpu;
+        int rc = nb_create(c, &cfg);
+        if (rc) return rc;
+        return nb_set_state(*c, qx, qy, qz, vx, vy, vz, m, is_device);
+    };
+    auto base_scn = [&](int kind) {
+        nb_scenario s{};
+        s.kind = kind;
+        s.first_step = 0;
+        s.last_step = n_steps;
+        s.planet = planet;
+        s.asteroid = asteroid;
+        s.sync_every = 2000;
+        s.planet_radius = 1e7;  // nbody.cc:17
+        s.missile_speed = 1e6;  // nbody.cc:18
+        return s;
+    };
+
+    // Problem 1 (devices massless, nbody.cc:109-122) and Problem 2 (nbody.cc:124-138) are independent: run them
+    // concurrently, each on its own context/stream (and GPU when several are given) like hw5.cu:564-567.
+    nb_context *c1 = nullptr, *c2 = nullptr;
+    int rc1 = NB_OK, rc2 = NB_OK;
+    nb_scenario_result r1{}, r2{};
+    std::thread t1([&] {
+        rc1 = make_ctx(gpus[0], &c1);
+        for (size_t k = 0; k < dev_idx.size() && !rc1; ++k) rc1 = nb_set_mass(c1, dev_idx[k], 0.0);
+        if (!rc1) {
+            nb_scenario s = base_scn(NB_SCN_MIN_DIST);
+            rc1 = nb_run_scenario(c1, &s, &r1);
+        }
+    });
+    {
+        rc2 = make_ctx(gpus[gpus.size() > 1 ? 1 : 0], &c2);
+        if (!rc2) {
+            nb_scenario s = base_scn(NB_SCN_FIRST_HIT);
+            s.n_watch = (int)dev_idx.size();
+            for (size_t k = 0; k < dev_idx.size(); ++k) s.watch[k] = dev_idx[k];
+            rc2 = nb_run_scenario(c2, &s, &r2);
+        }
+    }
+
+    // Problem 3 (hw5.cu:568-602): every device whose missile arrives before the hit is tried from its snapshot,
+    // all of them concurrently; answer = feasible device with the smallest cost (strict <, hw5.cu:512).
+    out->hit_time_step = r2.hit_step;
+    out->gravity_device_id = -1;
+    out->missile_cost = 0;
+    int rc3 = NB_OK;
+    if (!rc2 && r2.hit_step != -2) {
+        const size_t D = dev_idx.size();
+        std::vector<nb_context*> cs(D, nullptr);
+        std::vector<int> rcs(D, NB_OK);
+        std::vector<nb_scenario_result> rs(D);
+        std::vector<std::thread> ts;
+        for (size_t k = 0; k < D; ++k) {
+            if (r2.arrival_step[k] == -2) continue;
+            // restore on this thread (reads c2), simulate on a worker
+            nb_config cfg;
+            nb_config_default(&cfg);
+            cfg.n = n;
+            cfg.device = gpus[k % gpus.size()];
+            rcs[k] = nb_create(&cs[k], &cfg);
+            if (!rcs[k]) rcs[k] = nb_restore_snapshot(cs[k], c2, (int)k);
+            if (rcs[k]) continue;
+            ts.emplace_back([&, k] {
+                nb_scenario s = base_scn(NB_SCN_MISSILE);
+                s.first_step = r2.arrival_step[k];
+                s.n_watch = 1;
+                s.watch[0] = dev_idx[k];
+                rcs[k] = nb_run_scenario(cs[k], &s, &rs[k]);
+            });
+        }
+        for (auto& t : ts) t.join();
+        double best = std::numeric_limits<double>::infinity();
+        for (size_t k = 0; k < D; ++k) {
+            if (rcs[k]) rc3 = rcs[k];
+            if (r2.arrival_step[k] != -2 && !rcs[k] && rs[k].hit_step == -2 && rs[k].arrival_step[0] != -2 &&
+                rs[k].missile_cost[0] < best) {
+                best = rs[k].missile_cost[0];
+                out->gravity_device_id = dev_idx[k];
+                out->missile_cost = best;
+            }
+            if (cs[k]) nb_destroy(cs[k]);
+        }
+    }
+    t1.join();
+    out->min_dist = std::sqrt(r1.min_dist2);  // nbody.cc:121 takes min of sqrt; sqrt is monotone
+    if (c1) nb_destroy(c1);
+    if (c2) nb_destroy(c2);
+    if (rc1) return rc1;
+    if (rc2) return rc2;
+    return rc3;
+}
+
+// ---------------------------------------------------------------- raw launches on caller-owned HBM
+static int check_launch(const nb_launch_f32* a, bool accel_only) {
+    if (!a || !a->src || a->n_src <= 0 || a->n_tgt <= 0 || a->tgt_off < 0 || a->tgt_off + a->n_tgt > a->n_src)
+        return NB_ERR_INVALID;
+    if (!(a->eps2 > 0.f)) return NB_ERR_INVALID;
+    if (accel_only ? !a->acc : (!a->out || (a->acc64 ? (!a->pos64 || !a->vel64) : !a->vel))) return NB_ERR_INVALID;
+    if (a->targets_per_lane != 0 && a->targets_per_lane != 1 && a->targets_per_lane != 2 && a->targets_per_lane != 4)
+        return NB_ERR_INVALID;
+    return NB_OK;
+}
+
+static int resolve_R(const nb_launch_f32* a) {
+    if (a->targets_per_lane) return a->targets_per_lane;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return auto_targets_per_lane(a->n_tgt, cus);
+}
+
+static F32Args to_args(const nb_launch_f32* a) {
+    F32Args k{};
+    k.src = (const float4*)a->src;
+    k.out = (float4*)a->out;
+    k.vel = (float4*)a->vel;
+    k.pos64 = (double4*)a->pos64;
+    k.vel64 = (double4*)a->vel64;
+    k.acc = a->acc;
+    k.n_src = a->n_src;
+    k.tgt_off = a->tgt_off;
+    k.n_tgt = a->n_tgt;
+    k.eps2 = a->eps2;
+    k.dt = a->dt;
+    return k;
+}
+
+int nb_launch_step_f32(const nb_launch_f32* a, void* hip_stream) {
+    if (int rc = check_launch(a, false)) return rc;
+    hipError_t e = (hipError_t)launch_f32(to_args(a), resolve_R(a), a->acc64 != 0, false, (hipStream_t)hip_stream);
+    return e == hipSuccess ? NB_OK : NB_ERR_HIP;
+}
+
+int nb_launch_accel_f32(const nb_launch_f32* a, void* hip_stream) {
+    if (int rc = check_launch(a, true)) return rc;
+    hipError_t e = (hipError_t)launch_f32(to_args(a), resolve_R(a), a->acc64 != 0, true, (hipStream_t)hip_stream);
+    return e == hipSuccess ? NB_OK : NB_ERR_HIP;
+}
+
+const char* nb_kernel_name_f32(const nb_launch_f32* a, int accel_only) {
+    if (!a) return "";
+    return kernel_name_f32(resolve_R(a), a->acc64 != 0, accel_only != 0);
+}
+
+}  // extern "C"

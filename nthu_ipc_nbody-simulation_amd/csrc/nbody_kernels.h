@@ -1,0 +1,67 @@
+// nbody_kernels.h — internal interface between the C-ABI layer (nbody_capi.cpp) and the gfx950 kernels.
+// Not installed; the public surface is include/nbody_amd.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nbk {
+
+constexpr int WG = 256;    // threads per workgroup: 4 wave64, one per SIMD of a CU
+constexpr int TILE = 256;  // source bodies staged in LDS per tile (one per thread, one coalesced 16-B load each)
+constexpr int MAX_WATCH = 16;
+
+// ---------------------------------------------------------------- fp32 / fp32+fp64acc (large N)
+struct F32Args {
+    const float4* src;  // [n_src] {x,y,z,G*m}
+    float4* out;        // [n_src] other ping-pong array; [tgt_off, tgt_off+n_tgt) written
+    float4* vel;        // [n_tgt]
+    double4* pos64;     // [n_tgt] fp64 masters (ACC64 only)
+    double4* vel64;     // [n_tgt]
+    void* acc;          // accel-only output
+    long n_src, tgt_off, n_tgt;
+    float eps2, dt;
+};
+// R = targets per lane (1,2,4); returns hipError_t as int
+int launch_f32(const F32Args& a, int R, bool acc64, bool accel_only, hipStream_t stream);
+const char* kernel_name_f32(int R, bool acc64, bool accel_only);
+int auto_targets_per_lane(long n_tgt, int n_cus);
+
+// ---------------------------------------------------------------- fp64 (testcases, n <= a few thousand)
+struct F64Monitor {  // device-resident scenario state, written by workgroup 0 only
+    double min_d2;
+    int hit_step;
+    int arrival_step[MAX_WATCH];
+    int pad;
+};
+
+struct F64Scenario {  // by-value kernel argument
+    int kind;         // nb_scenario_kind, or -1 = no monitor (plain nb_step)
+    int planet, asteroid;
+    int n_watch;
+    int watch[MAX_WATCH];
+    int destroy_on_arrival;  // MISSILE: watched device's mass becomes 0 from the step after its arrival
+    double R2;               // planet_radius^2
+    double missile_dstep;    // missile_speed * dt  (distance per step index; hw5.cu:274,303)
+};
+
+struct F64Args {
+    const double* qin;   // [3][n] planes x,y,z : state after step-1
+    double* qout;        // [3][n] state after `step`
+    double* v;           // [3][n] in place
+    const double* m;     // [n]
+    const double* coef;  // [n] 0.5 for `device` bodies else 0 : m_eff = m + (coef*m)*fst
+    double* acc_out;     // [3][n] accel-only mode (update skipped) or nullptr
+    double* snap_q;      // [n_watch][3][n] snapshots at missile arrival (FIRST_HIT) or nullptr
+    double* snap_v;
+    F64Monitor* mon;
+    int n;
+    int step;       // index of the step this launch computes (monitors run on state step-1 first)
+    int do_update;  // 0 = monitor-only launch for the final state
+    double fst;     // |sin(step*dt/6000)| computed on the host (glibc, as the CPU reference does)
+    double G, eps2, dt;
+    F64Scenario scn;
+};
+int launch_f64(const F64Args& a, int S, hipStream_t stream);  // S = lanes sharing one target (1..64, pow2)
+int auto_split_f64(int n, int n_cus);
+
+}  // namespace nbk

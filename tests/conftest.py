@@ -1,0 +1,47 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+TESTCASES = os.path.join(GOLDEN, "testcases")
+ALL_CASES = ["b20", "b30", "b40", "b50", "b60", "b70", "b80", "b90", "b100", "b200", "b512", "b1024"]
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: long CPU-only oracle runs, opt in with NB_SLOW=1")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU checker (oracle/). Test infrastructure: never imported by the product package."""
+    from oracle import oracle as O
+    O.build()
+    return O
+
+
+@pytest.fixture(scope="session")
+def nb():
+    """The product package, with its HIP library built."""
+    import nbody_amd
+    from nbody_amd import capi
+    if not os.path.exists(capi.library_path()):
+        import __graft_entry__
+        __graft_entry__.build()
+    return nbody_amd
+
+
+def case_path(case, ext):
+    return os.path.join(TESTCASES, f"{case}.{ext}")
+
+
+def read_golden(case):
+    with open(case_path(case, "out")) as f:
+        lines = f.read().split("\n")
+    dev, cost = lines[2].split()
+    return float(lines[0]), int(lines[1]), int(dev), float(cost), "\n".join(lines)
