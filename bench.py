@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--bodies", type=int, default=1 << 20)
     ap.add_argument("--precision", choices=["f32", "f32acc64"], default="f32")
     ap.add_argument("--targets-per-lane", type=int, default=0)
+    ap.add_argument("--j-split", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -111,7 +112,7 @@ def main():
         import numpy as np
         pos = np.concatenate([q.T, (synthetic.G * m)[:, None]], axis=1)
         vel = np.concatenate([v.T, np.zeros((hi - lo, 1))], axis=1)
-    compute = hip_compute(acc64, args.targets_per_lane)
+    compute = hip_compute(acc64, args.targets_per_lane, args.j_split)
     sysm = ShardedSystem(n, torch.from_numpy(pos), torch.from_numpy(vel), synthetic.EPS, synthetic.DT, device,
                          compute=compute, acc64=acc64)
 
@@ -154,7 +155,9 @@ def main():
         # dominant kernel: this rank's force+kick-drift launch = n_tgt x N pair evaluations, 20 flop each
         flops_launch = FLOP_PER_PAIR * sysm.n_tgt * (n - 1)
         achieved = flops_launch / (k_ms * 1e-3) / 1e12
-        kname = capi.kernel_name_f32(n, sysm.n_tgt, acc64, args.targets_per_lane)
+        ws_bytes = capi.workspace_bytes_f32(sysm.n_tgt, acc64)
+        kname = capi.kernel_name_f32(n, sysm.n_tgt, acc64, args.targets_per_lane, args.j_split, ws_bytes)
+        tpl, jsp = capi.plan_f32(n, sysm.n_tgt, acc64, args.targets_per_lane, args.j_split, ws_bytes)
         out = {
             "metric": "body-pair interactions/sec",
             "value": value,
@@ -174,7 +177,7 @@ def main():
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_TFLOPS, "traffic": load_traffic(n, world),
-                         "kernel": kname, "kernel_ms": k_ms, "flop_per_pair": FLOP_PER_PAIR,
+                         "kernel": kname, "kernel_ms": k_ms, "targets_per_lane": tpl, "j_split": jsp, "flop_per_pair": FLOP_PER_PAIR,
                          "bound_detail": "compute roofline = fp32 vector-FMA peak 157.3 TFLOP/s (== dense f32 MFMA "
                                          "peak); kernel is VALU + v_rsq_f32, MFMA deliberately unused"},
         }

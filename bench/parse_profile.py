@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Condense bench/profile.sh's rocprofv3 CSVs into profiles/<tag>_rocprof_summary.md and profiles/pmc_traffic.json.
+
+HBM bytes follow MI355X_MICROARCH.md §HBM: FETCH_SIZE / WRITE_SIZE are in KiB-units of the TCC's fabric-side
+request counters; on gfx950 FETCH_SIZE reports exactly half of a wide coalesced streaming read, so it is doubled.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+KERNEL = "nbody_force_f32"
+
+
+def rows(pattern):
+    for path in glob.glob(pattern, recursive=True):
+        with open(path, newline="") as f:
+            yield from csv.DictReader(f)
+
+
+def main():
+    out, tag = sys.argv[1], sys.argv[2]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lines = [f"# rocprofv3 summary `{tag}` (bench/profile.sh; raw CSVs under {out}, scratch)", ""]
+    # 1. kernel stats
+    stats = list(rows(f"{out}/stats/**/*kernel_stats.csv"))
+    lines += ["## --kernel-trace --stats", "", "| kernel | calls | total ms | avg ms | % |", "|---|---|---|---|---|"]
+    avg_ms = None
+    for r in stats:
+        name = r.get("Name", "")
+        avg = float(r.get("AverageNs", 0)) / 1e6
+        lines.append(f"| `{name[:90]}` | {r.get('Calls')} | {float(r.get('TotalDurationNs', 0)) / 1e6:.3f} | {avg:.4f} | {r.get('Percentage')} |")
+        if KERNEL in name and avg_ms is None:
+            avg_ms = avg
+    # per-dispatch registers from the trace
+    for r in rows(f"{out}/stats/**/*kernel_trace.csv"):
+        if KERNEL in r.get("Kernel_Name", ""):
+            lines += ["", f"force kernel dispatch: grid {r.get('Grid_Size_X')} x wg {r.get('Workgroup_Size_X')}, "
+                          f"VGPR {r.get('VGPR_Count')}, SGPR {r.get('SGPR_Count')}, LDS {r.get('LDS_Block_Size')} B, "
+                          f"scratch {r.get('Scratch_Size')}"]
+            break
+
+    # 2./3./4. counters: one row per dispatch and counter
+    def counter(sub, name):
+        vals = [float(r["Counter_Value"]) for r in rows(f"{out}/{sub}/**/*counter_collection.csv")
+                if r.get("Counter_Name") == name and KERNEL in r.get("Kernel_Name", "")]
+        return vals
+
+    fetch = counter("pmc_fetch", "FETCH_SIZE")
+    write = counter("pmc_write", "WRITE_SIZE")
+    lines += ["", "## --pmc (separate passes)", ""]
+    traffic = None
+    if fetch and write:
+        f_kib, w_kib = sum(fetch) / len(fetch), sum(write) / len(write)
+        traffic = (2.0 * f_kib + w_kib) * 1024.0
+        lines += [f"* FETCH_SIZE = {f_kib:.1f} KiB per launch (raw) -> x2 gfx950 correction = {2 * f_kib * 1024 / 1e6:.2f} MB read",
+                  f"* WRITE_SIZE = {w_kib:.1f} KiB per launch = {w_kib * 1024 / 1e6:.2f} MB written",
+                  f"* HBM traffic per launch = {traffic / 1e6:.2f} MB"]
+    sq = {}
+    for name in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY",
+                 "SQ_INSTS_LDS", "SQ_ACTIVE_INST_ANY", "GRBM_GUI_ACTIVE"):
+        v = counter("pmc_sq", name)
+        if v:
+            sq[name] = sum(v) / len(v)
+            lines.append(f"* {name} = {sq[name]:.4g} per launch")
+    if "SQ_ACTIVE_INST_VALU" in sq and "SQ_WAVE_CYCLES" in sq and sq["SQ_WAVE_CYCLES"]:
+        lines.append(f"* VALU-active share of wave cycles = {sq['SQ_ACTIVE_INST_VALU'] / sq['SQ_WAVE_CYCLES']:.3f}")
+    if "SQ_ACTIVE_INST_VALU" in sq and "SQ_BUSY_CYCLES" in sq and sq["SQ_BUSY_CYCLES"]:
+        lines.append(f"* SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES = {sq['SQ_ACTIVE_INST_VALU'] / sq['SQ_BUSY_CYCLES']:.3f}")
+    if avg_ms:
+        lines += ["", f"force kernel average duration (stats pass): **{avg_ms:.3f} ms**"]
+    os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
+    with open(os.path.join(root, "profiles", f"{tag}_rocprof_summary.md"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    # copy the small stats csv verbatim
+    for path in glob.glob(f"{out}/stats/**/*kernel_stats.csv", recursive=True):
+        with open(path) as src, open(os.path.join(root, "profiles", f"{tag}_kernel_stats.csv"), "w") as dst:
+            dst.write(src.read())
+    if traffic is not None:
+        tpath = os.path.join(root, "profiles", "pmc_traffic.json")
+        try:
+            t = json.load(open(tpath))
+        except Exception:
+            t = {}
+        key = os.environ.get("NB_TRAFFIC_KEY", "n1048576_p1")
+        t[key] = {"hbm_bytes_per_launch": traffic, "fetch_kib_raw": f_kib, "write_kib": w_kib, "tag": tag,
+                  "kernel_avg_ms": avg_ms}
+        json.dump(t, open(tpath, "w"), indent=1)
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,210 @@
+// force_variants.hip — experiment harness for the K1 inner loop (measurement tool, not product code).
+//
+// Times alternative formulations of the fp32 all-pairs loop on the same synthetic input and checks each against
+// variant 0's accelerations, so that a change only moves into csrc/nbody_kernels_f32.hip with a measured reason.
+//   V_LDS      the product loop: LDS tile, broadcast ds_read_b128, packed pairs, source-major order
+//   V_STAGE    same data path, but U sources x P pairs advanced stage by stage (dependent ops >= U*P apart)
+//   V_SMEM     no LDS: sources are wave-uniform, fetched with scalar loads (s_load_dwordx4..16) into SGPRs,
+//              software-prefetched one batch ahead
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o force_variants force_variants.hip
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+  fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f splat(float x) { return (v2f){x, x}; }
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+
+constexpr int WG = 256, TILE = 256;
+enum { V_LDS = 0, V_STAGE = 1, V_SMEM = 2 };
+
+template <int P>
+struct Acc {
+    v2f ax[P], ay[P], az[P], sx[P], sy[P], sz[P], cx[P], cy[P], cz[P];
+    __device__ void init() {
+#pragma unroll
+        for (int p = 0; p < P; ++p) ax[p] = ay[p] = az[p] = sx[p] = sy[p] = sz[p] = cx[p] = cy[p] = cz[p] = splat(0.f);
+    }
+    __device__ void flush() {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            v2f y, tt;
+            y = ax[p] - cx[p]; tt = sx[p] + y; cx[p] = (tt - sx[p]) - y; sx[p] = tt;
+            y = ay[p] - cy[p]; tt = sy[p] + y; cy[p] = (tt - sy[p]) - y; sy[p] = tt;
+            y = az[p] - cz[p]; tt = sz[p] + y; cz[p] = (tt - sz[p]) - y; sz[p] = tt;
+            ax[p] = ay[p] = az[p] = splat(0.f);
+        }
+    }
+};
+
+template <int P>
+__device__ __forceinline__ void interact(const float4 s, const v2f* xi, const v2f* yi, const v2f* zi, v2f eps2, Acc<P>& A) {
+    const v2f qx = splat(s.x), qy = splat(s.y), qz = splat(s.z), gm = splat(s.w);
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        v2f dx = qx - xi[p], dy = qy - yi[p], dz = qz - zi[p];
+        v2f r2 = pk_fma(dx, dx, eps2);
+        r2 = pk_fma(dy, dy, r2);
+        r2 = pk_fma(dz, dz, r2);
+        v2f rinv = (v2f){__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
+        v2f rinv2 = rinv * rinv;
+        v2f sc = gm * rinv;
+        sc = sc * rinv2;
+        A.ax[p] = pk_fma(dx, sc, A.ax[p]);
+        A.ay[p] = pk_fma(dy, sc, A.ay[p]);
+        A.az[p] = pk_fma(dz, sc, A.az[p]);
+    }
+}
+
+// U sources x P pairs, stage by stage
+template <int P, int U>
+__device__ __forceinline__ void interact_staged(const float4* s, const v2f* xi, const v2f* yi, const v2f* zi, v2f eps2,
+                                                Acc<P>& A) {
+    v2f dx[U][P], dy[U][P], dz[U][P], r2[U][P], ri[U][P], sc[U][P];
+#define ST(stmt) _Pragma("unroll") for (int u = 0; u < U; ++u) _Pragma("unroll") for (int p = 0; p < P; ++p) { stmt; }
+    ST(dx[u][p] = splat(s[u].x) - xi[p])
+    ST(dy[u][p] = splat(s[u].y) - yi[p])
+    ST(dz[u][p] = splat(s[u].z) - zi[p])
+    ST(r2[u][p] = pk_fma(dx[u][p], dx[u][p], eps2))
+    ST(r2[u][p] = pk_fma(dy[u][p], dy[u][p], r2[u][p]))
+    ST(r2[u][p] = pk_fma(dz[u][p], dz[u][p], r2[u][p]))
+    ST(ri[u][p] = ((v2f){__builtin_amdgcn_rsqf(r2[u][p].x), __builtin_amdgcn_rsqf(r2[u][p].y)}))
+    ST(sc[u][p] = splat(s[u].w) * ri[u][p])
+    ST(ri[u][p] = ri[u][p] * ri[u][p])
+    ST(sc[u][p] = sc[u][p] * ri[u][p])
+    ST(A.ax[p] = pk_fma(dx[u][p], sc[u][p], A.ax[p]))
+    ST(A.ay[p] = pk_fma(dy[u][p], sc[u][p], A.ay[p]))
+    ST(A.az[p] = pk_fma(dz[u][p], sc[u][p], A.az[p]))
+#undef ST
+}
+
+template <int P, int VAR, int U, int MINW>
+__global__ __launch_bounds__(WG, MINW) void force(const float4* __restrict__ src, long n_src, long n_tgt,
+                                                  float4* __restrict__ acc, float eps2s) {
+    __shared__ float4 tile[2][TILE];
+    constexpr int R = 2 * P;
+    const int t = threadIdx.x;
+    const long base = (long)blockIdx.x * (WG * R);
+    v2f xi[P], yi[P], zi[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        float4 b0 = src[min(base + (long)(2 * p) * WG + t, n_tgt - 1)];
+        float4 b1 = src[min(base + (long)(2 * p + 1) * WG + t, n_tgt - 1)];
+        xi[p] = (v2f){b0.x, b1.x}; yi[p] = (v2f){b0.y, b1.y}; zi[p] = (v2f){b0.z, b1.z};
+    }
+    Acc<P> A;
+    A.init();
+    const v2f eps2 = splat(eps2s);
+    const long ntiles = n_src / TILE;  // harness: n_src multiple of TILE
+
+    if (VAR == V_SMEM) {
+        // sources straight from memory with wave-uniform addresses (scalar loads), one batch prefetched ahead
+        float4 cur[U], nxt[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = src[u];
+        for (long j = 0; j < n_src; j += U) {
+            const long jn = (j + U < n_src) ? j + U : 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) nxt[u] = src[jn + u];
+#pragma unroll
+            for (int u = 0; u < U; ++u) interact<P>(cur[u], xi, yi, zi, eps2, A);
+#pragma unroll
+            for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+            if (((j + U) & (TILE - 1)) == 0) A.flush();
+        }
+    } else {
+        tile[0][t] = src[t];
+        __syncthreads();
+        for (long k = 0; k < ntiles; ++k) {
+            const int cur = (int)(k & 1);
+            float4 nxt;
+            if (k + 1 < ntiles) nxt = src[(k + 1) * TILE + t];
+            if (VAR == V_LDS) {
+#pragma unroll U
+                for (int j = 0; j < TILE; ++j) interact<P>(tile[cur][j], xi, yi, zi, eps2, A);
+            } else {
+#pragma unroll 1
+                for (int j = 0; j < TILE; j += U) {
+                    float4 s[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) s[u] = tile[cur][j + u];
+                    interact_staged<P, U>(s, xi, yi, zi, eps2, A);
+                }
+            }
+            A.flush();
+            if (k + 1 < ntiles) tile[cur ^ 1][t] = nxt;
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        long i = base + (long)r * WG + t;
+        if (i < n_tgt) acc[i] = make_float4(A.sx[r >> 1][r & 1], A.sy[r >> 1][r & 1], A.sz[r >> 1][r & 1], 0.f);
+    }
+}
+
+static std::vector<float4> ref_acc;
+
+template <int P, int VAR, int U, int MINW>
+static void run(const char* name, const float4* d_src, long n_src, long n_tgt, float4* d_acc) {
+    const long blocks = (n_tgt + WG * 2 * P - 1) / (WG * 2 * P);
+    auto launch = [&] { hipLaunchKernelGGL((force<P, VAR, U, MINW>), dim3(blocks), dim3(WG), 0, 0, d_src, n_src, n_tgt, d_acc, 1e-6f); };
+    launch();
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float best = 1e30f, sum = 0;
+    const int reps = 5;
+    for (int r = 0; r < reps; ++r) {
+        CK(hipEventRecord(e0)); launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = std::min(best, ms); sum += ms;
+    }
+    std::vector<float4> h(n_tgt);
+    CK(hipMemcpy(h.data(), d_acc, n_tgt * sizeof(float4), hipMemcpyDeviceToHost));
+    double maxrel = 0;
+    if (ref_acc.empty()) ref_acc = h;
+    for (long i = 0; i < n_tgt; ++i) {
+        double d = std::fabs(h[i].x - ref_acc[i].x) + std::fabs(h[i].y - ref_acc[i].y) + std::fabs(h[i].z - ref_acc[i].z);
+        double s = std::fabs(ref_acc[i].x) + std::fabs(ref_acc[i].y) + std::fabs(ref_acc[i].z) + 1e-30;
+        maxrel = std::max(maxrel, d / s);
+    }
+    double pairs = (double)n_tgt * n_src;
+    double cyc = best * 1e-3 * 2.4e9 * 1024.0 / (pairs / 64.0);
+    printf("%-34s blocks=%5ld best %8.3f ms avg %8.3f ms  %.3e pairs/s  %5.1f%% of 157.3TF  ~%5.2f cyc/64pairs@2.4GHz  maxdiff_vs_v0 %.2e\n",
+           name, blocks, best, sum / reps, pairs / (best * 1e-3), pairs / (best * 1e-3) * 20 / 157.3e12 * 100, cyc, maxrel);
+}
+
+int main(int argc, char** argv) {
+    const long n_tgt = 1 << 20, n_src = (argc > 1) ? atol(argv[1]) : (1 << 17);
+    std::vector<float4> h(n_tgt);
+    unsigned long long x = 42;
+    auto rnd = [&] { x += 0x9E3779B97F4A7C15ull; unsigned long long z = x; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+                     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31; return (double)(z >> 11) * (1.0 / 9007199254740992.0); };
+    for (long i = 0; i < n_tgt; ++i) h[i] = make_float4(2 * rnd() - 1, 2 * rnd() - 1, 2 * rnd() - 1, (0.5 + rnd()) / n_tgt);
+    float4 *d_src, *d_acc;
+    CK(hipMalloc(&d_src, n_tgt * sizeof(float4))); CK(hipMalloc(&d_acc, n_tgt * sizeof(float4)));
+    CK(hipMemcpy(d_src, h.data(), n_tgt * sizeof(float4), hipMemcpyHostToDevice));
+    printf("n_tgt=%ld n_src=%ld\n", n_tgt, n_src);
+    run<2, V_LDS, 4, 4>("LDS   P=2 unroll4 (product)", d_src, n_src, n_tgt, d_acc);
+    run<2, V_LDS, 8, 4>("LDS   P=2 unroll8", d_src, n_src, n_tgt, d_acc);
+    run<2, V_LDS, 2, 4>("LDS   P=2 unroll2", d_src, n_src, n_tgt, d_acc);
+    run<1, V_LDS, 4, 8>("LDS   P=1 unroll4 8w", d_src, n_src, n_tgt, d_acc);
+    run<4, V_LDS, 4, 2>("LDS   P=4 unroll4 2w", d_src, n_src, n_tgt, d_acc);
+    run<2, V_STAGE, 2, 4>("STAGE P=2 U=2", d_src, n_src, n_tgt, d_acc);
+    run<2, V_STAGE, 4, 3>("STAGE P=2 U=4 3w", d_src, n_src, n_tgt, d_acc);
+    run<1, V_STAGE, 4, 6>("STAGE P=1 U=4 6w", d_src, n_src, n_tgt, d_acc);
+    run<1, V_STAGE, 8, 4>("STAGE P=1 U=8 4w", d_src, n_src, n_tgt, d_acc);
+    run<4, V_STAGE, 2, 2>("STAGE P=4 U=2 2w", d_src, n_src, n_tgt, d_acc);
+    run<2, V_SMEM, 4, 4>("SMEM  P=2 U=4", d_src, n_src, n_tgt, d_acc);
+    run<2, V_SMEM, 8, 4>("SMEM  P=2 U=8", d_src, n_src, n_tgt, d_acc);
+    run<1, V_SMEM, 4, 8>("SMEM  P=1 U=4 8w", d_src, n_src, n_tgt, d_acc);
+    run<4, V_SMEM, 4, 2>("SMEM  P=4 U=4 2w", d_src, n_src, n_tgt, d_acc);
+    run<3, V_LDS, 4, 3>("LDS   P=3 unroll4 3w", d_src, n_src, n_tgt, d_acc);
+    run<3, V_SMEM, 4, 3>("SMEM  P=3 U=4 3w", d_src, n_src, n_tgt, d_acc);
+    return 0;
+}

@@ -149,18 +149,26 @@ typedef struct nb_launch_f32 {
     void* pos64; /* NULL unless acc64 */
     void* vel64; /* NULL unless acc64 */
     void* acc;   /* nb_launch_accel_f32 only: float4[n_tgt] {ax,ay,az,0} (acc64: double4[n_tgt]) */
+    void* workspace; /* optional scratch for the j-split (partial sums); NULL -> never split */
+    int64_t workspace_bytes; /* its size; nb_workspace_bytes_f32() is always enough */
     int64_t n_src;
     int64_t tgt_off;
     int64_t n_tgt;
     float eps2;
     float dt;
     int32_t acc64;            /* 0 = NB_F32, 1 = NB_F32_ACC64 */
-    int32_t targets_per_lane; /* 0 = auto; 1, 2 or 4 */
+    int32_t targets_per_lane; /* 0 = auto; 2, 4 or 8 (packed pairs of targets per lane) */
+    int32_t j_split;          /* 0 = auto; 1..16 workgroups share a target block, each over a slice of the sources */
+    int32_t reserved;
 } nb_launch_f32;
 int nb_launch_step_f32(const nb_launch_f32* a, void* hip_stream);  /* force + fused kick-drift */
 int nb_launch_accel_f32(const nb_launch_f32* a, void* hip_stream); /* force only -> a->acc */
 /* name of the kernel symbol the two launches above resolve to for these arguments (for matching rocprofv3 rows) */
 const char* nb_kernel_name_f32(const nb_launch_f32* a, int accel_only);
+/* the register blocking and source split the launches above will use for these arguments */
+int nb_plan_f32(const nb_launch_f32* a, int* targets_per_lane, int* j_split);
+/* workspace size that allows any split for n_tgt targets */
+int64_t nb_workspace_bytes_f32(int64_t n_tgt, int acc64);
 
 #ifdef __cplusplus
 }

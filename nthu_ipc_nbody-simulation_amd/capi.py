@@ -38,9 +38,10 @@ class NbAnswer(C.Structure):
 
 class NbLaunchF32(C.Structure):
     _fields_ = [("src", C.c_void_p), ("out", C.c_void_p), ("vel", C.c_void_p), ("pos64", C.c_void_p),
-                ("vel64", C.c_void_p), ("acc", C.c_void_p), ("n_src", C.c_int64), ("tgt_off", C.c_int64),
+                ("vel64", C.c_void_p), ("acc", C.c_void_p), ("workspace", C.c_void_p),
+                ("workspace_bytes", C.c_int64), ("n_src", C.c_int64), ("tgt_off", C.c_int64),
                 ("n_tgt", C.c_int64), ("eps2", C.c_float), ("dt", C.c_float), ("acc64", C.c_int32),
-                ("targets_per_lane", C.c_int32)]
+                ("targets_per_lane", C.c_int32), ("j_split", C.c_int32), ("reserved", C.c_int32)]
 
 
 # every symbol include/nbody_amd.h declares: (restype, argtypes)
@@ -65,6 +66,8 @@ SYMBOLS = {
     "nb_launch_step_f32": (C.c_int, [C.POINTER(NbLaunchF32), C.c_void_p]),
     "nb_launch_accel_f32": (C.c_int, [C.POINTER(NbLaunchF32), C.c_void_p]),
     "nb_kernel_name_f32": (C.c_char_p, [C.POINTER(NbLaunchF32), C.c_int]),
+    "nb_plan_f32": (C.c_int, [C.POINTER(NbLaunchF32), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "nb_workspace_bytes_f32": (C.c_int64, [C.c_int64, C.c_int]),
 }
 
 
@@ -227,15 +230,35 @@ def solve(n, planet, asteroid, q, v, m, is_device, devices=None):
     return ans.min_dist, ans.hit_time_step, ans.gravity_device_id, ans.missile_cost
 
 
-def launch_f32(src_ptr, out_ptr, n_src, tgt_off, n_tgt, eps2, dt, stream, vel_ptr=0, pos64_ptr=0, vel64_ptr=0,
-               acc_ptr=0, acc64=False, targets_per_lane=0, accel_only=False):
-    """Raw launch on caller-owned device memory (pointers as ints, e.g. torch.Tensor.data_ptr())."""
-    a = NbLaunchF32(src_ptr, out_ptr or None, vel_ptr or None, pos64_ptr or None, vel64_ptr or None,
-                    acc_ptr or None, n_src, tgt_off, n_tgt, eps2, dt, int(acc64), targets_per_lane)
+def _launch_struct(src_ptr, out_ptr, n_src, tgt_off, n_tgt, eps2, dt, vel_ptr=0, pos64_ptr=0, vel64_ptr=0, acc_ptr=0,
+                   acc64=False, targets_per_lane=0, j_split=0, workspace_ptr=0, workspace_bytes=0):
+    return NbLaunchF32(src_ptr or None, out_ptr or None, vel_ptr or None, pos64_ptr or None, vel64_ptr or None,
+                       acc_ptr or None, workspace_ptr or None, workspace_bytes, n_src, tgt_off, n_tgt, eps2, dt,
+                       int(acc64), targets_per_lane, j_split, 0)
+
+
+def launch_f32(src_ptr, out_ptr, n_src, tgt_off, n_tgt, eps2, dt, stream, accel_only=False, **kw):
+    """Raw launch on caller-owned device memory (pointers as ints, e.g. torch.Tensor.data_ptr()).
+    kw: vel_ptr, pos64_ptr, vel64_ptr, acc_ptr, acc64, targets_per_lane, j_split, workspace_ptr, workspace_bytes."""
+    a = _launch_struct(src_ptr, out_ptr, n_src, tgt_off, n_tgt, eps2, dt, **kw)
     f = lib().nb_launch_accel_f32 if accel_only else lib().nb_launch_step_f32
     _check(f(C.byref(a), C.c_void_p(stream)), "nb_launch_accel_f32" if accel_only else "nb_launch_step_f32")
 
 
-def kernel_name_f32(n_src, n_tgt, acc64=False, targets_per_lane=0, accel_only=False):
-    a = NbLaunchF32(None, None, None, None, None, None, n_src, 0, n_tgt, 1.0, 1.0, int(acc64), targets_per_lane)
+def plan_f32(n_src, n_tgt, acc64=False, targets_per_lane=0, j_split=0, workspace_bytes=0):
+    """(targets_per_lane, j_split) the launches will use; workspace_bytes > 0 means a workspace will be passed."""
+    a = _launch_struct(1, 0, n_src, 0, n_tgt, 1.0, 1.0, acc64=acc64, targets_per_lane=targets_per_lane,
+                       j_split=j_split, workspace_ptr=1 if workspace_bytes else 0, workspace_bytes=workspace_bytes)
+    r, j = C.c_int(), C.c_int()
+    _check(lib().nb_plan_f32(C.byref(a), C.byref(r), C.byref(j)), "nb_plan_f32")
+    return r.value, j.value
+
+
+def workspace_bytes_f32(n_tgt, acc64=False):
+    return lib().nb_workspace_bytes_f32(n_tgt, int(acc64))
+
+
+def kernel_name_f32(n_src, n_tgt, acc64=False, targets_per_lane=0, j_split=0, workspace_bytes=0, accel_only=False):
+    a = _launch_struct(1, 0, n_src, 0, n_tgt, 1.0, 1.0, acc64=acc64, targets_per_lane=targets_per_lane,
+                       j_split=j_split, workspace_ptr=1 if workspace_bytes else 0, workspace_bytes=workspace_bytes)
     return lib().nb_kernel_name_f32(C.byref(a), int(accel_only)).decode()

@@ -53,6 +53,7 @@ struct nb_context {
     double4* pos64 = nullptr;
     double4* vel64 = nullptr;
     void* acc32 = nullptr;
+    void* partial = nullptr;  // j-split workspace [MAX_JSPLIT][n] double4
 };
 
 namespace {
@@ -88,6 +89,7 @@ void release(nb_context* c) {
     free_dev(c->mon); free_dev(c->snap_q); free_dev(c->snap_v);
     free_dev(c->pos[0]); free_dev(c->pos[1]); free_dev(c->vel); free_dev(c->pos64); free_dev(c->vel64);
     free_dev(c->acc32);
+    free_dev(c->partial);
     if (c->mon_host) (void)hipHostFree(c->mon_host);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -130,6 +132,7 @@ F32Args f32_args(nb_context* c) {
     a.pos64 = c->pos64;
     a.vel64 = c->vel64;
     a.acc = c->acc32;
+    a.partial = c->partial;
     a.n_src = c->n;
     a.tgt_off = 0;
     a.n_tgt = c->n;
@@ -140,10 +143,10 @@ F32Args f32_args(nb_context* c) {
 
 int step_f32(nb_context* c, int count) {
     const bool acc64 = c->cfg.precision == NB_F32_ACC64;
-    const int R = auto_targets_per_lane(c->n, c->n_cus);
+    const F32Plan plan = plan_f32(c->n, c->n, c->n_cus, 0, 0, c->partial != nullptr);
     for (int s = 0; s < count; ++s) {
         F32Args a = f32_args(c);
-        NB_HIP(c, (hipError_t)launch_f32(a, R, acc64, false, c->stream));
+        NB_HIP(c, (hipError_t)launch_f32(a, plan, acc64, false, c->stream));
         c->cur ^= 1;
     }
     return NB_OK;
@@ -224,6 +227,8 @@ int nb_create(nb_context** out, const nb_config* cfg) {
         NB_HIP(c, hipMalloc(&c->pos[1], n * sizeof(float4)));
         NB_HIP(c, hipMalloc(&c->vel, n * sizeof(float4)));
         NB_HIP(c, hipMalloc(&c->acc32, n * sizeof(double4)));
+        if (plan_f32(c->n, c->n, c->n_cus, 0, 0, true).j_split > 1)
+            NB_HIP(c, hipMalloc(&c->partial, (size_t)MAX_JSPLIT * n * sizeof(double4)));
         if (cfg->precision == NB_F32_ACC64) {
             NB_HIP(c, hipMalloc(&c->pos64, n * sizeof(double4)));
             NB_HIP(c, hipMalloc(&c->vel64, n * sizeof(double4)));
@@ -382,7 +387,8 @@ int nb_accel(nb_context* c, int step, double* ax, double* ay, double* az) {
     } else {
         const bool acc64 = c->cfg.precision == NB_F32_ACC64;
         F32Args a = f32_args(c);
-        NB_HIP(c, (hipError_t)launch_f32(a, auto_targets_per_lane(c->n, c->n_cus), acc64, true, c->stream));
+        NB_HIP(c, (hipError_t)launch_f32(a, plan_f32(c->n, c->n, c->n_cus, 0, 0, c->partial != nullptr), acc64, true,
+                                         c->stream));
         if (acc64) {
             std::vector<double4> h(n);
             NB_HIP(c, hipMemcpyAsync(h.data(), c->acc32, n * sizeof(double4), hipMemcpyDeviceToHost, c->stream));
@@ -616,16 +622,21 @@ static int check_launch(const nb_launch_f32* a, bool accel_only) {
         return NB_ERR_INVALID;
     if (!(a->eps2 > 0.f)) return NB_ERR_INVALID;
     if (accel_only ? !a->acc : (!a->out || (a->acc64 ? (!a->pos64 || !a->vel64) : !a->vel))) return NB_ERR_INVALID;
-    if (a->targets_per_lane != 0 && a->targets_per_lane != 1 && a->targets_per_lane != 2 && a->targets_per_lane != 4)
-        return NB_ERR_INVALID;
+    const int r = a->targets_per_lane;
+    if (r != 0 && r != 2 && r != 4 && r != 8) return NB_ERR_INVALID;
+    if (a->j_split < 0 || a->j_split > MAX_JSPLIT) return NB_ERR_INVALID;
+    if (a->j_split > 1 && !a->workspace) return NB_ERR_INVALID;
     return NB_OK;
 }
 
-static int resolve_R(const nb_launch_f32* a) {
-    if (a->targets_per_lane) return a->targets_per_lane;
+static F32Plan resolve_plan(const nb_launch_f32* a) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    return auto_targets_per_lane(a->n_tgt, cus);
+    F32Plan p = plan_f32(a->n_tgt, a->n_src, cus, a->targets_per_lane, a->j_split, a->workspace != nullptr);
+    // the caller's workspace must hold j_split slices of n_tgt records
+    const size_t rec = a->acc64 ? sizeof(double4) : sizeof(float4);
+    while (p.j_split > 1 && (size_t)p.j_split * (size_t)a->n_tgt * rec > (size_t)a->workspace_bytes) p.j_split >>= 1;
+    return p;
 }
 
 static F32Args to_args(const nb_launch_f32* a) {
@@ -636,6 +647,7 @@ static F32Args to_args(const nb_launch_f32* a) {
     k.pos64 = (double4*)a->pos64;
     k.vel64 = (double4*)a->vel64;
     k.acc = a->acc;
+    k.partial = a->workspace;
     k.n_src = a->n_src;
     k.tgt_off = a->tgt_off;
     k.n_tgt = a->n_tgt;
@@ -646,19 +658,31 @@ static F32Args to_args(const nb_launch_f32* a) {
 
 int nb_launch_step_f32(const nb_launch_f32* a, void* hip_stream) {
     if (int rc = check_launch(a, false)) return rc;
-    hipError_t e = (hipError_t)launch_f32(to_args(a), resolve_R(a), a->acc64 != 0, false, (hipStream_t)hip_stream);
+    hipError_t e = (hipError_t)launch_f32(to_args(a), resolve_plan(a), a->acc64 != 0, false, (hipStream_t)hip_stream);
     return e == hipSuccess ? NB_OK : NB_ERR_HIP;
 }
 
 int nb_launch_accel_f32(const nb_launch_f32* a, void* hip_stream) {
     if (int rc = check_launch(a, true)) return rc;
-    hipError_t e = (hipError_t)launch_f32(to_args(a), resolve_R(a), a->acc64 != 0, true, (hipStream_t)hip_stream);
+    hipError_t e = (hipError_t)launch_f32(to_args(a), resolve_plan(a), a->acc64 != 0, true, (hipStream_t)hip_stream);
     return e == hipSuccess ? NB_OK : NB_ERR_HIP;
 }
 
 const char* nb_kernel_name_f32(const nb_launch_f32* a, int accel_only) {
     if (!a) return "";
-    return kernel_name_f32(resolve_R(a), a->acc64 != 0, accel_only != 0);
+    return kernel_name_f32(resolve_plan(a), a->acc64 != 0, accel_only != 0);
+}
+
+int nb_plan_f32(const nb_launch_f32* a, int* targets_per_lane, int* j_split) {
+    if (!a || a->n_src <= 0 || a->n_tgt <= 0) return NB_ERR_INVALID;
+    F32Plan p = resolve_plan(a);
+    if (targets_per_lane) *targets_per_lane = p.targets_per_lane;
+    if (j_split) *j_split = p.j_split;
+    return NB_OK;
+}
+
+int64_t nb_workspace_bytes_f32(int64_t n_tgt, int acc64) {
+    return (int64_t)MAX_JSPLIT * n_tgt * (int64_t)(acc64 ? sizeof(double4) : sizeof(float4));
 }
 
 }  // extern "C"

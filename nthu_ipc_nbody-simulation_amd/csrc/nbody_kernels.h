@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 namespace nbk {
 
@@ -18,13 +19,18 @@ struct F32Args {
     double4* pos64;     // [n_tgt] fp64 masters (ACC64 only)
     double4* vel64;     // [n_tgt]
     void* acc;          // accel-only output
+    void* partial;      // j-split workspace: float4 (double4 if acc64) [j_split][n_tgt]
     long n_src, tgt_off, n_tgt;
     float eps2, dt;
 };
-// R = targets per lane (1,2,4); returns hipError_t as int
-int launch_f32(const F32Args& a, int R, bool acc64, bool accel_only, hipStream_t stream);
-const char* kernel_name_f32(int R, bool acc64, bool accel_only);
-int auto_targets_per_lane(long n_tgt, int n_cus);
+constexpr int MAX_JSPLIT = 16;
+struct F32Plan {
+    int targets_per_lane = 4;  // 2, 4 or 8 (one, two or four packed pairs per lane)
+    int j_split = 1;           // workgroups sharing one target block, each over 1/j_split of the sources
+};
+F32Plan plan_f32(long n_tgt, long n_src, int n_cus, int force_tpl, int force_js, bool have_workspace);
+int launch_f32(const F32Args& a, const F32Plan& plan, bool acc64, bool accel_only, hipStream_t stream);  // hipError_t
+const char* kernel_name_f32(const F32Plan& plan, bool acc64, bool accel_only);
 
 // ---------------------------------------------------------------- fp64 (testcases, n <= a few thousand)
 struct F64Monitor {  // device-resident scenario state, written by workgroup 0 only

@@ -6,141 +6,234 @@
 // accel/kick/drift phases of run_step (samples/nbody.cc:56-88), for large synthetic N.
 //
 // Design:
-//  * owner-computes: a lane owns R whole target bodies (R = 1,2,4) in registers; no atomics, no global `a`
-//    array, bitwise run-to-run reproducible.
+//  * owner-computes: a lane owns R whole target bodies in registers; no atomics, no global `a` array,
+//    bitwise run-to-run reproducible.
 //  * sources stream through LDS in tiles of 256 float4 {x,y,z,G*m}: every lane issues ONE coalesced 16-byte
-//    global load per tile (a wave reads 1 KiB contiguous), the tile is double-buffered so one s_barrier per
-//    tile suffices and the next tile's HBM/L2 load is in flight while the current one is consumed.
-//  * the inner loop reads the tile with wave-uniform (broadcast) ds_read_b128, conflict-free, and feeds R
-//    interactions per read: 3 sub, 3 fma, v_rsq_f32, 3 mul, 3 fma = 12 VALU + 1 transcendental per pair.
-//    Measured issue costs on MI355X (profiles/r01_ubench_valu_rate.txt): fp32 VALU 2 cycles per wave64
-//    instruction per SIMD with >= 2 resident waves, v_rsq_f32 8 cycles, no overlap between them -> floor of
-//    32 SIMD-cycles per 64 pairs = 62 % of the 157.3 TFLOP/s fp32 peak in the 20-flop/pair convention.
+//    global load per tile (a wave reads 1 KiB contiguous); the tile is double-buffered so one s_barrier per
+//    tile suffices and the next tile's load is in flight while the current one is consumed.
+//  * the inner loop reads the tile with wave-uniform (broadcast) ds_read_b128 and feeds R interactions per
+//    read.  Targets are held two-per-register-pair (ext_vector float2) so the loop is PACKED fp32:
+//    per source and target pair 3 v_pk_add, 3 v_pk_fma, 2 v_rsq_f32, 3 v_pk_mul, 3 v_pk_fma
+//    = 12 packed VALU + 2 transcendentals per 2 pairs.
+//    Why packed (profiles/r01_ubench_valu_rate.txt): a packed op costs 4 SIMD-cycles for 128 lane-ops, a
+//    scalar op 2 cycles for 64 — same arithmetic rate — but ONE wave can only issue an instruction every
+//    ~5 cycles, so the scalar form needs >= 3 always-ready waves per SIMD to keep the pipe full (measured
+//    40-43 cycles per 64 pairs at 4-8 waves) while the packed form gets there with 2 (33 cycles measured,
+//    floor 12*2 + 8 = 32).  v_rsq_f32 costs 8 cycles and does not overlap other VALU work: the floor is
+//    62 % of the 157.3 TFLOP/s fp32 peak in the 20-flop/pair convention.
+//  * summation is two-level: the 256 contributions of a tile are summed in fp32 registers, then the tile's
+//    partial is added to the running sum — compensated (Kahan) in NB_F32, in fp64 in NB_F32_ACC64 — so the
+//    rounding error does not grow with sqrt(N) (plain fp32 running sums measured 2.6e-5 * sum|a_ij| at N=2^20).
+//  * j-split: when the targets alone cannot fill the chip (multi-GPU shards), blockIdx.y splits the source
+//    range; partial sums go to a workspace and nbody_reduce_update_f32 combines them and does the update.
 //  * MFMA deliberately unused: the only GEMM-shaped reformulation (sum_j s_ij x_j - x_i sum_j s_ij) cancels
 //    catastrophically for close pairs; the loop is rsqrt-bound VALU work.
-//  * every workgroup streams the whole source array at the same pace, so a tile is fetched from HBM /
-//    Infinity Cache once per XCD and then served by that XCD's L2 to its other ~127 resident workgroups:
-//    HBM traffic ~ 8 x 16 B x N per step; no XCD-aware block remap is needed (all blocks share all sources).
+//  * every workgroup streams the whole source array at the same pace, so a tile is fetched once per XCD and
+//    then served by that XCD's L2 / the Infinity Cache to its other resident workgroups; no XCD-aware block
+//    remap is needed (all blocks share all sources).
 //  * kick-drift fused: v += a*dt ; q_new = q + v*dt written to the OTHER position array (ping-pong), because
 //    other workgroups still read the old positions — the barrier the reference gets from its kernel boundary
 //    between hw5.cu:371 and :375.
-//  * NB_F32_ACC64: fp32 pair arithmetic; each tile's 256 partial sums are added into fp64 accumulators
-//    (3R v_add_f64 per 256R pairs) and q,v masters are integrated in fp64.
 #include "nbody_kernels.h"
 
 namespace nbk {
 
-template <int R, bool ACC64, bool ACCEL_ONLY>
-__global__ __launch_bounds__(WG, (R == 4 ? 4 : 8)) void nbody_force_f32(F32Args a) {
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2f splat(float x) { return (v2f){x, x}; }
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+
+// ---- shared epilogue: store accelerations, or kick + drift (samples/nbody.cc:76-88) ----
+template <bool ACC64, bool ACCEL_ONLY, typename ACC_T>
+__device__ __forceinline__ void finish_target(const F32Args& a, long i, ACC_T ax, ACC_T ay, ACC_T az, float xi,
+                                              float yi, float zi, float gmi) {
+    if (ACCEL_ONLY) {
+        if (ACC64) ((double4*)a.acc)[i] = make_double4((double)ax, (double)ay, (double)az, 0.0);
+        else ((float4*)a.acc)[i] = make_float4((float)ax, (float)ay, (float)az, 0.f);
+    } else if (ACC64) {
+        const double dt = (double)a.dt;
+        double4 v = a.vel64[i];
+        double4 p = a.pos64[i];
+        v.x += (double)ax * dt; v.y += (double)ay * dt; v.z += (double)az * dt;
+        p.x += v.x * dt; p.y += v.y * dt; p.z += v.z * dt;
+        a.vel64[i] = v;
+        a.pos64[i] = p;
+        a.out[a.tgt_off + i] = make_float4((float)p.x, (float)p.y, (float)p.z, gmi);
+    } else {
+        const float dt = a.dt;
+        float4 v = a.vel[i];
+        v.x = __builtin_fmaf((float)ax, dt, v.x);
+        v.y = __builtin_fmaf((float)ay, dt, v.y);
+        v.z = __builtin_fmaf((float)az, dt, v.z);
+        a.vel[i] = v;
+        a.out[a.tgt_off + i] = make_float4(__builtin_fmaf(v.x, dt, xi), __builtin_fmaf(v.y, dt, yi),
+                                           __builtin_fmaf(v.z, dt, zi), gmi);
+    }
+}
+
+// P = target PAIRS per lane (R = 2P targets).  SPLIT: blockIdx.y selects a slice of the source tiles and the
+// partial sums go to a.partial instead of the epilogue.
+template <int P, bool ACC64, bool ACCEL_ONLY, bool SPLIT>
+__global__ __launch_bounds__(WG, (P >= 4 ? 2 : 4)) void nbody_force_f32(F32Args a) {
     __shared__ float4 tile[2][TILE];
+    constexpr int R = 2 * P;
     const int t = threadIdx.x;
     const long base = (long)blockIdx.x * (WG * R);
 
-    float xi[R], yi[R], zi[R], gmi[R];
-    float ax[R], ay[R], az[R];
-    double dax[R], day[R], daz[R];
+    // target pair p of this lane = bodies base + (2p)*WG + t and base + (2p+1)*WG + t  (coalesced loads)
+    v2f xi[P], yi[P], zi[P], gmi[P];
+    v2f ax[P], ay[P], az[P];      // partial sums of the current tile
+    v2f sx[P], sy[P], sz[P];      // NB_F32: running sums ...
+    v2f cx[P], cy[P], cz[P];      // ... and their Kahan compensation
+    double dax[R], day[R], daz[R];  // NB_F32_ACC64: running sums in fp64
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        long i = base + (long)r * WG + t;
-        long ic = i < a.n_tgt ? i : a.n_tgt - 1;  // clamp: tail lanes recompute the last body, never store
-        float4 p = a.src[a.tgt_off + ic];
-        xi[r] = p.x; yi[r] = p.y; zi[r] = p.z; gmi[r] = p.w;
-        ax[r] = ay[r] = az[r] = 0.f;
-        dax[r] = day[r] = daz[r] = 0.0;
+    for (int p = 0; p < P; ++p) {
+        float4 b[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            long i = base + (long)(2 * p + h) * WG + t;
+            long ic = i < a.n_tgt ? i : a.n_tgt - 1;  // tail lanes recompute the last body, never store
+            b[h] = a.src[a.tgt_off + ic];
+        }
+        xi[p] = (v2f){b[0].x, b[1].x}; yi[p] = (v2f){b[0].y, b[1].y};
+        zi[p] = (v2f){b[0].z, b[1].z}; gmi[p] = (v2f){b[0].w, b[1].w};
+        ax[p] = ay[p] = az[p] = splat(0.f);
+        sx[p] = sy[p] = sz[p] = cx[p] = cy[p] = cz[p] = splat(0.f);
     }
+#pragma unroll
+    for (int r = 0; r < R; ++r) dax[r] = day[r] = daz[r] = 0.0;
 
-    const long ntiles = (a.n_src + TILE - 1) / TILE;
-    const float eps2 = a.eps2;
+    const long ntiles_all = (a.n_src + TILE - 1) / TILE;
+    long k0 = 0, k1 = ntiles_all;
+    if (SPLIT) {
+        const long per = (ntiles_all + gridDim.y - 1) / gridDim.y;
+        k0 = (long)blockIdx.y * per;
+        k1 = k0 + per < ntiles_all ? k0 + per : ntiles_all;
+    }
+    const v2f eps2 = splat(a.eps2);
     auto load_src = [&](long k) -> float4 {
         long j = k * TILE + t;
         // bodies past the end are massless points at the origin: with eps2 > 0 they add exactly +0
         return j < a.n_src ? a.src[j] : make_float4(0.f, 0.f, 0.f, 0.f);
     };
 
-    tile[0][t] = load_src(0);
-    __syncthreads();
-
-    for (long k = 0; k < ntiles; ++k) {
-        const int cur = (int)(k & 1);
+    if (k0 < k1) {
+        tile[0][t] = load_src(k0);
+        __syncthreads();
+    }
+    for (long k = k0; k < k1; ++k) {
+        const int cur = (int)((k - k0) & 1);
         float4 nxt;
-        if (k + 1 < ntiles) nxt = load_src(k + 1);  // in flight while tile k is consumed
+        if (k + 1 < k1) nxt = load_src(k + 1);  // in flight while tile k is consumed
 
-#pragma unroll 8
+#pragma unroll 4
         for (int j = 0; j < TILE; ++j) {
             const float4 s = tile[cur][j];  // wave-uniform address: broadcast ds_read_b128
+            const v2f qx = splat(s.x), qy = splat(s.y), qz = splat(s.z), gm = splat(s.w);
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                float dx = s.x - xi[r];
-                float dy = s.y - yi[r];
-                float dz = s.z - zi[r];
-                float r2 = __builtin_fmaf(dx, dx, eps2);
-                r2 = __builtin_fmaf(dy, dy, r2);
-                r2 = __builtin_fmaf(dz, dz, r2);
-                float rinv = __builtin_amdgcn_rsqf(r2);  // v_rsq_f32, 1 ulp
-                float rinv2 = rinv * rinv;
-                float sc = s.w * rinv;
+            for (int p = 0; p < P; ++p) {
+                v2f dx = qx - xi[p];
+                v2f dy = qy - yi[p];
+                v2f dz = qz - zi[p];
+                v2f r2 = pk_fma(dx, dx, eps2);
+                r2 = pk_fma(dy, dy, r2);
+                r2 = pk_fma(dz, dz, r2);
+                v2f rinv = (v2f){__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};  // v_rsq_f32 x2
+                v2f rinv2 = rinv * rinv;
+                v2f sc = gm * rinv;
                 sc = sc * rinv2;  // G*m_j / (r2+eps2)^(3/2) ; the self pair gives sc*0 = +0
-                ax[r] = __builtin_fmaf(dx, sc, ax[r]);
-                ay[r] = __builtin_fmaf(dy, sc, ay[r]);
-                az[r] = __builtin_fmaf(dz, sc, az[r]);
+                ax[p] = pk_fma(dx, sc, ax[p]);
+                ay[p] = pk_fma(dy, sc, ay[p]);
+                az[p] = pk_fma(dz, sc, az[p]);
             }
         }
-        if (ACC64) {
+        // ---- second summation level: fold this tile's partial into the running sum
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                dax[r] += (double)ax[r]; day[r] += (double)ay[r]; daz[r] += (double)az[r];
-                ax[r] = ay[r] = az[r] = 0.f;
+        for (int p = 0; p < P; ++p) {
+            if (ACC64) {
+                dax[2 * p] += (double)ax[p].x; dax[2 * p + 1] += (double)ax[p].y;
+                day[2 * p] += (double)ay[p].x; day[2 * p + 1] += (double)ay[p].y;
+                daz[2 * p] += (double)az[p].x; daz[2 * p + 1] += (double)az[p].y;
+            } else {  // Kahan: y = part - c ; t = s + y ; c = (t - s) - y ; s = t   (no reassociation: not fast-math)
+                v2f y, tt;
+                y = ax[p] - cx[p]; tt = sx[p] + y; cx[p] = (tt - sx[p]) - y; sx[p] = tt;
+                y = ay[p] - cy[p]; tt = sy[p] + y; cy[p] = (tt - sy[p]) - y; sy[p] = tt;
+                y = az[p] - cz[p]; tt = sz[p] + y; cz[p] = (tt - sz[p]) - y; sz[p] = tt;
             }
+            ax[p] = ay[p] = az[p] = splat(0.f);
         }
-        if (k + 1 < ntiles) tile[cur ^ 1][t] = nxt;  // buffer cur^1 was last read before the previous barrier
+        if (k + 1 < k1) tile[cur ^ 1][t] = nxt;  // buffer cur^1 was last read before the previous barrier
         __syncthreads();
     }
 
 #pragma unroll
     for (int r = 0; r < R; ++r) {
+        const int p = r >> 1, h = r & 1;
         long i = base + (long)r * WG + t;
         if (i >= a.n_tgt) continue;
-        if (ACCEL_ONLY) {
-            if (ACC64) ((double4*)a.acc)[i] = make_double4(dax[r], day[r], daz[r], 0.0);
-            else ((float4*)a.acc)[i] = make_float4(ax[r], ay[r], az[r], 0.f);
+        if (SPLIT) {
+            const long slot = (long)blockIdx.y * a.n_tgt + i;
+            if (ACC64) ((double4*)a.partial)[slot] = make_double4(dax[r], day[r], daz[r], 0.0);
+            else ((float4*)a.partial)[slot] = make_float4(sx[p][h], sy[p][h], sz[p][h], 0.f);
         } else if (ACC64) {
-            // kick then drift on the fp64 masters (samples/nbody.cc:76-88), fp32 copy for the next step's sources
-            const double dt = (double)a.dt;
-            double4 v = a.vel64[i];
-            double4 p = a.pos64[i];
-            v.x += dax[r] * dt; v.y += day[r] * dt; v.z += daz[r] * dt;
-            p.x += v.x * dt; p.y += v.y * dt; p.z += v.z * dt;
-            a.vel64[i] = v;
-            a.pos64[i] = p;
-            a.out[a.tgt_off + i] = make_float4((float)p.x, (float)p.y, (float)p.z, gmi[r]);
+            finish_target<true, ACCEL_ONLY>(a, i, dax[r], day[r], daz[r], xi[p][h], yi[p][h], zi[p][h], gmi[p][h]);
         } else {
-            const float dt = a.dt;
-            float4 v = a.vel[i];
-            v.x = __builtin_fmaf(ax[r], dt, v.x);
-            v.y = __builtin_fmaf(ay[r], dt, v.y);
-            v.z = __builtin_fmaf(az[r], dt, v.z);
-            a.vel[i] = v;
-            a.out[a.tgt_off + i] = make_float4(__builtin_fmaf(v.x, dt, xi[r]), __builtin_fmaf(v.y, dt, yi[r]),
-                                               __builtin_fmaf(v.z, dt, zi[r]), gmi[r]);
+            finish_target<false, ACCEL_ONLY>(a, i, sx[p][h], sy[p][h], sz[p][h], xi[p][h], yi[p][h], zi[p][h],
+                                             gmi[p][h]);
         }
     }
 }
 
-template <int R, bool ACC64, bool ACCEL_ONLY>
-static int launch_one(const F32Args& a, hipStream_t stream) {
-    long per_block = (long)WG * R;
-    long blocks = (a.n_tgt + per_block - 1) / per_block;
+// combine the j-split partials (a.partial[js][n_tgt]) and run the epilogue
+template <bool ACC64, bool ACCEL_ONLY>
+__global__ __launch_bounds__(WG) void nbody_reduce_update_f32(F32Args a, int js) {
+    const long i = (long)blockIdx.x * WG + threadIdx.x;
+    if (i >= a.n_tgt) return;
+    const float4 b = a.src[a.tgt_off + i];
+    if (ACC64) {
+        double x = 0, y = 0, z = 0;
+        for (int s = 0; s < js; ++s) {
+            double4 p = ((const double4*)a.partial)[(long)s * a.n_tgt + i];
+            x += p.x; y += p.y; z += p.z;
+        }
+        finish_target<true, ACCEL_ONLY>(a, i, x, y, z, b.x, b.y, b.z, b.w);
+    } else {
+        float x = 0, y = 0, z = 0;
+        for (int s = 0; s < js; ++s) {
+            float4 p = ((const float4*)a.partial)[(long)s * a.n_tgt + i];
+            x += p.x; y += p.y; z += p.z;
+        }
+        finish_target<false, ACCEL_ONLY>(a, i, x, y, z, b.x, b.y, b.z, b.w);
+    }
+}
+
+template <int P, bool ACC64, bool ACCEL_ONLY>
+static int launch_one(const F32Args& a, int js, hipStream_t stream) {
+    const long per_block = (long)WG * 2 * P;
+    const long blocks = (a.n_tgt + per_block - 1) / per_block;
     if (blocks <= 0 || blocks > 0x7fffffffL) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL((nbody_force_f32<R, ACC64, ACCEL_ONLY>), dim3((unsigned)blocks), dim3(WG), 0, stream, a);
+    if (js <= 1) {
+        hipLaunchKernelGGL((nbody_force_f32<P, ACC64, ACCEL_ONLY, false>), dim3((unsigned)blocks), dim3(WG), 0, stream, a);
+        return (int)hipGetLastError();
+    }
+    if (!a.partial) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL((nbody_force_f32<P, ACC64, ACCEL_ONLY, true>), dim3((unsigned)blocks, (unsigned)js), dim3(WG), 0,
+                       stream, a);
+    if (hipError_t e = hipGetLastError()) return (int)e;
+    const long rblocks = (a.n_tgt + WG - 1) / WG;
+    hipLaunchKernelGGL((nbody_reduce_update_f32<ACC64, ACCEL_ONLY>), dim3((unsigned)rblocks), dim3(WG), 0, stream, a, js);
     return (int)hipGetLastError();
 }
 
-int launch_f32(const F32Args& a, int R, bool acc64, bool accel_only, hipStream_t stream) {
-#define NBK_CASE(RR)                                                                      \
-    case RR:                                                                              \
-        if (acc64) return accel_only ? launch_one<RR, true, true>(a, stream) : launch_one<RR, true, false>(a, stream); \
-        return accel_only ? launch_one<RR, false, true>(a, stream) : launch_one<RR, false, false>(a, stream);
-    switch (R) {
+int launch_f32(const F32Args& a, const F32Plan& plan, bool acc64, bool accel_only, hipStream_t stream) {
+#define NBK_CASE(PP)                                                                                         \
+    case 2 * PP:                                                                                             \
+        if (acc64)                                                                                           \
+            return accel_only ? launch_one<PP, true, true>(a, plan.j_split, stream)                          \
+                              : launch_one<PP, true, false>(a, plan.j_split, stream);                        \
+        return accel_only ? launch_one<PP, false, true>(a, plan.j_split, stream)                             \
+                          : launch_one<PP, false, false>(a, plan.j_split, stream);
+    switch (plan.targets_per_lane) {
         NBK_CASE(1)
         NBK_CASE(2)
         NBK_CASE(4)
@@ -149,25 +242,41 @@ int launch_f32(const F32Args& a, int R, bool acc64, bool accel_only, hipStream_t
     return (int)hipErrorInvalidValue;
 }
 
-const char* kernel_name_f32(int R, bool acc64, bool accel_only) {
-    static const char* names[3][2][2] = {
-        {{"nbody_force_f32<1, false, false>", "nbody_force_f32<1, false, true>"},
-         {"nbody_force_f32<1, true, false>", "nbody_force_f32<1, true, true>"}},
-        {{"nbody_force_f32<2, false, false>", "nbody_force_f32<2, false, true>"},
-         {"nbody_force_f32<2, true, false>", "nbody_force_f32<2, true, true>"}},
-        {{"nbody_force_f32<4, false, false>", "nbody_force_f32<4, false, true>"},
-         {"nbody_force_f32<4, true, false>", "nbody_force_f32<4, true, true>"}}};
-    int ri = R == 1 ? 0 : R == 2 ? 1 : 2;
-    return names[ri][acc64 ? 1 : 0][accel_only ? 1 : 0];
+const char* kernel_name_f32(const F32Plan& plan, bool acc64, bool accel_only) {
+    static char buf[8][96];
+    static int slot = 0;
+    char* s = buf[slot++ & 7];
+    snprintf(s, 96, "nbody_force_f32<%d, %s, %s, %s>", plan.targets_per_lane / 2, acc64 ? "true" : "false",
+             accel_only ? "true" : "false", plan.j_split > 1 ? "true" : "false");
+    return s;
 }
 
-// Enough workgroups to give every SIMD >= 2 waves (the fp32 VALU needs two resident waves per SIMD to issue at
-// its full 2-cycle rate) while amortising each LDS read over as many targets as the register file allows.
-int auto_targets_per_lane(long n_tgt, int n_cus) {
-    long wg2 = 2L * n_cus;
-    if (n_tgt >= wg2 * WG * 4) return 4;
-    if (n_tgt >= wg2 * WG * 2) return 2;
-    return 1;
+// Register blocking and j-split for n_tgt targets against n_src sources on a chip with n_cus CUs:
+//  * R = 4 targets per lane (2 packed pairs) amortises each broadcast LDS read over 4 interactions at
+//    ~64 VGPRs; R = 8 halves the LDS reads again when there are targets to spare; tiny systems use R = 2;
+//  * the grid should hold >= 4 workgroups per CU (>= 4 waves per SIMD: two to alternate on the packed
+//    pipe plus cover for LDS/barrier waits); if the targets alone give fewer, split the source range.
+F32Plan plan_f32(long n_tgt, long n_src, int n_cus, int force_tpl, int force_js, bool have_workspace) {
+    F32Plan p;
+    int R = force_tpl;
+    if (R != 2 && R != 4 && R != 8) {
+        R = 4;
+        if (n_tgt < (long)WG * 4) R = 2;
+    }
+    p.targets_per_lane = R;
+    const long bx = (n_tgt + (long)WG * R - 1) / ((long)WG * R);
+    const long ntiles = (n_src + TILE - 1) / TILE;
+    int js = force_js;
+    if (js <= 0) {
+        js = 1;
+        const long want = 4L * n_cus;
+        while (bx * js < want && js < MAX_JSPLIT && (long)js * 2 * 8 <= ntiles) js <<= 1;  // keep >= 8 tiles per slice
+    }
+    if (js > MAX_JSPLIT) js = MAX_JSPLIT;
+    if ((long)js > ntiles) js = (int)(ntiles > 0 ? ntiles : 1);
+    if (!have_workspace) js = 1;
+    p.j_split = js;
+    return p;
 }
 
 }  // namespace nbk

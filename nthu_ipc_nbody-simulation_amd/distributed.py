@@ -31,18 +31,25 @@ def shard_range(n, rank, world):
     return rank * per, (rank + 1) * per
 
 
-def hip_compute(acc64=False, targets_per_lane=0):
-    """The product compute step: nb_launch_step_f32 on torch's current HIP stream."""
+def hip_compute(acc64=False, targets_per_lane=0, j_split=0):
+    """The product compute step: nb_launch_step_f32 on torch's current HIP stream.  The j-split workspace
+    (partial sums when a shard's targets alone cannot fill the chip) is a torch tensor allocated once."""
+    ws = {}
 
     def compute(src, out, vel, off, n_tgt, eps2, dt, pos64=None, vel64=None):
         if not src.is_cuda:
             raise RuntimeError("nbody_amd has no CPU compute path: tensors must live on a HIP device")
+        key = (src.device, n_tgt)
+        if key not in ws:
+            ws[key] = torch.empty(capi.workspace_bytes_f32(n_tgt, acc64), dtype=torch.uint8, device=src.device)
+        w = ws[key]
         stream = torch.cuda.current_stream(src.device).cuda_stream
         capi.launch_f32(src.data_ptr(), out.data_ptr(), src.shape[0], off, n_tgt, eps2, dt, stream,
                         vel_ptr=vel.data_ptr() if vel is not None else 0,
                         pos64_ptr=pos64.data_ptr() if pos64 is not None else 0,
                         vel64_ptr=vel64.data_ptr() if vel64 is not None else 0,
-                        acc64=acc64, targets_per_lane=targets_per_lane)
+                        acc64=acc64, targets_per_lane=targets_per_lane, j_split=j_split,
+                        workspace_ptr=w.data_ptr(), workspace_bytes=w.numel())
 
     return compute
 
@@ -76,7 +83,14 @@ class ShardedSystem:
         """In-place all-gather: every rank contributes its own slot of `buf`."""
         if self.world == 1:
             return
-        dist.all_gather_into_tensor(buf, buf[self.lo:self.hi], group=self.group)
+        if dist.get_backend(self.group) == "nccl":
+            # RCCL: in place, send buffer = this rank's slot of the receive buffer
+            dist.all_gather_into_tensor(buf, buf[self.lo:self.hi], group=self.group)
+        else:
+            # gloo (CPU tests / single-GPU rehearsal): same exchange through the list form
+            per = self.n_tgt
+            dist.all_gather([buf[r * per:(r + 1) * per] for r in range(self.world)],
+                            buf[self.lo:self.hi].clone(), group=self.group)
 
     def step(self):
         src, out = self.pos[self.cur], self.pos[self.cur ^ 1]
