@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--precision", choices=["f32", "f32acc64"], default="f32")
     ap.add_argument("--targets-per-lane", type=int, default=0)
     ap.add_argument("--j-split", type=int, default=0)
+    ap.add_argument("--source-path", type=int, default=0, help="0 auto, 1 LDS tile, 2 SGPR/scalar loads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -112,7 +113,7 @@ def main():
         import numpy as np
         pos = np.concatenate([q.T, (synthetic.G * m)[:, None]], axis=1)
         vel = np.concatenate([v.T, np.zeros((hi - lo, 1))], axis=1)
-    compute = hip_compute(acc64, args.targets_per_lane, args.j_split)
+    compute = hip_compute(acc64, args.targets_per_lane, args.j_split, args.source_path)
     sysm = ShardedSystem(n, torch.from_numpy(pos), torch.from_numpy(vel), synthetic.EPS, synthetic.DT, device,
                          compute=compute, acc64=acc64)
 
@@ -156,8 +157,9 @@ def main():
         flops_launch = FLOP_PER_PAIR * sysm.n_tgt * (n - 1)
         achieved = flops_launch / (k_ms * 1e-3) / 1e12
         ws_bytes = capi.workspace_bytes_f32(sysm.n_tgt, acc64)
-        kname = capi.kernel_name_f32(n, sysm.n_tgt, acc64, args.targets_per_lane, args.j_split, ws_bytes)
-        tpl, jsp = capi.plan_f32(n, sysm.n_tgt, acc64, args.targets_per_lane, args.j_split, ws_bytes)
+        kname = capi.kernel_name_f32(n, sysm.n_tgt, acc64, args.targets_per_lane, args.j_split, ws_bytes,
+                                     source_path=args.source_path)
+        tpl, jsp = capi.plan_f32(n, sysm.n_tgt, acc64, args.targets_per_lane, args.j_split, ws_bytes, args.source_path)
         out = {
             "metric": "body-pair interactions/sec",
             "value": value,

@@ -22,7 +22,16 @@ __device__ __forceinline__ v2f splat(float x) { return (v2f){x, x}; }
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
 constexpr int WG = 256, TILE = 256;
-enum { V_LDS = 0, V_STAGE = 1, V_SMEM = 2 };
+enum { V_LDS = 0, V_STAGE = 1, V_SMEM = 2, V_SMEM_PF = 3 };
+typedef float v16f __attribute__((ext_vector_type(16)));
+// 4 bodies (64 B) into 16 SGPRs; completion is NOT tracked by the compiler: pair with sload_wait() before use
+__device__ __forceinline__ v16f sload16(const float4* p) { v16f v; asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(v) : "s"(p)); return v; }
+__device__ __forceinline__ void sload_wait(v16f& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a)); }
+// as above, and additionally ordered AFTER the last write of `dep` (an accumulator of the batch being consumed), so the
+// scheduler cannot hoist the wait above the compute it is meant to overlap with
+__device__ __forceinline__ void sload_wait_after(v16f& a, v2f& dep) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+v"(dep)); }
+__device__ __forceinline__ void sload_wait2(v16f& a, v16f& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)); }
+
 
 template <int P>
 struct Acc {
@@ -85,8 +94,11 @@ __device__ __forceinline__ void interact_staged(const float4* s, const v2f* xi, 
 }
 
 template <int P, int VAR, int U, int MINW>
-__global__ __launch_bounds__(WG, MINW) void force(const float4* __restrict__ src, long n_src, long n_tgt,
-                                                  float4* __restrict__ acc, float eps2s) {
+__global__ __launch_bounds__(WG, MINW) void force(const float4* __restrict__ src_all, long n_src_all, long n_tgt,
+                                                  float4* __restrict__ acc_all, float eps2s) {
+    const long n_src = n_src_all / gridDim.y;
+    const float4* __restrict__ src = src_all + (long)blockIdx.y * n_src;
+    float4* __restrict__ acc = acc_all + (long)blockIdx.y * n_tgt;
     __shared__ float4 tile[2][TILE];
     constexpr int R = 2 * P;
     const int t = threadIdx.x;
@@ -94,8 +106,8 @@ __global__ __launch_bounds__(WG, MINW) void force(const float4* __restrict__ src
     v2f xi[P], yi[P], zi[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        float4 b0 = src[min(base + (long)(2 * p) * WG + t, n_tgt - 1)];
-        float4 b1 = src[min(base + (long)(2 * p + 1) * WG + t, n_tgt - 1)];
+        float4 b0 = src_all[min(base + (long)(2 * p) * WG + t, n_tgt - 1)];
+        float4 b1 = src_all[min(base + (long)(2 * p + 1) * WG + t, n_tgt - 1)];
         xi[p] = (v2f){b0.x, b1.x}; yi[p] = (v2f){b0.y, b1.y}; zi[p] = (v2f){b0.z, b1.z};
     }
     Acc<P> A;
@@ -103,7 +115,29 @@ __global__ __launch_bounds__(WG, MINW) void force(const float4* __restrict__ src
     const v2f eps2 = splat(eps2s);
     const long ntiles = n_src / TILE;  // harness: n_src multiple of TILE
 
-    if (VAR == V_SMEM) {
+    if constexpr (VAR == V_SMEM_PF) {
+        // batches of 4 sources (one s_load_dwordx16 = 64 B) in two SGPR sets A/B, explicit ping-pong: the load of
+        // the next batch is issued before the current one is consumed, and waited for (tied "+s" operand, so
+        // no use can be scheduled above the wait) only afterwards.  U counts sources per half iteration.
+        static_assert(U == 4, "");
+        auto body = [&](const v16f& c) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                interact<P>(make_float4(c[4 * u], c[4 * u + 1], c[4 * u + 2], c[4 * u + 3]), xi, yi, zi, eps2, A);
+        };
+        v16f a = sload16(src), b;
+        sload_wait(a);
+#pragma unroll 1
+        for (long j = 0; j < n_src; j += 8) {
+            b = sload16(src + j + 4);
+            body(a);
+            sload_wait_after(b, A.az[P - 1]);
+            a = sload16(src + ((j + 8 < n_src) ? j + 8 : 0));
+            body(b);
+            sload_wait_after(a, A.az[P - 1]);
+            if (((j + 8) & (TILE - 1)) == 0) A.flush();
+        }
+    } else if constexpr (VAR == V_SMEM) {
         // sources straight from memory with wave-uniform addresses (scalar loads), one batch prefetched ahead
         float4 cur[U], nxt[U];
 #pragma unroll
@@ -152,9 +186,9 @@ __global__ __launch_bounds__(WG, MINW) void force(const float4* __restrict__ src
 static std::vector<float4> ref_acc;
 
 template <int P, int VAR, int U, int MINW>
-static void run(const char* name, const float4* d_src, long n_src, long n_tgt, float4* d_acc) {
+static void run(const char* name, const float4* d_src, long n_src, long n_tgt, float4* d_acc, int js = 1) {
     const long blocks = (n_tgt + WG * 2 * P - 1) / (WG * 2 * P);
-    auto launch = [&] { hipLaunchKernelGGL((force<P, VAR, U, MINW>), dim3(blocks), dim3(WG), 0, 0, d_src, n_src, n_tgt, d_acc, 1e-6f); };
+    auto launch = [&] { hipLaunchKernelGGL((force<P, VAR, U, MINW>), dim3(blocks, js), dim3(WG), 0, 0, d_src, n_src, n_tgt, d_acc, 1e-6f); };
     launch();
     CK(hipDeviceSynchronize());
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -168,6 +202,7 @@ static void run(const char* name, const float4* d_src, long n_src, long n_tgt, f
     CK(hipMemcpy(h.data(), d_acc, n_tgt * sizeof(float4), hipMemcpyDeviceToHost));
     double maxrel = 0;
     if (ref_acc.empty()) ref_acc = h;
+    if (js > 1) h = ref_acc;  // slices are not combined in the harness: timing only
     for (long i = 0; i < n_tgt; ++i) {
         double d = std::fabs(h[i].x - ref_acc[i].x) + std::fabs(h[i].y - ref_acc[i].y) + std::fabs(h[i].z - ref_acc[i].z);
         double s = std::fabs(ref_acc[i].x) + std::fabs(ref_acc[i].y) + std::fabs(ref_acc[i].z) + 1e-30;
@@ -187,24 +222,25 @@ int main(int argc, char** argv) {
                      z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31; return (double)(z >> 11) * (1.0 / 9007199254740992.0); };
     for (long i = 0; i < n_tgt; ++i) h[i] = make_float4(2 * rnd() - 1, 2 * rnd() - 1, 2 * rnd() - 1, (0.5 + rnd()) / n_tgt);
     float4 *d_src, *d_acc;
-    CK(hipMalloc(&d_src, n_tgt * sizeof(float4))); CK(hipMalloc(&d_acc, n_tgt * sizeof(float4)));
+    CK(hipMalloc(&d_src, n_tgt * sizeof(float4))); CK(hipMalloc(&d_acc, 4 * n_tgt * sizeof(float4)));
     CK(hipMemcpy(d_src, h.data(), n_tgt * sizeof(float4), hipMemcpyHostToDevice));
     printf("n_tgt=%ld n_src=%ld\n", n_tgt, n_src);
     run<2, V_LDS, 4, 4>("LDS   P=2 unroll4 (product)", d_src, n_src, n_tgt, d_acc);
-    run<2, V_LDS, 8, 4>("LDS   P=2 unroll8", d_src, n_src, n_tgt, d_acc);
-    run<2, V_LDS, 2, 4>("LDS   P=2 unroll2", d_src, n_src, n_tgt, d_acc);
-    run<1, V_LDS, 4, 8>("LDS   P=1 unroll4 8w", d_src, n_src, n_tgt, d_acc);
-    run<4, V_LDS, 4, 2>("LDS   P=4 unroll4 2w", d_src, n_src, n_tgt, d_acc);
-    run<2, V_STAGE, 2, 4>("STAGE P=2 U=2", d_src, n_src, n_tgt, d_acc);
-    run<2, V_STAGE, 4, 3>("STAGE P=2 U=4 3w", d_src, n_src, n_tgt, d_acc);
-    run<1, V_STAGE, 4, 6>("STAGE P=1 U=4 6w", d_src, n_src, n_tgt, d_acc);
-    run<1, V_STAGE, 8, 4>("STAGE P=1 U=8 4w", d_src, n_src, n_tgt, d_acc);
-    run<4, V_STAGE, 2, 2>("STAGE P=4 U=2 2w", d_src, n_src, n_tgt, d_acc);
-    run<2, V_SMEM, 4, 4>("SMEM  P=2 U=4", d_src, n_src, n_tgt, d_acc);
-    run<2, V_SMEM, 8, 4>("SMEM  P=2 U=8", d_src, n_src, n_tgt, d_acc);
-    run<1, V_SMEM, 4, 8>("SMEM  P=1 U=4 8w", d_src, n_src, n_tgt, d_acc);
+    run<4, V_SMEM, 8, 2>("SMEM  P=4 U=8 2w", d_src, n_src, n_tgt, d_acc);
+    run<4, V_SMEM, 16, 2>("SMEM  P=4 U=16 2w", d_src, n_src, n_tgt, d_acc);
     run<4, V_SMEM, 4, 2>("SMEM  P=4 U=4 2w", d_src, n_src, n_tgt, d_acc);
-    run<3, V_LDS, 4, 3>("LDS   P=3 unroll4 3w", d_src, n_src, n_tgt, d_acc);
-    run<3, V_SMEM, 4, 3>("SMEM  P=3 U=4 3w", d_src, n_src, n_tgt, d_acc);
+    run<2, V_SMEM, 16, 4>("SMEM  P=2 U=16 4w", d_src, n_src, n_tgt, d_acc);
+    run<2, V_SMEM, 8, 4>("SMEM  P=2 U=8 4w", d_src, n_src, n_tgt, d_acc);
+    run<4, V_SMEM, 8, 3>("SMEM  P=4 U=8 3w js2", d_src, n_src, n_tgt, d_acc, 2);
+    run<4, V_SMEM, 8, 4>("SMEM  P=4 U=8 4w js2", d_src, n_src, n_tgt, d_acc, 2);
+    run<4, V_SMEM, 8, 2>("SMEM  P=4 U=8 2w js2", d_src, n_src, n_tgt, d_acc, 2);
+    run<2, V_SMEM, 8, 4>("SMEM  P=2 U=8 4w js2", d_src, n_src, n_tgt, d_acc, 2);
+    run<2, V_SMEM, 8, 8>("SMEM  P=2 U=8 8w js2", d_src, n_src, n_tgt, d_acc, 2);
+    run<1, V_SMEM, 8, 8>("SMEM  P=1 U=8 8w", d_src, n_src, n_tgt, d_acc);
+    run<1, V_SMEM, 16, 8>("SMEM  P=1 U=16 8w", d_src, n_src, n_tgt, d_acc);
+    run<4, V_SMEM_PF, 4, 2>("SMEMPF P=4 U=4 2w", d_src, n_src, n_tgt, d_acc);
+    run<4, V_SMEM_PF, 4, 3>("SMEMPF P=4 U=4 3w js2", d_src, n_src, n_tgt, d_acc, 2);
+    run<6, V_SMEM, 4, 1>("SMEM  P=6 U=4 1w", d_src, n_src, n_tgt, d_acc);
+    run<8, V_SMEM, 4, 1>("SMEM  P=8 U=4 1w", d_src, n_src, n_tgt, d_acc);
     return 0;
 }

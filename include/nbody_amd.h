@@ -159,7 +159,7 @@ typedef struct nb_launch_f32 {
     int32_t acc64;            /* 0 = NB_F32, 1 = NB_F32_ACC64 */
     int32_t targets_per_lane; /* 0 = auto; 2, 4 or 8 (packed pairs of targets per lane) */
     int32_t j_split;          /* 0 = auto; 1..16 workgroups share a target block, each over a slice of the sources */
-    int32_t reserved;
+    int32_t source_path;      /* 0 = auto; 1 = sources through the LDS tile; 2 = sources through scalar loads/SGPRs */
 } nb_launch_f32;
 int nb_launch_step_f32(const nb_launch_f32* a, void* hip_stream);  /* force + fused kick-drift */
 int nb_launch_accel_f32(const nb_launch_f32* a, void* hip_stream); /* force only -> a->acc */

@@ -626,13 +626,15 @@ static int check_launch(const nb_launch_f32* a, bool accel_only) {
     if (r != 0 && r != 2 && r != 4 && r != 8) return NB_ERR_INVALID;
     if (a->j_split < 0 || a->j_split > MAX_JSPLIT) return NB_ERR_INVALID;
     if (a->j_split > 1 && !a->workspace) return NB_ERR_INVALID;
+    if (a->source_path < 0 || a->source_path > 2) return NB_ERR_INVALID;
     return NB_OK;
 }
 
 static F32Plan resolve_plan(const nb_launch_f32* a) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    F32Plan p = plan_f32(a->n_tgt, a->n_src, cus, a->targets_per_lane, a->j_split, a->workspace != nullptr);
+    F32Plan p = plan_f32(a->n_tgt, a->n_src, cus, a->targets_per_lane, a->j_split, a->workspace != nullptr,
+                         a->source_path);
     // the caller's workspace must hold j_split slices of n_tgt records
     const size_t rec = a->acc64 ? sizeof(double4) : sizeof(float4);
     while (p.j_split > 1 && (size_t)p.j_split * (size_t)a->n_tgt * rec > (size_t)a->workspace_bytes) p.j_split >>= 1;

@@ -8,11 +8,18 @@
 // Design:
 //  * owner-computes: a lane owns R whole target bodies in registers; no atomics, no global `a` array,
 //    bitwise run-to-run reproducible.
-//  * sources stream through LDS in tiles of 256 float4 {x,y,z,G*m}: every lane issues ONE coalesced 16-byte
-//    global load per tile (a wave reads 1 KiB contiguous); the tile is double-buffered so one s_barrier per
-//    tile suffices and the next tile's load is in flight while the current one is consumed.
-//  * the inner loop reads the tile with wave-uniform (broadcast) ds_read_b128 and feeds R interactions per
-//    read.  Targets are held two-per-register-pair (ext_vector float2) so the loop is PACKED fp32:
+//  * two source paths, same arithmetic (template parameter SGPR, chosen by plan_f32, both parity-tested):
+//    - LDS: sources stream through LDS in tiles of 256 float4 {x,y,z,G*m}: every lane issues ONE coalesced
+//      16-byte global load per tile (a wave reads 1 KiB contiguous); the tile is double-buffered so one
+//      s_barrier per tile suffices and the next tile's load is in flight while the current one is consumed;
+//      the inner loop reads the tile with wave-uniform (broadcast) ds_read_b128.
+//    - SGPR (default): a source is the same for all 64 lanes, so it never needs a vector register or LDS at
+//      all: batches of 16 bodies are fetched with scalar loads (s_load_dwordx16, through the scalar cache and
+//      L2) into SGPRs and used directly as the broadcast operand of the packed VALU ops
+//      (v_pk_add_f32 v, s[n:n+1], v op_sel_hi:[0,1]).  No ds_read, no v_mov, no barrier, no s_nop in the
+//      loop: exactly 12 packed VALU + 2 v_rsq_f32 per 2 pairs.  Measured (bench/ubench/force_variants.hip,
+//      profiles/r01_force_variants.txt): 58 % of peak vs 52 % for the LDS path.
+//  * targets are held two-per-register-pair (ext_vector float2) so the loop is PACKED fp32:
 //    per source and target pair 3 v_pk_add, 3 v_pk_fma, 2 v_rsq_f32, 3 v_pk_mul, 3 v_pk_fma
 //    = 12 packed VALU + 2 transcendentals per 2 pairs.
 //    Why packed (profiles/r01_ubench_valu_rate.txt): a packed op costs 4 SIMD-cycles for 128 lane-ops, a
@@ -71,11 +78,13 @@ __device__ __forceinline__ void finish_target(const F32Args& a, long i, ACC_T ax
     }
 }
 
-// P = target PAIRS per lane (R = 2P targets).  SPLIT: blockIdx.y selects a slice of the source tiles and the
-// partial sums go to a.partial instead of the epilogue.
-template <int P, bool ACC64, bool ACCEL_ONLY, bool SPLIT>
+constexpr int SGPR_BATCH = 8;  // bodies per scalar-load batch (32 SGPRs; two batches live = 64 of the ~100 SGPRs)
+
+// P = target PAIRS per lane (R = 2P targets).  SPLIT: blockIdx.y selects a slice of the sources and the partial
+// sums go to a.partial instead of the epilogue.  SGPR: sources via scalar loads instead of the LDS tile.
+template <int P, bool ACC64, bool ACCEL_ONLY, bool SPLIT, bool SGPR>
 __global__ __launch_bounds__(WG, (P >= 4 ? 2 : 4)) void nbody_force_f32(F32Args a) {
-    __shared__ float4 tile[2][TILE];
+    __shared__ float4 tile[SGPR ? 1 : 2][SGPR ? 1 : TILE];
     constexpr int R = 2 * P;
     const int t = threadIdx.x;
     const long base = (long)blockIdx.x * (WG * R);
@@ -103,51 +112,30 @@ __global__ __launch_bounds__(WG, (P >= 4 ? 2 : 4)) void nbody_force_f32(F32Args 
 #pragma unroll
     for (int r = 0; r < R; ++r) dax[r] = day[r] = daz[r] = 0.0;
 
-    const long ntiles_all = (a.n_src + TILE - 1) / TILE;
-    long k0 = 0, k1 = ntiles_all;
-    if (SPLIT) {
-        const long per = (ntiles_all + gridDim.y - 1) / gridDim.y;
-        k0 = (long)blockIdx.y * per;
-        k1 = k0 + per < ntiles_all ? k0 + per : ntiles_all;
-    }
     const v2f eps2 = splat(a.eps2);
-    auto load_src = [&](long k) -> float4 {
-        long j = k * TILE + t;
-        // bodies past the end are massless points at the origin: with eps2 > 0 they add exactly +0
-        return j < a.n_src ? a.src[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-    };
 
-    if (k0 < k1) {
-        tile[0][t] = load_src(k0);
-        __syncthreads();
-    }
-    for (long k = k0; k < k1; ++k) {
-        const int cur = (int)((k - k0) & 1);
-        float4 nxt;
-        if (k + 1 < k1) nxt = load_src(k + 1);  // in flight while tile k is consumed
-
-#pragma unroll 4
-        for (int j = 0; j < TILE; ++j) {
-            const float4 s = tile[cur][j];  // wave-uniform address: broadcast ds_read_b128
-            const v2f qx = splat(s.x), qy = splat(s.y), qz = splat(s.z), gm = splat(s.w);
+    // one source body against this lane's P target pairs: 12 packed VALU + 2 v_rsq_f32 per pair of targets
+    auto interact = [&](const float4 s) {
+        const v2f qx = splat(s.x), qy = splat(s.y), qz = splat(s.z), gm = splat(s.w);
 #pragma unroll
-            for (int p = 0; p < P; ++p) {
-                v2f dx = qx - xi[p];
-                v2f dy = qy - yi[p];
-                v2f dz = qz - zi[p];
-                v2f r2 = pk_fma(dx, dx, eps2);
-                r2 = pk_fma(dy, dy, r2);
-                r2 = pk_fma(dz, dz, r2);
-                v2f rinv = (v2f){__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};  // v_rsq_f32 x2
-                v2f rinv2 = rinv * rinv;
-                v2f sc = gm * rinv;
-                sc = sc * rinv2;  // G*m_j / (r2+eps2)^(3/2) ; the self pair gives sc*0 = +0
-                ax[p] = pk_fma(dx, sc, ax[p]);
-                ay[p] = pk_fma(dy, sc, ay[p]);
-                az[p] = pk_fma(dz, sc, az[p]);
-            }
+        for (int p = 0; p < P; ++p) {
+            v2f dx = qx - xi[p];
+            v2f dy = qy - yi[p];
+            v2f dz = qz - zi[p];
+            v2f r2 = pk_fma(dx, dx, eps2);
+            r2 = pk_fma(dy, dy, r2);
+            r2 = pk_fma(dz, dz, r2);
+            v2f rinv = (v2f){__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};  // v_rsq_f32 x2
+            v2f rinv2 = rinv * rinv;
+            v2f sc = gm * rinv;
+            sc = sc * rinv2;  // G*m_j / (r2+eps2)^(3/2) ; the self pair gives sc*0 = +0
+            ax[p] = pk_fma(dx, sc, ax[p]);
+            ay[p] = pk_fma(dy, sc, ay[p]);
+            az[p] = pk_fma(dz, sc, az[p]);
         }
-        // ---- second summation level: fold this tile's partial into the running sum
+    };
+    // second summation level: fold the partial of the last <= 256 sources into the running sum
+    auto flush = [&]() {
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             if (ACC64) {
@@ -162,8 +150,62 @@ __global__ __launch_bounds__(WG, (P >= 4 ? 2 : 4)) void nbody_force_f32(F32Args 
             }
             ax[p] = ay[p] = az[p] = splat(0.f);
         }
-        if (k + 1 < k1) tile[cur ^ 1][t] = nxt;  // buffer cur^1 was last read before the previous barrier
-        __syncthreads();
+    };
+
+    // this workgroup's slice of the sources, in whole tiles (the last slice takes the ragged end)
+    const long ntiles_all = (a.n_src + TILE - 1) / TILE;
+    long k0 = 0, k1 = ntiles_all;
+    if (SPLIT) {
+        const long per = (ntiles_all + gridDim.y - 1) / gridDim.y;
+        k0 = (long)blockIdx.y * per;
+        k1 = k0 + per < ntiles_all ? k0 + per : ntiles_all;
+        if (k0 > k1) k0 = k1;
+    }
+
+    if constexpr (SGPR) {
+        const long j0 = k0 * TILE;
+        const long j1 = k1 * TILE < a.n_src ? k1 * TILE : a.n_src;
+        constexpr int U = SGPR_BATCH;
+        const long jb = j0 + (j1 - j0) / U * U;  // end of the whole batches
+        if (jb > j0) {
+            // wave-uniform addresses on a read-only array: the compiler selects s_load_dwordx16; one batch is
+            // requested ahead of the one being consumed
+            float4 cur[U], nxt[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) cur[u] = a.src[j0 + u];
+            for (long j = j0; j < jb; j += U) {
+                const long jn = (j + U < jb) ? j + U : j0;  // the last prefetch wraps around (harmless re-read)
+#pragma unroll
+                for (int u = 0; u < U; ++u) nxt[u] = a.src[jn + u];
+#pragma unroll
+                for (int u = 0; u < U; ++u) interact(cur[u]);
+#pragma unroll
+                for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+                if ((((j - j0) + U) & (TILE - 1)) == 0) flush();
+            }
+        }
+        for (long j = jb; j < j1; ++j) interact(a.src[j]);  // ragged end, one body at a time
+        flush();
+    } else {
+        auto load_src = [&](long k) -> float4 {
+            long j = k * TILE + t;
+            // bodies past the end are massless points at the origin: with eps2 > 0 they add exactly +0
+            return j < a.n_src ? a.src[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        };
+        if (k0 < k1) {
+            tile[0][t] = load_src(k0);
+            __syncthreads();
+        }
+        for (long k = k0; k < k1; ++k) {
+            const int cur = (int)((k - k0) & 1);
+            float4 nxt;
+            if (k + 1 < k1) nxt = load_src(k + 1);  // in flight while tile k is consumed
+#pragma unroll 4
+            for (int j = 0; j < TILE; ++j) interact(tile[cur][j]);  // wave-uniform address: broadcast ds_read_b128
+            flush();
+            if (k + 1 < k1) tile[cur ^ 1][t] = nxt;  // buffer cur^1 was last read before the previous barrier
+            __syncthreads();
+        }
     }
 
 #pragma unroll
@@ -207,38 +249,41 @@ __global__ __launch_bounds__(WG) void nbody_reduce_update_f32(F32Args a, int js)
     }
 }
 
-template <int P, bool ACC64, bool ACCEL_ONLY>
+template <int P, bool ACC64, bool ACCEL_ONLY, bool SGPR>
 static int launch_one(const F32Args& a, int js, hipStream_t stream) {
     const long per_block = (long)WG * 2 * P;
     const long blocks = (a.n_tgt + per_block - 1) / per_block;
     if (blocks <= 0 || blocks > 0x7fffffffL) return (int)hipErrorInvalidValue;
     if (js <= 1) {
-        hipLaunchKernelGGL((nbody_force_f32<P, ACC64, ACCEL_ONLY, false>), dim3((unsigned)blocks), dim3(WG), 0, stream, a);
+        hipLaunchKernelGGL((nbody_force_f32<P, ACC64, ACCEL_ONLY, false, SGPR>), dim3((unsigned)blocks), dim3(WG), 0, stream, a);
         return (int)hipGetLastError();
     }
     if (!a.partial) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL((nbody_force_f32<P, ACC64, ACCEL_ONLY, true>), dim3((unsigned)blocks, (unsigned)js), dim3(WG), 0,
-                       stream, a);
+    hipLaunchKernelGGL((nbody_force_f32<P, ACC64, ACCEL_ONLY, true, SGPR>), dim3((unsigned)blocks, (unsigned)js), dim3(WG),
+                       0, stream, a);
     if (hipError_t e = hipGetLastError()) return (int)e;
     const long rblocks = (a.n_tgt + WG - 1) / WG;
     hipLaunchKernelGGL((nbody_reduce_update_f32<ACC64, ACCEL_ONLY>), dim3((unsigned)rblocks), dim3(WG), 0, stream, a, js);
     return (int)hipGetLastError();
 }
 
-int launch_f32(const F32Args& a, const F32Plan& plan, bool acc64, bool accel_only, hipStream_t stream) {
-#define NBK_CASE(PP)                                                                                         \
-    case 2 * PP:                                                                                             \
-        if (acc64)                                                                                           \
-            return accel_only ? launch_one<PP, true, true>(a, plan.j_split, stream)                          \
-                              : launch_one<PP, true, false>(a, plan.j_split, stream);                        \
-        return accel_only ? launch_one<PP, false, true>(a, plan.j_split, stream)                             \
-                          : launch_one<PP, false, false>(a, plan.j_split, stream);
-    switch (plan.targets_per_lane) {
-        NBK_CASE(1)
-        NBK_CASE(2)
-        NBK_CASE(4)
+template <int P>
+static int launch_p(const F32Args& a, const F32Plan& plan, bool acc64, bool accel_only, hipStream_t stream) {
+    const int js = plan.j_split;
+    if (plan.sgpr_sources) {
+        if (acc64) return accel_only ? launch_one<P, true, true, true>(a, js, stream) : launch_one<P, true, false, true>(a, js, stream);
+        return accel_only ? launch_one<P, false, true, true>(a, js, stream) : launch_one<P, false, false, true>(a, js, stream);
     }
-#undef NBK_CASE
+    if (acc64) return accel_only ? launch_one<P, true, true, false>(a, js, stream) : launch_one<P, true, false, false>(a, js, stream);
+    return accel_only ? launch_one<P, false, true, false>(a, js, stream) : launch_one<P, false, false, false>(a, js, stream);
+}
+
+int launch_f32(const F32Args& a, const F32Plan& plan, bool acc64, bool accel_only, hipStream_t stream) {
+    switch (plan.targets_per_lane) {
+        case 2: return launch_p<1>(a, plan, acc64, accel_only, stream);
+        case 4: return launch_p<2>(a, plan, acc64, accel_only, stream);
+        case 8: return launch_p<4>(a, plan, acc64, accel_only, stream);
+    }
     return (int)hipErrorInvalidValue;
 }
 
@@ -246,21 +291,25 @@ const char* kernel_name_f32(const F32Plan& plan, bool acc64, bool accel_only) {
     static char buf[8][96];
     static int slot = 0;
     char* s = buf[slot++ & 7];
-    snprintf(s, 96, "nbody_force_f32<%d, %s, %s, %s>", plan.targets_per_lane / 2, acc64 ? "true" : "false",
-             accel_only ? "true" : "false", plan.j_split > 1 ? "true" : "false");
+    snprintf(s, 96, "nbody_force_f32<%d, %s, %s, %s, %s>", plan.targets_per_lane / 2, acc64 ? "true" : "false",
+             accel_only ? "true" : "false", plan.j_split > 1 ? "true" : "false", plan.sgpr_sources ? "true" : "false");
     return s;
 }
 
-// Register blocking and j-split for n_tgt targets against n_src sources on a chip with n_cus CUs:
-//  * R = 4 targets per lane (2 packed pairs) amortises each broadcast LDS read over 4 interactions at
-//    ~64 VGPRs; R = 8 halves the LDS reads again when there are targets to spare; tiny systems use R = 2;
-//  * the grid should hold >= 4 workgroups per CU (>= 4 waves per SIMD: two to alternate on the packed
-//    pipe plus cover for LDS/barrier waits); if the targets alone give fewer, split the source range.
-F32Plan plan_f32(long n_tgt, long n_src, int n_cus, int force_tpl, int force_js, bool have_workspace) {
+// Register blocking and j-split for n_tgt targets against n_src sources on a chip with n_cus CUs
+// (measured: profiles/r01_force_variants.txt, bench.py --targets-per-lane/--j-split):
+//  * R = 8 targets per lane (4 packed pairs, ~150 VGPRs, 2 workgroups per CU) is fastest once the packed pipe
+//    has two waves per SIMD to alternate; R = 4 (4 waves/SIMD) is 1-2 % behind; tiny systems use R = 2;
+//  * the grid must give every SIMD its two waves: >= 2 workgroups per CU for R = 8 (>= 4 for R <= 4, which
+//    need the extra waves to cover their more frequent scalar-load / LDS waits); if the targets alone give
+//    fewer (multi-GPU shards), the source range is split over blockIdx.y and a reducer combines the partials.
+F32Plan plan_f32(long n_tgt, long n_src, int n_cus, int force_tpl, int force_js, bool have_workspace, int source_path) {
     F32Plan p;
+    p.sgpr_sources = source_path != 1;
     int R = force_tpl;
     if (R != 2 && R != 4 && R != 8) {
-        R = 4;
+        R = 8;
+        if (n_tgt < (long)WG * 8 * 8) R = 4;
         if (n_tgt < (long)WG * 4) R = 2;
     }
     p.targets_per_lane = R;
@@ -269,7 +318,7 @@ F32Plan plan_f32(long n_tgt, long n_src, int n_cus, int force_tpl, int force_js,
     int js = force_js;
     if (js <= 0) {
         js = 1;
-        const long want = 4L * n_cus;
+        const long want = (R == 8 ? 2L : 4L) * n_cus;
         while (bx * js < want && js < MAX_JSPLIT && (long)js * 2 * 8 <= ntiles) js <<= 1;  // keep >= 8 tiles per slice
     }
     if (js > MAX_JSPLIT) js = MAX_JSPLIT;

@@ -31,7 +31,7 @@ def shard_range(n, rank, world):
     return rank * per, (rank + 1) * per
 
 
-def hip_compute(acc64=False, targets_per_lane=0, j_split=0):
+def hip_compute(acc64=False, targets_per_lane=0, j_split=0, source_path=0):
     """The product compute step: nb_launch_step_f32 on torch's current HIP stream.  The j-split workspace
     (partial sums when a shard's targets alone cannot fill the chip) is a torch tensor allocated once."""
     ws = {}
@@ -48,7 +48,7 @@ def hip_compute(acc64=False, targets_per_lane=0, j_split=0):
                         vel_ptr=vel.data_ptr() if vel is not None else 0,
                         pos64_ptr=pos64.data_ptr() if pos64 is not None else 0,
                         vel64_ptr=vel64.data_ptr() if vel64 is not None else 0,
-                        acc64=acc64, targets_per_lane=targets_per_lane, j_split=j_split,
+                        acc64=acc64, targets_per_lane=targets_per_lane, j_split=j_split, source_path=source_path,
                         workspace_ptr=w.data_ptr(), workspace_bytes=w.numel())
 
     return compute

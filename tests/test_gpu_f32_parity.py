@@ -45,9 +45,10 @@ def test_accel_f32_acc64(nb, oracle, n):
     assert err < TOL_ACC64, (n, err)
 
 
+@pytest.mark.parametrize("path", [1, 2], ids=["lds", "sgpr"])
 @pytest.mark.parametrize("tpl,js,acc64", [(2, 1, False), (4, 1, False), (8, 1, False), (4, 2, False), (2, 16, False),
                                            (8, 3, False), (4, 4, True), (8, 1, True), (0, 0, False), (0, 0, True)])
-def test_raw_launch_all_register_blockings_and_splits(nb, oracle, tpl, js, acc64):
+def test_raw_launch_all_register_blockings_and_splits(nb, oracle, tpl, js, acc64, path):
     """nb_launch_accel_f32 on torch-owned HBM: every targets-per-lane variant, source splits with the partial-sum
     reducer, a target window inside the sources."""
     import torch
@@ -60,7 +61,7 @@ def test_raw_launch_all_register_blockings_and_splits(nb, oracle, tpl, js, acc64
     nb.capi.launch_f32(src.data_ptr(), 0, n, off, cnt, syn.EPS ** 2, syn.DT,
                        torch.cuda.current_stream().cuda_stream, acc_ptr=acc.data_ptr(), targets_per_lane=tpl,
                        j_split=js, workspace_ptr=ws.data_ptr(), workspace_bytes=ws.numel(), acc64=acc64,
-                       accel_only=True)
+                       source_path=path, accel_only=True)
     torch.cuda.synchronize()
     if tpl == 0:
         r, j = nb.capi.plan_f32(n, cnt, acc64, workspace_bytes=ws.numel())
@@ -79,18 +80,19 @@ def test_split_step_equals_unsplit_step(nb):
     n = 4096 + 5
     pos, vel = syn.body4_f32(n)
     outs = []
-    for js in (1, 4):
+    for js, path in ((1, 2), (4, 2), (1, 1), (3, 1)):
         src = torch.from_numpy(pos).cuda()
         out = torch.zeros_like(src)
         v = torch.from_numpy(vel).cuda()
         ws = torch.empty(nb.capi.workspace_bytes_f32(n), dtype=torch.uint8, device="cuda")
         nb.capi.launch_f32(src.data_ptr(), out.data_ptr(), n, 0, n, syn.EPS ** 2, 1e-2,
                            torch.cuda.current_stream().cuda_stream, vel_ptr=v.data_ptr(), targets_per_lane=4,
-                           j_split=js, workspace_ptr=ws.data_ptr(), workspace_bytes=ws.numel())
+                           j_split=js, source_path=path, workspace_ptr=ws.data_ptr(), workspace_bytes=ws.numel())
         torch.cuda.synchronize()
         outs.append((out.cpu().numpy(), v.cpu().numpy()))
     assert np.array_equal(outs[0][0][:, 3], pos[:, 3])
-    assert np.abs(outs[0][0] - outs[1][0]).max() < 1e-6 and np.abs(outs[0][1] - outs[1][1]).max() < 1e-5
+    for o in outs[1:]:
+        assert np.abs(outs[0][0] - o[0]).max() < 1e-6 and np.abs(outs[0][1] - o[1]).max() < 1e-5
     assert not np.array_equal(outs[0][0][:, :3], pos[:, :3])
 
 
