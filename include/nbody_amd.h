@@ -121,6 +121,15 @@ int nb_run_scenario(nb_context* ctx, const nb_scenario* scn, nb_scenario_result*
  * missile arrival into `dst` (same n, precision F64, same GPU or not); hw5.cu:482-484 */
 int nb_restore_snapshot(nb_context* dst, nb_context* src, int watch_slot);
 
+/* ---- binary state files (checkpoint / large-N input; the reference only has the text format, nbody.cc:22-49,
+ *      and an in-memory snapshot, hw5.cu:265-287).  Layout, little endian:
+ *        char magic[8] = "NBODYST1"; int64 n; int32 precision; int32 step; double G, eps, dt;
+ *        double q[3][n]; double v[3][n]; double m[n]; uint8 is_device[n]
+ *      q,v are the fp64 masters (F64 / F32_ACC64) or the widened fp32 state (F32). ---- */
+int nb_save_state(nb_context* ctx, const char* path, int step);
+int nb_load_state(nb_context* ctx, const char* path, int* step); /* n must match the context */
+int nb_state_file_info(const char* path, int64_t* n, int* precision, int* step);
+
 /* ---- whole reference program: P1, P2, P3 (nbody.cc:106-146 ; hw5.cu:532-606) ---- */
 typedef struct nb_answer {
     double min_dist;

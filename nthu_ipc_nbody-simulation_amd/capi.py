@@ -61,6 +61,9 @@ SYMBOLS = {
     "nb_step_timed": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "nb_run_scenario": (C.c_int, [C.c_void_p, C.POINTER(NbScenario), C.POINTER(NbScenarioResult)]),
     "nb_restore_snapshot": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "nb_save_state": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "nb_load_state": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]),
+    "nb_state_file_info": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "nb_solve": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _u8p,
                            C.POINTER(C.c_int), C.c_int, C.POINTER(NbAnswer)]),
     "nb_launch_step_f32": (C.c_int, [C.POINTER(NbLaunchF32), C.c_void_p]),
@@ -211,8 +214,23 @@ class Context:
         return dict(min_dist2=r.min_dist2, hit_step=r.hit_step, steps_done=r.steps_done,
                     arrival_step=list(r.arrival_step[:len(watch)]), missile_cost=list(r.missile_cost[:len(watch)]))
 
+    def save_state(self, path, step=0):
+        _check(lib().nb_save_state(self._h, os.fsencode(path), step), "nb_save_state", self._h)
+
+    def load_state(self, path):
+        step = C.c_int()
+        _check(lib().nb_load_state(self._h, os.fsencode(path), C.byref(step)), "nb_load_state", self._h)
+        return step.value
+
     def restore_snapshot_from(self, src, slot):
         _check(lib().nb_restore_snapshot(self._h, src._h, slot), "nb_restore_snapshot", self._h)
+
+
+def state_file_info(path):
+    """-> (n, precision, step) of a binary state file written by nb_save_state."""
+    n, prec, step = C.c_int64(), C.c_int(), C.c_int()
+    _check(lib().nb_state_file_info(os.fsencode(path), C.byref(n), C.byref(prec), C.byref(step)), "nb_state_file_info")
+    return n.value, prec.value, step.value
 
 
 def solve(n, planet, asteroid, q, v, m, is_device, devices=None):

@@ -499,6 +499,77 @@ int nb_restore_snapshot(nb_context* dst, nb_context* src, int slot) {
                         src->m_host.data(), src->dev_host.data());
 }
 
+// ---------------------------------------------------------------- binary state files
+namespace {
+struct StateHeader {
+    char magic[8];
+    int64_t n;
+    int32_t precision;
+    int32_t step;
+    double G, eps, dt;
+};
+const char kMagic[8] = {'N', 'B', 'O', 'D', 'Y', 'S', 'T', '1'};
+}  // namespace
+
+int nb_state_file_info(const char* path, int64_t* n, int* precision, int* step) {
+    if (!path) return NB_ERR_INVALID;
+    FILE* f = fopen(path, "rb");
+    if (!f) return NB_ERR_IO;
+    StateHeader h;
+    const bool ok = fread(&h, sizeof h, 1, f) == 1 && memcmp(h.magic, kMagic, 8) == 0 && h.n > 0;
+    fclose(f);
+    if (!ok) return NB_ERR_IO;
+    if (n) *n = h.n;
+    if (precision) *precision = h.precision;
+    if (step) *step = h.step;
+    return NB_OK;
+}
+
+int nb_save_state(nb_context* c, const char* path, int step) {
+    if (!c || !path) return NB_ERR_INVALID;
+    if (!c->have_state) return NB_ERR_STATE;
+    const size_t n = (size_t)c->n;
+    std::vector<double> buf(6 * n);
+    if (int rc = nb_get_state(c, &buf[0], &buf[n], &buf[2 * n], &buf[3 * n], &buf[4 * n], &buf[5 * n])) return rc;
+    StateHeader h;
+    memcpy(h.magic, kMagic, 8);
+    h.n = c->n;
+    h.precision = c->cfg.precision;
+    h.step = step;
+    h.G = c->cfg.G;
+    h.eps = c->cfg.eps;
+    h.dt = c->cfg.dt;
+    FILE* f = fopen(path, "wb");
+    if (!f) return NB_ERR_IO;
+    bool ok = fwrite(&h, sizeof h, 1, f) == 1 && fwrite(buf.data(), sizeof(double), 6 * n, f) == 6 * n &&
+              fwrite(c->m_host.data(), sizeof(double), n, f) == n && fwrite(c->dev_host.data(), 1, n, f) == n;
+    ok = (fclose(f) == 0) && ok;
+    return ok ? NB_OK : NB_ERR_IO;
+}
+
+int nb_load_state(nb_context* c, const char* path, int* step) {
+    if (!c || !path) return NB_ERR_INVALID;
+    FILE* f = fopen(path, "rb");
+    if (!f) return NB_ERR_IO;
+    StateHeader h;
+    if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, kMagic, 8) != 0) {
+        fclose(f);
+        return NB_ERR_IO;
+    }
+    if (h.n != c->n) {
+        fclose(f);
+        return NB_ERR_INVALID;
+    }
+    const size_t n = (size_t)c->n;
+    std::vector<double> buf(7 * n);
+    std::vector<uint8_t> dev(n);
+    const bool ok = fread(buf.data(), sizeof(double), 7 * n, f) == 7 * n && fread(dev.data(), 1, n, f) == n;
+    fclose(f);
+    if (!ok) return NB_ERR_IO;
+    if (step) *step = h.step;
+    return nb_set_state(c, &buf[0], &buf[n], &buf[2 * n], &buf[3 * n], &buf[4 * n], &buf[5 * n], &buf[6 * n], dev.data());
+}
+
 // ---------------------------------------------------------------- whole program
 int nb_solve(int n, int planet, int asteroid, const double* qx, const double* qy, const double* qz,
              const double* vx, const double* vy, const double* vz, const double* m, const uint8_t* is_device,

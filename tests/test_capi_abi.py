@@ -56,3 +56,18 @@ def test_product_never_imports_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text and "liboracle" not in text \
                     and "nbody_oracle" not in text, f
+
+
+def test_state_file_header_errors(nb, tmp_path):
+    """nb_state_file_info needs no GPU: bad path / bad magic are I/O errors, not crashes."""
+    with pytest.raises(nb.capi.NBodyError) as e:
+        nb.capi.state_file_info(str(tmp_path / "missing.nbst"))
+    assert e.value.code == nb.capi.NB_ERR_IO
+    bad = tmp_path / "bad.nbst"
+    bad.write_bytes(b"NOTASTATEFILE" * 8)
+    with pytest.raises(nb.capi.NBodyError):
+        nb.capi.state_file_info(str(bad))
+    import struct
+    good = tmp_path / "hdr.nbst"
+    good.write_bytes(b"NBODYST1" + struct.pack("<qiiddd", 7, 0, 123, 6.674e-11, 1e-3, 60.0))
+    assert nb.capi.state_file_info(str(good)) == (7, 0, 123)

@@ -149,3 +149,24 @@ def test_cli_argument_contract(nb):
     p = subprocess.run([os.path.join(root, "bin", "hw5")], capture_output=True)
     assert p.returncode in (-6, 134)
     assert b"must supply 2 arguments" in p.stderr
+
+
+def test_checkpoint_resume_is_bitwise(nb, oracle, tmp_path):
+    """Binary state file: save at step 50, load into a fresh context, continue -> same bits as the
+    uninterrupted run; the file also carries masses and the device predicate."""
+    s = oracle.read_input(case_path("b70", "in"))
+    with _ctx(nb, s) as ctx:
+        ctx.step(1, 120)
+        q_ref, v_ref = ctx.get_state()
+    path = str(tmp_path / "b70.nbst")
+    with _ctx(nb, s) as ctx:
+        ctx.step(1, 50)
+        ctx.save_state(path, step=50)
+    assert nb.capi.state_file_info(path) == (s.n, nb.capi.NB_F64, 50)
+    with nb.capi.Context(s.n) as ctx:
+        step = ctx.load_state(path)
+        ctx.step(step + 1, 120 - step)
+        q, v = ctx.get_state()
+    assert np.array_equal(q, q_ref) and np.array_equal(v, v_ref)
+    with nb.capi.Context(s.n + 1) as ctx, pytest.raises(nb.capi.NBodyError):
+        ctx.load_state(path)
