@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--targets-per-lane", type=int, default=0)
     ap.add_argument("--j-split", type=int, default=0)
     ap.add_argument("--source-path", type=int, default=0, help="0 auto, 1 LDS tile, 2 SGPR/scalar loads")
+    ap.add_argument("--wg-size", type=int, default=0, help="0 auto, 256, 512 (with --targets-per-lane 8), 1024 (4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -113,7 +114,7 @@ def main():
         import numpy as np
         pos = np.concatenate([q.T, (synthetic.G * m)[:, None]], axis=1)
         vel = np.concatenate([v.T, np.zeros((hi - lo, 1))], axis=1)
-    compute = hip_compute(acc64, args.targets_per_lane, args.j_split, args.source_path)
+    compute = hip_compute(acc64, args.targets_per_lane, args.j_split, args.source_path, args.wg_size)
     sysm = ShardedSystem(n, torch.from_numpy(pos), torch.from_numpy(vel), synthetic.EPS, synthetic.DT, device,
                          compute=compute, acc64=acc64)
 
@@ -158,8 +159,9 @@ def main():
         achieved = flops_launch / (k_ms * 1e-3) / 1e12
         ws_bytes = capi.workspace_bytes_f32(sysm.n_tgt, acc64)
         kname = capi.kernel_name_f32(n, sysm.n_tgt, acc64, args.targets_per_lane, args.j_split, ws_bytes,
-                                     source_path=args.source_path)
-        tpl, jsp = capi.plan_f32(n, sysm.n_tgt, acc64, args.targets_per_lane, args.j_split, ws_bytes, args.source_path)
+                                     source_path=args.source_path, wg_size=args.wg_size)
+        tpl, jsp, wgs = capi.plan_f32(n, sysm.n_tgt, acc64, args.targets_per_lane, args.j_split, ws_bytes,
+                                      args.source_path, args.wg_size)
         out = {
             "metric": "body-pair interactions/sec",
             "value": value,
@@ -179,7 +181,7 @@ def main():
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_TFLOPS, "traffic": load_traffic(n, world),
-                         "kernel": kname, "kernel_ms": k_ms, "targets_per_lane": tpl, "j_split": jsp, "flop_per_pair": FLOP_PER_PAIR,
+                         "kernel": kname, "kernel_ms": k_ms, "targets_per_lane": tpl, "j_split": jsp, "wg_size": wgs, "flop_per_pair": FLOP_PER_PAIR,
                          "bound_detail": "compute roofline = fp32 vector-FMA peak 157.3 TFLOP/s (== dense f32 MFMA "
                                          "peak); kernel is VALU + v_rsq_f32, MFMA deliberately unused"},
         }

@@ -93,8 +93,8 @@ __device__ __forceinline__ void interact_staged(const float4* s, const v2f* xi, 
 #undef ST
 }
 
-template <int P, int VAR, int U, int MINW>
-__global__ __launch_bounds__(WG, MINW) void force(const float4* __restrict__ src_all, long n_src_all, long n_tgt,
+template <int P, int VAR, int U, int MINW, int WGS = 256, bool SYNC = false>
+__global__ __launch_bounds__(WGS, MINW) void force(const float4* __restrict__ src_all, long n_src_all, long n_tgt,
                                                   float4* __restrict__ acc_all, float eps2s) {
     const long n_src = n_src_all / gridDim.y;
     const float4* __restrict__ src = src_all + (long)blockIdx.y * n_src;
@@ -102,6 +102,7 @@ __global__ __launch_bounds__(WG, MINW) void force(const float4* __restrict__ src
     __shared__ float4 tile[2][TILE];
     constexpr int R = 2 * P;
     const int t = threadIdx.x;
+    constexpr int WG = WGS;
     const long base = (long)blockIdx.x * (WG * R);
     v2f xi[P], yi[P], zi[P];
 #pragma unroll
@@ -150,7 +151,10 @@ __global__ __launch_bounds__(WG, MINW) void force(const float4* __restrict__ src
             for (int u = 0; u < U; ++u) interact<P>(cur[u], xi, yi, zi, eps2, A);
 #pragma unroll
             for (int u = 0; u < U; ++u) cur[u] = nxt[u];
-            if (((j + U) & (TILE - 1)) == 0) A.flush();
+            if (((j + U) & (TILE - 1)) == 0) {
+                A.flush();
+                if (SYNC) __syncthreads();  // keep the workgroup's waves within one tile of each other (L2 locality)
+            }
         }
     } else {
         tile[0][t] = src[t];
@@ -185,10 +189,10 @@ __global__ __launch_bounds__(WG, MINW) void force(const float4* __restrict__ src
 
 static std::vector<float4> ref_acc;
 
-template <int P, int VAR, int U, int MINW>
+template <int P, int VAR, int U, int MINW, int WGS = 256, bool SYNC = false>
 static void run(const char* name, const float4* d_src, long n_src, long n_tgt, float4* d_acc, int js = 1) {
-    const long blocks = (n_tgt + WG * 2 * P - 1) / (WG * 2 * P);
-    auto launch = [&] { hipLaunchKernelGGL((force<P, VAR, U, MINW>), dim3(blocks, js), dim3(WG), 0, 0, d_src, n_src, n_tgt, d_acc, 1e-6f); };
+    const long blocks = (n_tgt + WGS * 2 * P - 1) / (WGS * 2 * P);
+    auto launch = [&] { hipLaunchKernelGGL((force<P, VAR, U, MINW, WGS, SYNC>), dim3(blocks, js), dim3(WGS), 0, 0, d_src, n_src, n_tgt, d_acc, 1e-6f); };
     launch();
     CK(hipDeviceSynchronize());
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -225,22 +229,12 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&d_src, n_tgt * sizeof(float4))); CK(hipMalloc(&d_acc, 4 * n_tgt * sizeof(float4)));
     CK(hipMemcpy(d_src, h.data(), n_tgt * sizeof(float4), hipMemcpyHostToDevice));
     printf("n_tgt=%ld n_src=%ld\n", n_tgt, n_src);
-    run<2, V_LDS, 4, 4>("LDS   P=2 unroll4 (product)", d_src, n_src, n_tgt, d_acc);
-    run<4, V_SMEM, 8, 2>("SMEM  P=4 U=8 2w", d_src, n_src, n_tgt, d_acc);
-    run<4, V_SMEM, 16, 2>("SMEM  P=4 U=16 2w", d_src, n_src, n_tgt, d_acc);
-    run<4, V_SMEM, 4, 2>("SMEM  P=4 U=4 2w", d_src, n_src, n_tgt, d_acc);
-    run<2, V_SMEM, 16, 4>("SMEM  P=2 U=16 4w", d_src, n_src, n_tgt, d_acc);
-    run<2, V_SMEM, 8, 4>("SMEM  P=2 U=8 4w", d_src, n_src, n_tgt, d_acc);
-    run<4, V_SMEM, 8, 3>("SMEM  P=4 U=8 3w js2", d_src, n_src, n_tgt, d_acc, 2);
-    run<4, V_SMEM, 8, 4>("SMEM  P=4 U=8 4w js2", d_src, n_src, n_tgt, d_acc, 2);
-    run<4, V_SMEM, 8, 2>("SMEM  P=4 U=8 2w js2", d_src, n_src, n_tgt, d_acc, 2);
-    run<2, V_SMEM, 8, 4>("SMEM  P=2 U=8 4w js2", d_src, n_src, n_tgt, d_acc, 2);
-    run<2, V_SMEM, 8, 8>("SMEM  P=2 U=8 8w js2", d_src, n_src, n_tgt, d_acc, 2);
-    run<1, V_SMEM, 8, 8>("SMEM  P=1 U=8 8w", d_src, n_src, n_tgt, d_acc);
-    run<1, V_SMEM, 16, 8>("SMEM  P=1 U=16 8w", d_src, n_src, n_tgt, d_acc);
-    run<4, V_SMEM_PF, 4, 2>("SMEMPF P=4 U=4 2w", d_src, n_src, n_tgt, d_acc);
-    run<4, V_SMEM_PF, 4, 3>("SMEMPF P=4 U=4 3w js2", d_src, n_src, n_tgt, d_acc, 2);
-    run<6, V_SMEM, 4, 1>("SMEM  P=6 U=4 1w", d_src, n_src, n_tgt, d_acc);
-    run<8, V_SMEM, 4, 1>("SMEM  P=8 U=4 1w", d_src, n_src, n_tgt, d_acc);
+    run<4, V_SMEM, 8, 2>("SMEM P=4 U=8 wg256", d_src, n_src, n_tgt, d_acc);
+    run<4, V_SMEM, 8, 2, 256, true>("SMEM P=4 U=8 wg256 sync", d_src, n_src, n_tgt, d_acc);
+    run<4, V_SMEM, 8, 2, 512, false>("SMEM P=4 U=8 wg512", d_src, n_src, n_tgt, d_acc);
+    run<4, V_SMEM, 8, 2, 512, true>("SMEM P=4 U=8 wg512 sync", d_src, n_src, n_tgt, d_acc);
+    run<4, V_SMEM, 8, 1, 1024, true>("SMEM P=4 U=8 wg1024 sync", d_src, n_src, n_tgt, d_acc);
+    run<2, V_SMEM, 8, 4, 1024, true>("SMEM P=2 U=8 wg1024 sync", d_src, n_src, n_tgt, d_acc);
+    run<2, V_SMEM, 8, 4, 256, false>("SMEM P=2 U=8 wg256", d_src, n_src, n_tgt, d_acc);
     return 0;
 }

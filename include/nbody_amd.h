@@ -169,13 +169,15 @@ typedef struct nb_launch_f32 {
     int32_t targets_per_lane; /* 0 = auto; 2, 4 or 8 (packed pairs of targets per lane) */
     int32_t j_split;          /* 0 = auto; 1..16 workgroups share a target block, each over a slice of the sources */
     int32_t source_path;      /* 0 = auto; 1 = sources through the LDS tile; 2 = sources through scalar loads/SGPRs */
+    int32_t wg_size;          /* 0 = auto; 256, 512 (targets_per_lane 8) or 1024 (targets_per_lane 4) */
+    int32_t reserved;
 } nb_launch_f32;
 int nb_launch_step_f32(const nb_launch_f32* a, void* hip_stream);  /* force + fused kick-drift */
 int nb_launch_accel_f32(const nb_launch_f32* a, void* hip_stream); /* force only -> a->acc */
 /* name of the kernel symbol the two launches above resolve to for these arguments (for matching rocprofv3 rows) */
 const char* nb_kernel_name_f32(const nb_launch_f32* a, int accel_only);
-/* the register blocking and source split the launches above will use for these arguments */
-int nb_plan_f32(const nb_launch_f32* a, int* targets_per_lane, int* j_split);
+/* the register blocking, source split and workgroup size the launches above will use for these arguments */
+int nb_plan_f32(const nb_launch_f32* a, int* targets_per_lane, int* j_split, int* wg_size);
 /* workspace size that allows any split for n_tgt targets */
 int64_t nb_workspace_bytes_f32(int64_t n_tgt, int acc64);
 

@@ -41,7 +41,8 @@ class NbLaunchF32(C.Structure):
                 ("vel64", C.c_void_p), ("acc", C.c_void_p), ("workspace", C.c_void_p),
                 ("workspace_bytes", C.c_int64), ("n_src", C.c_int64), ("tgt_off", C.c_int64),
                 ("n_tgt", C.c_int64), ("eps2", C.c_float), ("dt", C.c_float), ("acc64", C.c_int32),
-                ("targets_per_lane", C.c_int32), ("j_split", C.c_int32), ("source_path", C.c_int32)]
+                ("targets_per_lane", C.c_int32), ("j_split", C.c_int32), ("source_path", C.c_int32),
+                ("wg_size", C.c_int32), ("reserved", C.c_int32)]
 
 
 # every symbol include/nbody_amd.h declares: (restype, argtypes)
@@ -69,7 +70,7 @@ SYMBOLS = {
     "nb_launch_step_f32": (C.c_int, [C.POINTER(NbLaunchF32), C.c_void_p]),
     "nb_launch_accel_f32": (C.c_int, [C.POINTER(NbLaunchF32), C.c_void_p]),
     "nb_kernel_name_f32": (C.c_char_p, [C.POINTER(NbLaunchF32), C.c_int]),
-    "nb_plan_f32": (C.c_int, [C.POINTER(NbLaunchF32), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "nb_plan_f32": (C.c_int, [C.POINTER(NbLaunchF32), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "nb_workspace_bytes_f32": (C.c_int64, [C.c_int64, C.c_int]),
 }
 
@@ -249,10 +250,11 @@ def solve(n, planet, asteroid, q, v, m, is_device, devices=None):
 
 
 def _launch_struct(src_ptr, out_ptr, n_src, tgt_off, n_tgt, eps2, dt, vel_ptr=0, pos64_ptr=0, vel64_ptr=0, acc_ptr=0,
-                   acc64=False, targets_per_lane=0, j_split=0, workspace_ptr=0, workspace_bytes=0, source_path=0):
+                   acc64=False, targets_per_lane=0, j_split=0, workspace_ptr=0, workspace_bytes=0, source_path=0,
+                   wg_size=0):
     return NbLaunchF32(src_ptr or None, out_ptr or None, vel_ptr or None, pos64_ptr or None, vel64_ptr or None,
                        acc_ptr or None, workspace_ptr or None, workspace_bytes, n_src, tgt_off, n_tgt, eps2, dt,
-                       int(acc64), targets_per_lane, j_split, source_path)
+                       int(acc64), targets_per_lane, j_split, source_path, wg_size, 0)
 
 
 def launch_f32(src_ptr, out_ptr, n_src, tgt_off, n_tgt, eps2, dt, stream, accel_only=False, **kw):
@@ -263,14 +265,14 @@ def launch_f32(src_ptr, out_ptr, n_src, tgt_off, n_tgt, eps2, dt, stream, accel_
     _check(f(C.byref(a), C.c_void_p(stream)), "nb_launch_accel_f32" if accel_only else "nb_launch_step_f32")
 
 
-def plan_f32(n_src, n_tgt, acc64=False, targets_per_lane=0, j_split=0, workspace_bytes=0, source_path=0):
-    """(targets_per_lane, j_split) the launches will use; workspace_bytes > 0 means a workspace will be passed."""
+def plan_f32(n_src, n_tgt, acc64=False, targets_per_lane=0, j_split=0, workspace_bytes=0, source_path=0, wg_size=0):
+    """(targets_per_lane, j_split, wg_size) the launches will use; workspace_bytes > 0 = a workspace will be passed."""
     a = _launch_struct(1, 0, n_src, 0, n_tgt, 1.0, 1.0, acc64=acc64, targets_per_lane=targets_per_lane,
                        j_split=j_split, workspace_ptr=1 if workspace_bytes else 0, workspace_bytes=workspace_bytes,
-                       source_path=source_path)
-    r, j = C.c_int(), C.c_int()
-    _check(lib().nb_plan_f32(C.byref(a), C.byref(r), C.byref(j)), "nb_plan_f32")
-    return r.value, j.value
+                       source_path=source_path, wg_size=wg_size)
+    r, j, w = C.c_int(), C.c_int(), C.c_int()
+    _check(lib().nb_plan_f32(C.byref(a), C.byref(r), C.byref(j), C.byref(w)), "nb_plan_f32")
+    return r.value, j.value, w.value
 
 
 def workspace_bytes_f32(n_tgt, acc64=False):
@@ -278,8 +280,8 @@ def workspace_bytes_f32(n_tgt, acc64=False):
 
 
 def kernel_name_f32(n_src, n_tgt, acc64=False, targets_per_lane=0, j_split=0, workspace_bytes=0, accel_only=False,
-                    source_path=0):
+                    source_path=0, wg_size=0):
     a = _launch_struct(1, 0, n_src, 0, n_tgt, 1.0, 1.0, acc64=acc64, targets_per_lane=targets_per_lane,
                        j_split=j_split, workspace_ptr=1 if workspace_bytes else 0, workspace_bytes=workspace_bytes,
-                       source_path=source_path)
+                       source_path=source_path, wg_size=wg_size)
     return lib().nb_kernel_name_f32(C.byref(a), int(accel_only)).decode()

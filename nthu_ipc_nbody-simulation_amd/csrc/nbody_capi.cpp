@@ -698,6 +698,7 @@ static int check_launch(const nb_launch_f32* a, bool accel_only) {
     if (a->j_split < 0 || a->j_split > MAX_JSPLIT) return NB_ERR_INVALID;
     if (a->j_split > 1 && !a->workspace) return NB_ERR_INVALID;
     if (a->source_path < 0 || a->source_path > 2) return NB_ERR_INVALID;
+    if (a->wg_size != 0 && a->wg_size != 256 && a->wg_size != 512 && a->wg_size != 1024) return NB_ERR_INVALID;
     return NB_OK;
 }
 
@@ -705,7 +706,7 @@ static F32Plan resolve_plan(const nb_launch_f32* a) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     F32Plan p = plan_f32(a->n_tgt, a->n_src, cus, a->targets_per_lane, a->j_split, a->workspace != nullptr,
-                         a->source_path);
+                         a->source_path, a->wg_size);
     // the caller's workspace must hold j_split slices of n_tgt records
     const size_t rec = a->acc64 ? sizeof(double4) : sizeof(float4);
     while (p.j_split > 1 && (size_t)p.j_split * (size_t)a->n_tgt * rec > (size_t)a->workspace_bytes) p.j_split >>= 1;
@@ -746,11 +747,12 @@ const char* nb_kernel_name_f32(const nb_launch_f32* a, int accel_only) {
     return kernel_name_f32(resolve_plan(a), a->acc64 != 0, accel_only != 0);
 }
 
-int nb_plan_f32(const nb_launch_f32* a, int* targets_per_lane, int* j_split) {
+int nb_plan_f32(const nb_launch_f32* a, int* targets_per_lane, int* j_split, int* wg_size) {
     if (!a || a->n_src <= 0 || a->n_tgt <= 0) return NB_ERR_INVALID;
     F32Plan p = resolve_plan(a);
     if (targets_per_lane) *targets_per_lane = p.targets_per_lane;
     if (j_split) *j_split = p.j_split;
+    if (wg_size) *wg_size = p.wg_size;
     return NB_OK;
 }
 

@@ -28,10 +28,11 @@ struct F32Plan {
     int targets_per_lane = 4;  // 2, 4 or 8 (one, two or four packed pairs per lane)
     int j_split = 1;           // workgroups sharing one target block, each over 1/j_split of the sources
     bool sgpr_sources = true;  // sources via scalar loads into SGPRs (default) instead of the LDS tile
+    int wg_size = 256;         // threads per workgroup: 256, 512 (R = 8) or 1024 (R = 4); LDS path: 256
 };
-// source_path: 0 = auto (SGPR), 1 = LDS tile, 2 = SGPR
+// source_path: 0 = auto (SGPR), 1 = LDS tile, 2 = SGPR ; force_wg: 0 = auto
 F32Plan plan_f32(long n_tgt, long n_src, int n_cus, int force_tpl, int force_js, bool have_workspace,
-                 int source_path = 0);
+                 int source_path = 0, int force_wg = 0);
 int launch_f32(const F32Args& a, const F32Plan& plan, bool acc64, bool accel_only, hipStream_t stream);  // hipError_t
 const char* kernel_name_f32(const F32Plan& plan, bool acc64, bool accel_only);
 

@@ -82,9 +82,16 @@ constexpr int SGPR_BATCH = 8;  // bodies per scalar-load batch (32 SGPRs; two ba
 
 // P = target PAIRS per lane (R = 2P targets).  SPLIT: blockIdx.y selects a slice of the sources and the partial
 // sums go to a.partial instead of the epilogue.  SGPR: sources via scalar loads instead of the LDS tile.
-template <int P, bool ACC64, bool ACCEL_ONLY, bool SPLIT, bool SGPR>
-__global__ __launch_bounds__(WG, (P >= 4 ? 2 : 4)) void nbody_force_f32(F32Args a) {
+// WGS = workgroup size.  The SGPR path has no LDS tile to fill, so its workgroup can be as large as the register
+// file allows: with ONE workgroup per CU and a barrier per 256 sources all waves of a CU stay within one tile
+// of each other and every source line is fetched once per XCD (measured, profiles/
+// r01_force_variants_wgsize_traffic.txt: 140 MB per step = 8 XCDs x 16.8 MB, the floor; two independent 256-thread
+// workgroups per CU drift apart — oldest-wave-first issue arbitration — and fetch it twice, four fetch it 4x).
+template <int P, bool ACC64, bool ACCEL_ONLY, bool SPLIT, bool SGPR, int WGS>
+__global__ __launch_bounds__(WGS, (WGS == 1024 ? 4 : WGS == 512 ? 2 : (P >= 4 ? 2 : 4))) void nbody_force_f32(F32Args a) {
+    static_assert(SGPR || WGS == TILE, "the LDS path stages one source per thread");
     __shared__ float4 tile[SGPR ? 1 : 2][SGPR ? 1 : TILE];
+    constexpr int WG = WGS;  // shadows nbk::WG inside this kernel
     constexpr int R = 2 * P;
     const int t = threadIdx.x;
     const long base = (long)blockIdx.x * (WG * R);
@@ -181,7 +188,10 @@ __global__ __launch_bounds__(WG, (P >= 4 ? 2 : 4)) void nbody_force_f32(F32Args 
                 for (int u = 0; u < U; ++u) interact(cur[u]);
 #pragma unroll
                 for (int u = 0; u < U; ++u) cur[u] = nxt[u];
-                if ((((j - j0) + U) & (TILE - 1)) == 0) flush();
+                if ((((j - j0) + U) & (TILE - 1)) == 0) {
+                    flush();
+                    __syncthreads();  // trip counts are workgroup-uniform: keeps the waves on one L2-resident tile
+                }
             }
         }
         for (long j = jb; j < j1; ++j) interact(a.src[j]);  // ragged end, one body at a time
@@ -249,76 +259,95 @@ __global__ __launch_bounds__(WG) void nbody_reduce_update_f32(F32Args a, int js)
     }
 }
 
-template <int P, bool ACC64, bool ACCEL_ONLY, bool SGPR>
+template <int P, bool ACC64, bool ACCEL_ONLY, bool SGPR, int WGS>
 static int launch_one(const F32Args& a, int js, hipStream_t stream) {
-    const long per_block = (long)WG * 2 * P;
+    const long per_block = (long)WGS * 2 * P;
     const long blocks = (a.n_tgt + per_block - 1) / per_block;
     if (blocks <= 0 || blocks > 0x7fffffffL) return (int)hipErrorInvalidValue;
     if (js <= 1) {
-        hipLaunchKernelGGL((nbody_force_f32<P, ACC64, ACCEL_ONLY, false, SGPR>), dim3((unsigned)blocks), dim3(WG), 0, stream, a);
+        hipLaunchKernelGGL((nbody_force_f32<P, ACC64, ACCEL_ONLY, false, SGPR, WGS>), dim3((unsigned)blocks), dim3(WGS), 0,
+                           stream, a);
         return (int)hipGetLastError();
     }
     if (!a.partial) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL((nbody_force_f32<P, ACC64, ACCEL_ONLY, true, SGPR>), dim3((unsigned)blocks, (unsigned)js), dim3(WG),
-                       0, stream, a);
+    hipLaunchKernelGGL((nbody_force_f32<P, ACC64, ACCEL_ONLY, true, SGPR, WGS>), dim3((unsigned)blocks, (unsigned)js),
+                       dim3(WGS), 0, stream, a);
     if (hipError_t e = hipGetLastError()) return (int)e;
     const long rblocks = (a.n_tgt + WG - 1) / WG;
     hipLaunchKernelGGL((nbody_reduce_update_f32<ACC64, ACCEL_ONLY>), dim3((unsigned)rblocks), dim3(WG), 0, stream, a, js);
     return (int)hipGetLastError();
 }
 
-template <int P>
-static int launch_p(const F32Args& a, const F32Plan& plan, bool acc64, bool accel_only, hipStream_t stream) {
-    const int js = plan.j_split;
-    if (plan.sgpr_sources) {
-        if (acc64) return accel_only ? launch_one<P, true, true, true>(a, js, stream) : launch_one<P, true, false, true>(a, js, stream);
-        return accel_only ? launch_one<P, false, true, true>(a, js, stream) : launch_one<P, false, false, true>(a, js, stream);
-    }
-    if (acc64) return accel_only ? launch_one<P, true, true, false>(a, js, stream) : launch_one<P, true, false, false>(a, js, stream);
-    return accel_only ? launch_one<P, false, true, false>(a, js, stream) : launch_one<P, false, false, false>(a, js, stream);
+template <int P, bool SGPR, int WGS>
+static int launch_p(const F32Args& a, int js, bool acc64, bool accel_only, hipStream_t stream) {
+    if (acc64) return accel_only ? launch_one<P, true, true, SGPR, WGS>(a, js, stream) : launch_one<P, true, false, SGPR, WGS>(a, js, stream);
+    return accel_only ? launch_one<P, false, true, SGPR, WGS>(a, js, stream) : launch_one<P, false, false, SGPR, WGS>(a, js, stream);
 }
 
+// valid (source path, workgroup size, targets per lane) combinations; anything else is refused
 int launch_f32(const F32Args& a, const F32Plan& plan, bool acc64, bool accel_only, hipStream_t stream) {
-    switch (plan.targets_per_lane) {
-        case 2: return launch_p<1>(a, plan, acc64, accel_only, stream);
-        case 4: return launch_p<2>(a, plan, acc64, accel_only, stream);
-        case 8: return launch_p<4>(a, plan, acc64, accel_only, stream);
+    const int R = plan.targets_per_lane, js = plan.j_split, wg = plan.wg_size;
+    if (!plan.sgpr_sources) {
+        if (wg != 256) return (int)hipErrorInvalidValue;
+        if (R == 2) return launch_p<1, false, 256>(a, js, acc64, accel_only, stream);
+        if (R == 4) return launch_p<2, false, 256>(a, js, acc64, accel_only, stream);
+        if (R == 8) return launch_p<4, false, 256>(a, js, acc64, accel_only, stream);
+        return (int)hipErrorInvalidValue;
     }
+    if (wg == 1024 && R == 4) return launch_p<2, true, 1024>(a, js, acc64, accel_only, stream);
+    if (wg == 512 && R == 8) return launch_p<4, true, 512>(a, js, acc64, accel_only, stream);
+    if (wg == 256 && R == 2) return launch_p<1, true, 256>(a, js, acc64, accel_only, stream);
+    if (wg == 256 && R == 4) return launch_p<2, true, 256>(a, js, acc64, accel_only, stream);
+    if (wg == 256 && R == 8) return launch_p<4, true, 256>(a, js, acc64, accel_only, stream);
     return (int)hipErrorInvalidValue;
 }
 
 const char* kernel_name_f32(const F32Plan& plan, bool acc64, bool accel_only) {
-    static char buf[8][96];
+    static char buf[8][112];
     static int slot = 0;
     char* s = buf[slot++ & 7];
-    snprintf(s, 96, "nbody_force_f32<%d, %s, %s, %s, %s>", plan.targets_per_lane / 2, acc64 ? "true" : "false",
-             accel_only ? "true" : "false", plan.j_split > 1 ? "true" : "false", plan.sgpr_sources ? "true" : "false");
+    snprintf(s, 112, "nbody_force_f32<%d, %s, %s, %s, %s, %d>", plan.targets_per_lane / 2, acc64 ? "true" : "false",
+             accel_only ? "true" : "false", plan.j_split > 1 ? "true" : "false", plan.sgpr_sources ? "true" : "false",
+             plan.wg_size);
     return s;
 }
 
-// Register blocking and j-split for n_tgt targets against n_src sources on a chip with n_cus CUs
-// (measured: profiles/r01_force_variants.txt, bench.py --targets-per-lane/--j-split):
-//  * R = 8 targets per lane (4 packed pairs, ~150 VGPRs, 2 workgroups per CU) is fastest once the packed pipe
-//    has two waves per SIMD to alternate; R = 4 (4 waves/SIMD) is 1-2 % behind; tiny systems use R = 2;
-//  * the grid must give every SIMD its two waves: >= 2 workgroups per CU for R = 8 (>= 4 for R <= 4, which
-//    need the extra waves to cover their more frequent scalar-load / LDS waits); if the targets alone give
-//    fewer (multi-GPU shards), the source range is split over blockIdx.y and a reducer combines the partials.
-F32Plan plan_f32(long n_tgt, long n_src, int n_cus, int force_tpl, int force_js, bool have_workspace, int source_path) {
+// Workgroup shape, register blocking and j-split for n_tgt targets against n_src sources on n_cus CUs
+// (measured: profiles/r01_force_variants*.txt, bench.py --targets-per-lane/--j-split/--wg-size):
+//  * SGPR path, plenty of targets: ONE 1024-thread workgroup per CU (16 waves = 4 per SIMD), R = 4 targets per
+//    lane (2 packed pairs, <= 128 VGPRs) — fastest variant measured and half the L2/fabric traffic of two
+//    independent workgroups per CU; 512 threads x R = 8 ties;
+//  * fewer targets (multi-GPU shards): first split the source range over blockIdx.y (partials + reducer) so that
+//    every CU still gets a workgroup, then fall back to 256-thread workgroups, then to R = 2;
+//  * LDS path: 256 threads (one source per thread per tile), R = 4, >= 4 workgroups per CU.
+F32Plan plan_f32(long n_tgt, long n_src, int n_cus, int force_tpl, int force_js, bool have_workspace, int source_path,
+                 int force_wg) {
     F32Plan p;
     p.sgpr_sources = source_path != 1;
-    int R = force_tpl;
-    if (R != 2 && R != 4 && R != 8) {
-        R = 8;
-        if (n_tgt < (long)WG * 8 * 8) R = 4;
-        if (n_tgt < (long)WG * 4) R = 2;
-    }
-    p.targets_per_lane = R;
-    const long bx = (n_tgt + (long)WG * R - 1) / ((long)WG * R);
     const long ntiles = (n_src + TILE - 1) / TILE;
+    const int max_js = have_workspace ? MAX_JSPLIT : 1;
+    int wg = force_wg, R = force_tpl;
+    if (!p.sgpr_sources) wg = 256;
+    if (wg != 256 && wg != 512 && wg != 1024) wg = 0;
+    if (R != 2 && R != 4 && R != 8) R = 0;
+    const bool big_ok = p.sgpr_sources && n_tgt * max_js >= 4096L * n_cus;  // a 4096-target workgroup for every CU
+    if (wg == 0 && R == 0) {
+        if (big_ok) { wg = 1024; R = 4; }
+        else { wg = 256; R = n_tgt < 1024 ? 2 : 4; }
+    } else if (wg == 0) {
+        wg = (big_ok && R == 4) ? 1024 : (big_ok && R == 8) ? 512 : 256;
+    } else if (R == 0) {
+        R = wg == 1024 ? 4 : wg == 512 ? 8 : (n_tgt < 1024 ? 2 : 4);
+    }
+    if ((wg == 1024 && R != 4) || (wg == 512 && R != 8)) wg = 256;  // beyond 256 threads only (1024,4) and (512,8) exist
+    p.wg_size = wg;
+    p.targets_per_lane = R;
+    const long bx = (n_tgt + (long)wg * R - 1) / ((long)wg * R);
     int js = force_js;
     if (js <= 0) {
         js = 1;
-        const long want = (R == 8 ? 2L : 4L) * n_cus;
+        // workgroups wanted per CU: 1 x 1024 or 1 x 512 threads (that is all their registers admit), 4 x 256 (2 x 256 for R = 8)
+        const long want = (wg >= 512 ? 1L : (R == 8 ? 2L : 4L)) * n_cus;
         while (bx * js < want && js < MAX_JSPLIT && (long)js * 2 * 8 <= ntiles) js <<= 1;  // keep >= 8 tiles per slice
     }
     if (js > MAX_JSPLIT) js = MAX_JSPLIT;

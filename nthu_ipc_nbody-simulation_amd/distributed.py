@@ -31,7 +31,7 @@ def shard_range(n, rank, world):
     return rank * per, (rank + 1) * per
 
 
-def hip_compute(acc64=False, targets_per_lane=0, j_split=0, source_path=0):
+def hip_compute(acc64=False, targets_per_lane=0, j_split=0, source_path=0, wg_size=0):
     """The product compute step: nb_launch_step_f32 on torch's current HIP stream.  The j-split workspace
     (partial sums when a shard's targets alone cannot fill the chip) is a torch tensor allocated once."""
     ws = {}
@@ -49,6 +49,7 @@ def hip_compute(acc64=False, targets_per_lane=0, j_split=0, source_path=0):
                         pos64_ptr=pos64.data_ptr() if pos64 is not None else 0,
                         vel64_ptr=vel64.data_ptr() if vel64 is not None else 0,
                         acc64=acc64, targets_per_lane=targets_per_lane, j_split=j_split, source_path=source_path,
+                        wg_size=wg_size,
                         workspace_ptr=w.data_ptr(), workspace_bytes=w.numel())
 
     return compute

@@ -64,13 +64,34 @@ def test_raw_launch_all_register_blockings_and_splits(nb, oracle, tpl, js, acc64
                        source_path=path, accel_only=True)
     torch.cuda.synchronize()
     if tpl == 0:
-        r, j = nb.capi.plan_f32(n, cnt, acc64, workspace_bytes=ws.numel())
-        assert r in (2, 4, 8) and 1 <= j <= 16
+        r, j, w = nb.capi.plan_f32(n, cnt, acc64, workspace_bytes=ws.numel())
+        assert r in (2, 4, 8) and 1 <= j <= 16 and w in (256, 512, 1024)
     a = acc.cpu().numpy()[:, :3].T.astype(np.float64)
     q32 = pos[:, :3].T.astype(np.float64).copy()
     gm = pos[:, 3].astype(np.float64) / syn.G
     ref, s = oracle.accel_rows(q32, gm, syn.G, syn.EPS, off, off + cnt, want_abs=True)
     assert (np.abs(a - ref).max(axis=0) / s).max() < (TOL_ACC64 if acc64 else TOL_F32)
+
+
+@pytest.mark.parametrize("wg,tpl,js", [(1024, 4, 1), (1024, 4, 4), (512, 8, 1), (512, 8, 2)])
+def test_large_workgroup_variants(nb, oracle, wg, tpl, js):
+    """SGPR path with one big workgroup per CU (1024 x R=4, 512 x R=8), with and without a source split; ragged n."""
+    import torch
+    syn = nb.synthetic
+    n = 3 * 4096 + 1234
+    pos, _ = syn.body4_f32(n)
+    src = torch.from_numpy(pos).cuda()
+    acc = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+    ws = torch.empty(nb.capi.workspace_bytes_f32(n), dtype=torch.uint8, device="cuda")
+    nb.capi.launch_f32(src.data_ptr(), 0, n, 0, n, syn.EPS ** 2, syn.DT, torch.cuda.current_stream().cuda_stream,
+                       acc_ptr=acc.data_ptr(), targets_per_lane=tpl, j_split=js, wg_size=wg, source_path=2,
+                       workspace_ptr=ws.data_ptr(), workspace_bytes=ws.numel(), accel_only=True)
+    torch.cuda.synchronize()
+    assert nb.capi.plan_f32(n, n, targets_per_lane=tpl, j_split=js, wg_size=wg, workspace_bytes=ws.numel()) == (tpl, js, wg)
+    a = acc.cpu().numpy()[:, :3].T.astype(np.float64)
+    q32 = pos[:, :3].T.astype(np.float64).copy()
+    ref, s = oracle.accel_rows(q32, pos[:, 3].astype(np.float64) / syn.G, syn.G, syn.EPS, want_abs=True)
+    assert (np.abs(a - ref).max(axis=0) / s).max() < TOL_F32
 
 
 def test_split_step_equals_unsplit_step(nb):
