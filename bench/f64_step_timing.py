@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 import nbody_amd  # noqa: E402
 from nbody_amd import capi, host, synthetic  # noqa: E402
 
-for case in ("b20", "b100", "b200", "b512", "b1024"):
+for case in ("b20", "b50", "b100", "b200", "b512", "b1024"):
     n, planet, asteroid, qx, qy, qz, vx, vy, vz, m, types = host.read_input(
         os.path.join(ROOT, "tests/golden/testcases", f"{case}.in"))
     dev = np.array([t == "device" for t in types], dtype=np.uint8)
@@ -20,10 +20,16 @@ for case in ("b20", "b100", "b200", "b512", "b1024"):
         ctx.step(1, 200)
         ms = ctx.step_timed(201, 5000)
         t0 = time.perf_counter()
-        r = ctx.run_scenario(capi.NB_SCN_MIN_DIST, planet, asteroid, first_step=0, last_step=20000)
+        r = ctx.run_scenario(capi.NB_SCN_MIN_DIST, planet, asteroid, first_step=0, last_step=20000, engine=1)
         wall = time.perf_counter() - t0
+        k3 = ""
+        if n <= 128:
+            ctx.run_scenario(capi.NB_SCN_MIN_DIST, planet, asteroid, first_step=0, last_step=1000, engine=2)
+            t0 = time.perf_counter()
+            ctx.run_scenario(capi.NB_SCN_MIN_DIST, planet, asteroid, first_step=0, last_step=100000, engine=2)
+            k3 = f"; K3 persistent engine {(time.perf_counter() - t0) / 100000 * 1e6:.3f} us/step wall"
     print(f"{case}: n={n} K2 {ms * 1e3:.2f} us/step (5000 back-to-back launches, HIP events); "
-          f"scenario engine {wall / 20000 * 1e6:.2f} us/step wall")
+          f"per-step-launch engine {wall / 20000 * 1e6:.2f} us/step wall{k3}")
 
 n = 1 << 20
 q, v, m = synthetic.bodies(n)

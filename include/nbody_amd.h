@@ -76,6 +76,8 @@ typedef struct nb_scenario {
     int32_t n_watch;               /* devices watched for missile arrival (FIRST_HIT: all; MISSILE: 1) */
     int32_t watch[NB_MAX_WATCH];   /* their body indices */
     int32_t sync_every;            /* host polls the hit flag every this many steps (hw5.cu:72: 2000); <=0 -> 2000 */
+    int32_t engine;                /* 0 = auto; 1 = one launch per step (any n); 2 = whole step loop inside one
+                                      persistent single-workgroup launch (n <= 128) */
     double planet_radius;          /* 1e7   nbody.cc:17 */
     double missile_speed;          /* 1e6   nbody.cc:18 */
 } nb_scenario;

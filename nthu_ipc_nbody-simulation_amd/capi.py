@@ -23,7 +23,8 @@ class NbConfig(C.Structure):
 class NbScenario(C.Structure):
     _fields_ = [("kind", C.c_int32), ("first_step", C.c_int32), ("last_step", C.c_int32), ("planet", C.c_int32),
                 ("asteroid", C.c_int32), ("n_watch", C.c_int32), ("watch", C.c_int32 * NB_MAX_WATCH),
-                ("sync_every", C.c_int32), ("planet_radius", C.c_double), ("missile_speed", C.c_double)]
+                ("sync_every", C.c_int32), ("engine", C.c_int32), ("planet_radius", C.c_double),
+                ("missile_speed", C.c_double)]
 
 
 class NbScenarioResult(C.Structure):
@@ -203,13 +204,14 @@ class Context:
         return a
 
     def run_scenario(self, kind, planet, asteroid, first_step=0, last_step=200000, watch=(), sync_every=2000,
-                     planet_radius=1e7, missile_speed=1e6):
+                     planet_radius=1e7, missile_speed=1e6, engine=0):
         s = NbScenario()
         s.kind, s.first_step, s.last_step, s.planet, s.asteroid = kind, first_step, last_step, planet, asteroid
         s.n_watch = len(watch)
         for k, w in enumerate(watch):
             s.watch[k] = w
         s.sync_every, s.planet_radius, s.missile_speed = sync_every, planet_radius, missile_speed
+        s.engine = engine
         r = NbScenarioResult()
         _check(lib().nb_run_scenario(self._h, C.byref(s), C.byref(r)), "nb_run_scenario", self._h)
         return dict(min_dist2=r.min_dist2, hit_step=r.hit_step, steps_done=r.steps_done,

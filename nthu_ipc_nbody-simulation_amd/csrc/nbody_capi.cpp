@@ -44,6 +44,10 @@ struct nb_context {
     double* snap_v = nullptr;
     int snap_slots = 0;
     int split = 1;
+    double* fst_dev = nullptr;  // K3: |sin(step*dt/6000)| table, steps 0 .. fst_len-1
+    int fst_len = 0;
+    int* done_dev = nullptr;
+    int* done_host = nullptr;  // pinned
     std::vector<double> m_host;
     std::vector<uint8_t> dev_host;
 
@@ -86,7 +90,8 @@ void free_dev(T*& p) {
 
 void release(nb_context* c) {
     free_dev(c->q[0]); free_dev(c->q[1]); free_dev(c->v); free_dev(c->m); free_dev(c->coef); free_dev(c->acc);
-    free_dev(c->mon); free_dev(c->snap_q); free_dev(c->snap_v);
+    free_dev(c->mon); free_dev(c->snap_q); free_dev(c->snap_v); free_dev(c->fst_dev); free_dev(c->done_dev);
+    if (c->done_host) (void)hipHostFree(c->done_host);
     free_dev(c->pos[0]); free_dev(c->pos[1]); free_dev(c->vel); free_dev(c->pos64); free_dev(c->vel64);
     free_dev(c->acc32);
     free_dev(c->partial);
@@ -442,6 +447,65 @@ int nb_run_scenario(nb_context* c, const nb_scenario* s, nb_scenario_result* res
     for (int k = 0; k < MAX_WATCH; ++k) mh->arrival_step[k] = -2;
     NB_HIP(c, hipMemcpyAsync(c->mon, mh, sizeof(F64Monitor), hipMemcpyHostToDevice, c->stream));
     NB_HIP(c, hipStreamSynchronize(c->stream));
+
+    if (s->engine < 0 || s->engine > 2) return NB_ERR_INVALID;
+    if (s->engine == 2 && c->n > SMALL_N_MAX) return NB_ERR_INVALID;
+    const bool small_engine = (s->engine == 2) || (s->engine == 0 && c->n <= SMALL_N_MAX);
+    if (small_engine) {
+        // K3: the whole step loop inside one single-workgroup kernel, in chunks so the host can stop after a hit
+        const int need = s->last_step + 2;
+        if (c->fst_len < need) {
+            free_dev(c->fst_dev);
+            std::vector<double> tab((size_t)need);
+            for (int k = 0; k < need; ++k) tab[(size_t)k] = fst_of(k, c->cfg.dt);
+            NB_HIP(c, hipMalloc(&c->fst_dev, (size_t)need * sizeof(double)));
+            NB_HIP(c, hipMemcpy(c->fst_dev, tab.data(), (size_t)need * sizeof(double), hipMemcpyHostToDevice));
+            c->fst_len = need;
+        }
+        if (!c->done_dev) {
+            NB_HIP(c, hipMalloc(&c->done_dev, sizeof(int)));
+            NB_HIP(c, hipHostMalloc(&c->done_host, sizeof(int)));
+        }
+        const int chunk = 50000;
+        int at = s->first_step;
+        bool first = true;
+        while (first || at < s->last_step) {
+            first = false;
+            F64SmallArgs k{};
+            k.q = c->q[c->cur];
+            k.v = c->v;
+            k.m = c->m;
+            k.coef = c->coef;
+            k.fst = c->fst_dev;
+            k.snap_q = want_snap ? c->snap_q : nullptr;
+            k.snap_v = want_snap ? c->snap_v : nullptr;
+            k.mon = c->mon;
+            k.steps_done = c->done_dev;
+            k.n = c->n;
+            k.first_step = at;
+            k.last_step = std::min(s->last_step, at + chunk);
+            k.final_monitor = (k.last_step == s->last_step);
+            k.G = c->cfg.G;
+            k.eps2 = c->cfg.eps * c->cfg.eps;
+            k.dt = c->cfg.dt;
+            k.scn = sc;
+            NB_HIP(c, (hipError_t)launch_f64_small(k, c->stream));
+            NB_HIP(c, hipMemcpyAsync(mh, c->mon, sizeof(F64Monitor), hipMemcpyDeviceToHost, c->stream));
+            NB_HIP(c, hipMemcpyAsync(c->done_host, c->done_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            NB_HIP(c, hipStreamSynchronize(c->stream));
+            at = *c->done_host;
+            if (mh->hit_step != -2 || at < k.last_step) break;
+        }
+        memset(res, 0, sizeof *res);
+        res->min_dist2 = mh->min_d2;
+        res->hit_step = mh->hit_step;
+        res->steps_done = at;
+        for (int k = 0; k < NB_MAX_WATCH; ++k) {
+            res->arrival_step[k] = (k < sc.n_watch) ? mh->arrival_step[k] : -2;
+            res->missile_cost[k] = (res->arrival_step[k] != -2) ? 1e5 + 1e3 * ((res->arrival_step[k] + 1) * c->cfg.dt) : 0.0;
+        }
+        return NB_OK;
+    }
 
     const int sync_every = s->sync_every > 0 ? s->sync_every : 2000;  // hw5.cu:72
     const bool can_stop = s->kind != NB_SCN_MIN_DIST;

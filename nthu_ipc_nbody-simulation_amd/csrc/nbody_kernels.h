@@ -74,4 +74,25 @@ struct F64Args {
 int launch_f64(const F64Args& a, int S, hipStream_t stream);  // S = lanes sharing one target (1..64, pow2)
 int auto_split_f64(int n, int n_cus);
 
+// K3: whole scenario of a small system (n <= SMALL_N_MAX) in ONE persistent single-workgroup launch
+constexpr int SMALL_N_MAX = 128;
+struct F64SmallArgs {
+    double* q;           // [3][n] in/out: state `first_step` in, last computed state out
+    double* v;           // [3][n] in/out
+    const double* m;     // [n]
+    const double* coef;  // [n]
+    const double* fst;   // [>= last_step + 2] |sin(step*dt/6000)| by step index, host-computed (glibc)
+    double* snap_q;      // [n_watch][3][n] or nullptr
+    double* snap_v;
+    F64Monitor* mon;     // in/out (carries min_d2 / hit / arrivals across launches)
+    int* steps_done;     // out: index of the last state computed
+    int n;
+    int first_step;      // index of the state in q,v
+    int last_step;       // inclusive
+    int final_monitor;   // evaluate the monitor on state last_step too (last launch of a scenario)
+    double G, eps2, dt;
+    F64Scenario scn;
+};
+int launch_f64_small(const F64SmallArgs& a, hipStream_t stream);
+
 }  // namespace nbk

@@ -12,8 +12,10 @@
 //
 // Mapping: n is tiny, so the j-range of each target is split across S lanes of one wave (S = 1..64) and the S
 // partial accelerations are combined with wave-level __shfl_xor reductions; S is chosen so that n*S threads
-// fill the chip.  Sources are staged through LDS as SoA planes (x,y,z,G*m_eff) in tiles of 256: lanes of a
-// wave then read S consecutive doubles per plane (each broadcast to 64/S lanes) — conflict-free ds_read_b64.
+// fill the chip.  Sources are staged through LDS as SoA planes (x,y,z,G*m_eff), 1024 per pass (4 per thread, all
+// loads of a pass in flight together and issued ahead of the monitor): lanes of a wave then read S consecutive
+// doubles per plane (each broadcast to 64/S lanes) — conflict-free ds_read_b64.  The launch is latency-bound
+// (n <= 1024 -> one pass, one barrier), so the structure minimises dependent memory round trips, not flops.
 // Owner-computes, no atomics: results are bitwise reproducible run to run (the reference's are not).
 //
 // Positions ping-pong (qin -> qout) because other workgroups still read the old positions while this one
@@ -29,6 +31,28 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
     return __hiloint2double(hi, lo);
 }
 
+// 1/sqrt(x) to fp64 rounding from the hardware seed: v_rsq_f64 (relative error e0 ~ 2^-26) followed by ONE third-order
+// (Halley) correction y <- y*(1 + e/2 + 3e^2/8), e = 1 - x*y*y, whose remaining error ~ (5/16)*e0^3 is far below 2^-53.
+// 6 fp64 VALU ops + the 16-cycle transcendental instead of the ~25-instruction IEEE sqrt + divide expansion the
+// compiler emits for 1.0/sqrt(x) — the pair loop is ~40 % shorter.  (the testcase outputs do not
+// move a digit for relative force errors up to 1e-7; this is at 1e-16.)
+__device__ __forceinline__ double rsqrt_fast(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double e = __builtin_fma(-x * y, y, 1.0);
+    double t = __builtin_fma(0.375, e, 0.5);
+    return __builtin_fma(y * e, t, y);
+}
+
+// lane l receives the value of lane l+K of its 16-lane row (0 past the row end): v_mov_b32 with a DPP row_shl modifier —
+// a plain VALU move, no LDS crossbar round trip like ds_bpermute (__shfl_*).
+template <int K>
+__device__ __forceinline__ double row_shl_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x100 + K, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x100 + K, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double dist2_bodies(const double* q, int n, int i, int j) {
     double dx = q[i] - q[j];
     double dy = q[n + i] - q[n + j];
@@ -36,9 +60,11 @@ __device__ __forceinline__ double dist2_bodies(const double* q, int n, int i, in
     return dx * dx + dy * dy + dz * dz;  // same association as nbody.cc:134 / hw5.cu:258
 }
 
+constexpr int K2_TILE = 1024;  // sources staged per pass: 4 per thread, 32 KB of LDS; n <= 1024 needs ONE pass
+
 template <int S>
 __global__ __launch_bounds__(WG) void nbody_step_f64(F64Args a) {
-    __shared__ double sx[TILE], sy[TILE], sz[TILE], sg[TILE];
+    __shared__ double sx[K2_TILE], sy[K2_TILE], sz[K2_TILE], sg[K2_TILE];
     __shared__ int sh_skip;
     __shared__ unsigned sh_destroyed;  // bit k: watched device k has mass 0 for this step
     __shared__ unsigned sh_snap;       // bit k: snapshot state step-1 for watched device k now
@@ -46,6 +72,24 @@ __global__ __launch_bounds__(WG) void nbody_step_f64(F64Args a) {
     const int t = threadIdx.x;
     const int n = a.n;
     const F64Scenario& sc = a.scn;
+    constexpr int PER = K2_TILE / WG;                    // sources each thread stages per full pass
+    const int per_n = n >= K2_TILE ? PER : (n + WG - 1) / WG;  // ... and for a small system (workgroup-uniform)
+
+    // ---- first pass's source loads are issued BEFORE the monitor so that their latency and thread 0's dependent
+    //      monitor chain (flag -> positions -> compare) overlap instead of adding up
+    double lx[PER], ly[PER], lz[PER], lm[PER], lc[PER];
+    auto issue_loads = [&](int base) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            if (u < per_n) {
+                const int j = base + u * WG + t;
+                const int jc = j < n ? j : n - 1;
+                lx[u] = a.qin[jc]; ly[u] = a.qin[n + jc]; lz[u] = a.qin[2 * n + jc];
+                lm[u] = a.m[jc]; lc[u] = a.coef[jc];
+            }
+        }
+    };
+    issue_loads(0);
 
     // ---- monitor on the state after step-1 (index step-1), evaluated identically by every workgroup;
     //      only workgroup 0 records it.  A value another workgroup of THIS launch may already have written
@@ -90,14 +134,32 @@ __global__ __launch_bounds__(WG) void nbody_step_f64(F64Args a) {
         sh_destroyed = destroyed;
         sh_snap = snap;
     }
-    __syncthreads();
-    const unsigned snap = sh_snap, destroyed = sh_destroyed;
-    const bool skip = sh_skip != 0;
 
     constexpr int TPB = WG / S;  // targets per workgroup
     const int ls = t % S;        // this lane's slice of the source range
     const int i = blockIdx.x * TPB + t / S;
     const bool owner = (ls == 0) && (i < n);
+    const int ic = i < n ? i : n - 1;
+    const double xi = a.qin[ic], yi = a.qin[n + ic], zi = a.qin[2 * n + ic];
+    double ax = 0, ay = 0, az = 0;
+
+    // stage a pass into LDS: G*m_eff with the device-mass law m0 + 0.5*m0*|sin(t/6000)| (nbody.cc:14-16,61-64), rounded
+    // exactly like the CPU reference (no FMA contraction): coef = 0.5 for devices, 0 otherwise -> m + 0 = m.
+    auto stage = [&](int base) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            if (u < per_n) {
+                const int jl = u * WG + t;
+                const double mj = __dadd_rn(lm[u], __dmul_rn(__dmul_rn(lc[u], lm[u]), a.fst));
+                sx[jl] = lx[u]; sy[jl] = ly[u]; sz[jl] = lz[u];
+                sg[jl] = (base + jl < n) ? __dmul_rn(a.G, mj) : 0.0;  // G*mj, the reference's first product (nbody.cc:70)
+            }
+        }
+    };
+    stage(0);
+    __syncthreads();  // monitor decisions + first pass visible
+    const unsigned snap = sh_snap, destroyed = sh_destroyed;
+    const bool skip = sh_skip != 0;
 
     // snapshot of (q,v) at missile arrival, taken from the not-yet-updated state (hw5.cu:277-285)
     if (snap && owner && a.snap_q) {
@@ -111,50 +173,45 @@ __global__ __launch_bounds__(WG) void nbody_step_f64(F64Args a) {
                 }
             }
     }
-    if (skip) return;
+    if (skip) return;  // workgroup-uniform
 
-    const int ic = i < n ? i : n - 1;
-    const double xi = a.qin[ic], yi = a.qin[n + ic], zi = a.qin[2 * n + ic];
-    double ax = 0, ay = 0, az = 0;
+    // a destroyed device (MISSILE scenario, one watched device) has mass 0 from the step after its arrival (hw5.cu:306)
+    int dead_j = -1;
+    for (int k = 0; k < sc.n_watch; ++k)
+        if (destroyed & (1u << k)) dead_j = sc.watch[k];
 
-    for (int base = 0; base < n; base += TILE) {
-        const int j = base + t;
-        double x = 0, y = 0, z = 0, g = 0;
-        if (j < n) {
-            x = a.qin[j]; y = a.qin[n + j]; z = a.qin[2 * n + j];
-            double mj = a.m[j];
-            // device-mass law m0 + 0.5*m0*|sin(t/6000)| (nbody.cc:14-16,61-64), rounded exactly like the CPU
-            // reference (no FMA contraction): coef = 0.5 for devices, 0 otherwise -> m + 0 = m.
-            mj = __dadd_rn(mj, __dmul_rn(__dmul_rn(a.coef[j], mj), a.fst));
-            for (int k = 0; k < sc.n_watch; ++k)
-                if ((destroyed & (1u << k)) && sc.watch[k] == j) mj = 0.0;
-            g = __dmul_rn(a.G, mj);  // G*mj, the reference's first product (nbody.cc:70)
+    for (int base = 0; base < n; base += K2_TILE) {
+        if (base) {  // further passes (n > 1024)
+            issue_loads(base);
+            __syncthreads();  // previous pass fully consumed
+            stage(base);
+            __syncthreads();
         }
-        if (base) __syncthreads();  // previous tile fully consumed
-        sx[t] = x; sy[t] = y; sz[t] = z; sg[t] = g;
-        __syncthreads();
-        const int lim = min(TILE, n - base);
-#pragma unroll 4
+        const int lim = min(K2_TILE, n - base);
+#pragma unroll 2
         for (int jj = ls; jj < lim; jj += S) {
             double dx = sx[jj] - xi;
             double dy = sy[jj] - yi;
             double dz = sz[jj] - zi;
             double r2 = dx * dx + dy * dy + dz * dz + a.eps2;
-            double rinv = rsqrt(r2);
+            double rinv = rsqrt_fast(r2);
             double s = sg[jj] * rinv * rinv * rinv;  // G*mj/(r2+eps2)^1.5
-            s = (base + jj == i) ? 0.0 : s;          // j == i skipped (nbody.cc:59); also keeps eps == 0 finite
+            const int j = base + jj;
+            s = (j == i || j == dead_j) ? 0.0 : s;  // j == i skipped (nbody.cc:59), also keeps eps == 0 finite
             ax += s * dx;
             ay += s * dy;
             az += s * dz;
         }
     }
 
-#pragma unroll
-    for (int off = S >> 1; off >= 1; off >>= 1) {  // the S lanes of a target are adjacent lanes of one wave
-        ax += shfl_xor_f64(ax, off);
-        ay += shfl_xor_f64(ay, off);
-        az += shfl_xor_f64(az, off);
-    }
+    // wave-level reduction of the S partial accelerations of a target (adjacent lanes of one wave) into lane ls == 0:
+    // across 16-lane rows with __shfl_xor (ds_bpermute), inside a row with DPP row_shl moves (plain VALU)
+    if (S >= 64) { ax += shfl_xor_f64(ax, 32); ay += shfl_xor_f64(ay, 32); az += shfl_xor_f64(az, 32); }
+    if (S >= 32) { ax += shfl_xor_f64(ax, 16); ay += shfl_xor_f64(ay, 16); az += shfl_xor_f64(az, 16); }
+    if (S >= 16) { ax += row_shl_f64<8>(ax); ay += row_shl_f64<8>(ay); az += row_shl_f64<8>(az); }
+    if (S >= 8) { ax += row_shl_f64<4>(ax); ay += row_shl_f64<4>(ay); az += row_shl_f64<4>(az); }
+    if (S >= 4) { ax += row_shl_f64<2>(ax); ay += row_shl_f64<2>(ay); az += row_shl_f64<2>(az); }
+    if (S >= 2) { ax += row_shl_f64<1>(ax); ay += row_shl_f64<1>(ay); az += row_shl_f64<1>(az); }
 
     if (owner) {
         if (a.acc_out) {
@@ -170,6 +227,158 @@ __global__ __launch_bounds__(WG) void nbody_step_f64(F64Args a) {
             a.qout[2 * n + i] = __dadd_rn(zi, __dmul_rn(vz, a.dt));
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K3 nbody_scenario_small_f64<S>: a whole scenario of a small system (n <= 128: testcases b20..b100) in ONE launch of
+// ONE workgroup.  The reference — and K2 above — pay a kernel launch (plus monitor launches) per step: 200 000 steps x
+// ~4 us is pure launch latency for systems whose 400..10 000 pairs take well under a microsecond to evaluate.
+// Here the state lives in LDS (positions and G*m_eff ping-pong, 8 KB), velocities in the owner lanes' registers, the
+// step loop runs inside the kernel with ONE s_barrier per step, and every thread evaluates the O(1) monitors redundantly
+// from LDS (identical inputs -> identical, hence workgroup-uniform, decisions): no flags, no inter-workgroup protocol,
+// no grid barrier, every wave reaches the loop exit.  Same arithmetic as K2 (same G*m_eff rounding, same pair term,
+// same non-contracted kick/drift); only the summation split S differs.
+template <int S>
+__global__ __launch_bounds__(SMALL_N_MAX * S) void nbody_scenario_small_f64(F64SmallArgs a) {
+    __shared__ double sq[2][3][SMALL_N_MAX];
+    __shared__ double sg[2][SMALL_N_MAX];
+    const int t = threadIdx.x;
+    const int n = a.n;
+    const F64Scenario& sc = a.scn;
+    const int ls = t % S;
+    const int i = t / S;
+    const bool owner = (ls == 0) && (i < n);
+    const int ic = i < n ? i : n - 1;
+
+    // owner state: velocity, mass law inputs
+    double vx = 0, vy = 0, vz = 0, mi = 0, cmi = 0;
+    if (owner) {
+        vx = a.v[i]; vy = a.v[n + i]; vz = a.v[2 * n + i];
+        mi = a.m[i];
+        cmi = __dmul_rn(a.coef[i], mi);  // (0.5*m0) for devices, 0 otherwise
+        sq[0][0][i] = a.q[i]; sq[0][1][i] = a.q[n + i]; sq[0][2][i] = a.q[2 * n + i];
+        // G*m_eff for the first step to be taken
+        sg[0][i] = __dmul_rn(a.G, __dadd_rn(mi, __dmul_rn(cmi, a.fst[a.first_step + 1])));
+    }
+    // scenario state, replicated in every thread (all derive it from the same LDS words)
+    double min_d2 = a.mon->min_d2;
+    int hit = a.mon->hit_step;
+    int arr[MAX_WATCH];
+    int dead_j = -1;  // MISSILE: the destroyed device's index once its missile has arrived
+    unsigned alive = 0;  // bit k: watched device k has a non-zero base mass (hw5.cu:299), read once
+#pragma unroll
+    for (int k = 0; k < MAX_WATCH; ++k) {
+        arr[k] = a.mon->arrival_step[k];
+        if (k < sc.n_watch && a.m[sc.watch[k]] != 0.0) alive |= 1u << k;
+    }
+    if (sc.destroy_on_arrival && sc.n_watch > 0 && arr[0] != -2) dead_j = sc.watch[0];
+    __syncthreads();
+
+    auto d2_of = [&](int buf, int p, int r) {
+        double dx = sq[buf][0][p] - sq[buf][0][r];
+        double dy = sq[buf][1][p] - sq[buf][1][r];
+        double dz = sq[buf][2][p] - sq[buf][2][r];
+        return dx * dx + dy * dy + dz * dz;
+    };
+    // monitor on the state with index idx held in buffer buf; returns true when the scenario must stop
+    auto monitor = [&](int buf, int idx) -> bool {
+        if (sc.kind < 0) return false;
+        const double d2 = d2_of(buf, sc.planet, sc.asteroid);
+        if (sc.kind == 0) {  // MIN_DIST  nbody.cc:118-121
+            if (d2 < min_d2) min_d2 = d2;
+            return false;
+        }
+        if (d2 < sc.R2) {  // nbody.cc:134-137 ; hw5.cu:295-298
+            hit = idx;
+            return true;
+        }
+        for (int k = 0; k < sc.n_watch; ++k) {
+            const int d = sc.watch[k];
+            if (arr[k] == -2 && (alive & (1u << k))) {  // hw5.cu:299
+                const double md = sc.missile_dstep * idx;
+                if (d2_of(buf, sc.planet, d) < md * md) {
+                    arr[k] = idx;
+                    if (sc.destroy_on_arrival) dead_j = d;  // hw5.cu:306
+                    if (a.snap_q && owner) {                // hw5.cu:277-285
+                        double* dq = a.snap_q + (size_t)k * 3 * n;
+                        double* dv = a.snap_v + (size_t)k * 3 * n;
+                        dq[i] = sq[buf][0][i]; dq[n + i] = sq[buf][1][i]; dq[2 * n + i] = sq[buf][2][i];
+                        dv[i] = vx; dv[n + i] = vy; dv[2 * n + i] = vz;
+                    }
+                }
+            }
+        }
+        return false;
+    };
+
+    int cur = 0;
+    int step = a.first_step + 1;
+    bool stopped = false;
+    for (; step <= a.last_step; ++step) {
+        if (monitor(cur, step - 1)) { stopped = true; break; }
+        const double fst_next = owner ? a.fst[step + 1] : 0.0;  // in flight during the pair loop
+        const double xi = sq[cur][0][ic], yi = sq[cur][1][ic], zi = sq[cur][2][ic];
+        double ax = 0, ay = 0, az = 0;
+#pragma unroll 2
+        for (int jj = ls; jj < n; jj += S) {
+            double dx = sq[cur][0][jj] - xi;
+            double dy = sq[cur][1][jj] - yi;
+            double dz = sq[cur][2][jj] - zi;
+            double r2 = dx * dx + dy * dy + dz * dz + a.eps2;
+            double rinv = rsqrt_fast(r2);
+            double s = sg[cur][jj] * rinv * rinv * rinv;
+            s = (jj == i || jj == dead_j) ? 0.0 : s;  // j == i skipped (nbody.cc:59); destroyed device has m = 0
+            ax += s * dx;
+            ay += s * dy;
+            az += s * dz;
+        }
+        // the S = 8 lanes of a target are adjacent lanes of one 16-lane row and only lane ls == 0 needs the total:
+        // three DPP row_shl folds (4, 2, 1)
+        static_assert(S == 8, "reduction below is written for 8 lanes per target");
+        ax += row_shl_f64<4>(ax); ay += row_shl_f64<4>(ay); az += row_shl_f64<4>(az);
+        ax += row_shl_f64<2>(ax); ay += row_shl_f64<2>(ay); az += row_shl_f64<2>(az);
+        ax += row_shl_f64<1>(ax); ay += row_shl_f64<1>(ay); az += row_shl_f64<1>(az);
+        if (owner) {  // kick, drift (nbody.cc:76-88), then G*m_eff of the NEXT step into the other buffer
+            vx = __dadd_rn(vx, __dmul_rn(ax, a.dt));
+            vy = __dadd_rn(vy, __dmul_rn(ay, a.dt));
+            vz = __dadd_rn(vz, __dmul_rn(az, a.dt));
+            sq[cur ^ 1][0][i] = __dadd_rn(xi, __dmul_rn(vx, a.dt));
+            sq[cur ^ 1][1][i] = __dadd_rn(yi, __dmul_rn(vy, a.dt));
+            sq[cur ^ 1][2][i] = __dadd_rn(zi, __dmul_rn(vz, a.dt));
+            sg[cur ^ 1][i] = __dmul_rn(a.G, __dadd_rn(mi, __dmul_rn(cmi, fst_next)));
+        }
+        __syncthreads();  // the only barrier of the step: buffer cur^1 complete, buffer cur free for step+1's writes
+        cur ^= 1;
+    }
+    int done = stopped ? step - 1 : a.last_step;
+    if (!stopped && a.final_monitor) (void)monitor(cur, a.last_step);
+
+    if (owner) {
+        a.q[i] = sq[cur][0][i]; a.q[n + i] = sq[cur][1][i]; a.q[2 * n + i] = sq[cur][2][i];
+        a.v[i] = vx; a.v[n + i] = vy; a.v[2 * n + i] = vz;
+    }
+    if (t == 0) {
+        a.mon->min_d2 = min_d2;
+        a.mon->hit_step = hit;
+        for (int k = 0; k < MAX_WATCH; ++k) a.mon->arrival_step[k] = arr[k];
+        *a.steps_done = done;
+    }
+}
+
+template <int S>
+static int launch_small_s(const F64SmallArgs& a, int threads, hipStream_t stream) {
+    hipLaunchKernelGGL((nbody_scenario_small_f64<S>), dim3(1), dim3(threads), 0, stream, a);
+    return (int)hipGetLastError();
+}
+
+// Geometry: S = 8 lanes per target (three shuffle rounds), NPAD = n rounded up to a multiple of 8 targets per wave,
+// threads = NPAD*S rounded up to whole waves: 256 threads for n <= 32 ... 1024 for n <= 128 — few waves keep the
+// per-step barrier and the dependent chain (LDS read -> pair -> 3 shuffles -> update -> LDS write) short.
+int launch_f64_small(const F64SmallArgs& a, hipStream_t stream) {
+    if (a.n <= 0 || a.n > SMALL_N_MAX) return (int)hipErrorInvalidValue;
+    constexpr int S = 8;
+    int threads = ((a.n * S + 63) / 64) * 64;
+    return launch_small_s<S>(a, threads, stream);
 }
 
 template <int S>
@@ -193,7 +402,9 @@ int launch_f64(const F64Args& a, int S, hipStream_t stream) {
     return (int)hipErrorInvalidValue;
 }
 
-// lanes per target so that n*S threads give about one 256-thread workgroup per CU
+// lanes per target so that n*S threads give about one 256-thread workgroup per TWO CUs.  The launch is latency-bound
+// and every workgroup stages the whole system, so more workgroups only add L2 traffic: measured at n = 1024,
+// S = 32 (128 workgroups) 5.9 us/step, S = 64 (256 workgroups) 6.2 us/step (profiles/r01_f64_step_timing.txt).
 int auto_split_f64(int n, int n_cus) {
     long want = (long)n_cus * WG;
     int S = 1;

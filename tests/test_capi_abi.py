@@ -27,7 +27,7 @@ def test_struct_layouts_match_header(nb):
     import ctypes as C
     c = nb.capi
     assert C.sizeof(c.NbConfig) == 40
-    assert C.sizeof(c.NbScenario) == 6 * 4 + 16 * 4 + 4 + 4 + 16  # ints, watch[], sync_every(+pad), 2 doubles
+    assert C.sizeof(c.NbScenario) == 6 * 4 + 16 * 4 + 4 + 4 + 16  # ints, watch[], sync_every, engine, 2 doubles
     assert C.sizeof(c.NbAnswer) == 24
     assert C.sizeof(c.NbLaunchF32) == 7 * 8 + 4 * 8 + 8 * 4
 

@@ -170,3 +170,49 @@ def test_checkpoint_resume_is_bitwise(nb, oracle, tmp_path):
     assert np.array_equal(q, q_ref) and np.array_equal(v, v_ref)
     with nb.capi.Context(s.n + 1) as ctx, pytest.raises(nb.capi.NBodyError):
         ctx.load_state(path)
+
+
+@pytest.mark.parametrize("case", ["b20", "b50", "b100"])
+def test_persistent_engine_equals_per_step_engine(nb, oracle, case):
+    """K3 (whole scenario in one single-workgroup launch) vs K2 (one launch per step): same monitors, same answers,
+    and the states after 3000 steps agree to rounding (only the summation split differs)."""
+    s = oracle.read_input(case_path(case, "in"))
+    devs = [int(i) for i in np.flatnonzero(s.is_device)]
+    res = {}
+    for eng in (1, 2):
+        with _ctx(nb, s) as ctx:
+            r = ctx.run_scenario(nb.capi.NB_SCN_FIRST_HIT, s.planet, s.asteroid, watch=devs, last_step=3000, engine=eng)
+            q, v = ctx.get_state()
+            assert r["steps_done"] == 3000 and r["hit_step"] == -2
+        with _ctx(nb, s) as ctx:
+            for d in devs:
+                ctx.set_mass(d, 0.0)
+            p1 = ctx.run_scenario(nb.capi.NB_SCN_MIN_DIST, s.planet, s.asteroid, last_step=3000, engine=eng)
+        res[eng] = (q, v, r, p1["min_dist2"])
+    assert _close(res[1][0], res[2][0], 1e-11) and _close(res[1][1], res[2][1], 1e-11)
+    assert res[1][2]["arrival_step"] == res[2][2]["arrival_step"]
+    assert abs(res[1][3] - res[2][3]) <= 1e-12 * res[1][3]
+    ref = s.copy()
+    oracle.run_steps(ref, 1, 3000)
+    assert _close(res[2][0], ref.q, RTOL_1000) and _close(res[2][1], ref.v, RTOL_1000)
+
+
+def test_persistent_engine_full_scenarios_b20(nb, oracle):
+    """K3 on the full 200 000-step P2 + P3 of b20: hit step, arrival steps, feasibility as the oracle."""
+    s = oracle.read_input(case_path("b20", "in"))
+    res, details = oracle.problem23(s)
+    devs = [d["device"] for d in details]
+    with _ctx(nb, s) as ctx:
+        r = ctx.run_scenario(nb.capi.NB_SCN_FIRST_HIT, s.planet, s.asteroid, watch=devs, engine=2)
+        assert r["hit_step"] == res.hit_time_step and r["arrival_step"] == [d["arrival_step"] for d in details]
+        for k, d in enumerate(details):
+            with nb.capi.Context(s.n) as c3:
+                c3.restore_snapshot_from(ctx, k)
+                r3 = c3.run_scenario(nb.capi.NB_SCN_MISSILE, s.planet, s.asteroid, first_step=d["arrival_step"],
+                                     watch=[d["device"]], engine=2)
+            assert (r3["hit_step"] == -2) == d["feasible"] and r3["hit_step"] == d["fail_step"]
+            assert r3["missile_cost"][0] == d["cost"]
+    with nb.capi.Context(200) as big, pytest.raises(nb.capi.NBodyError):
+        q = np.zeros((3, 200)); q[0] = np.arange(200)
+        big.set_state(q, q, np.ones(200))
+        big.run_scenario(nb.capi.NB_SCN_MIN_DIST, 0, 1, last_step=10, engine=2)  # n > 128: refused
