@@ -303,6 +303,14 @@ void orc_problem23(const orc_system* in, const orc_params* p, orc_result* out, o
             }
         }
     }
+    if (detail && hit == -2) /* no hit: nothing to prevent, but report what was observed */
+        for (int k = 0; k < ndev && k < max_detail; k++) {
+            detail[k].device = dev[k];
+            detail[k].arrival_step = arrival[k];
+            detail[k].feasible = 0;
+            detail[k].fail_step = -2;
+            detail[k].cost = arrival[k] != -2 ? orc_missile_cost((arrival[k] + 1) * p->dt) : INFINITY;
+        }
     if (detail)
         for (int k = ndev; k < max_detail; k++) detail[k].device = -1;
     for (int k = 0; k < ndev; k++) orc_system_free(&snap[k]);

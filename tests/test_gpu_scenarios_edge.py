@@ -1,0 +1,134 @@
+"""Edge cases of the scenario drivers (P1/P2/P3) on hand-made systems, GPU (nb_solve / hw5) vs the oracle:
+no hit, hit at step 0, hit with no devices, a device whose missile arrives but cannot prevent the hit, coincident
+bodies, massless bodies — and the ABI's error paths."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _system(oracle, bodies, planet=0, asteroid=1):
+    """bodies: list of (q, v, m, is_device)."""
+    s = oracle.System(len(bodies), planet, asteroid)
+    for i, (q, v, m, d) in enumerate(bodies):
+        s.q[:, i], s.v[:, i], s.m[i], s.is_device[i] = q, v, m, d
+    return s
+
+
+def _write_in(s, path):
+    with open(path, "w") as f:
+        f.write(f"{s.n} {s.planet} {s.asteroid}\n")
+        for i in range(s.n):
+            vals = list(s.q[:, i]) + list(s.v[:, i]) + [s.m[i]]
+            f.write(" ".join("%.16e" % x for x in vals) + (" device\n" if s.is_device[i] else " rock\n"))
+
+
+PLANET = ((0.0, 0.0, 0.0), (0.0, 0.0, 0.0), 6e24, 0)
+CASES = {
+    # asteroid on a collision course; a light device nearby: its missile arrives, the hit happens anyway
+    "collision_device_useless": [PLANET, ((3e8, 0, 0), (-3e3, 0, 0), 1e12, 0), ((1e8, 1e8, 0), (0, 0, 0), 1e15, 1)],
+    # asteroid leaving: never hits -> -2 / -1 0
+    "no_hit": [PLANET, ((3e8, 0, 0), (5e4, 0, 0), 1e12, 0), ((1e8, 1e8, 0), (0, 0, 0), 1e15, 1)],
+    # already inside the planet radius at step 0
+    "hit_at_step_0": [PLANET, ((5e6, 0, 0), (0, 0, 0), 1e12, 0), ((1e9, 1e9, 0), (0, 0, 0), 1e15, 1)],
+    # hit, but the input has no device at all
+    "hit_no_devices": [PLANET, ((3e8, 0, 0), (-3e3, 0, 0), 1e12, 0), ((0, 5e8, 0), (1e3, 0, 0), 1e20, 0)],
+    # two bodies at the same place (r = 0: only the softening keeps the pair finite) and a massless one
+    "coincident_and_massless": [PLANET, ((3e8, 0, 0), (-3e3, 0, 0), 1e12, 0), ((0, 7e8, 0), (0, 0, 0), 1e18, 0),
+                                ((0, 7e8, 0), (0, 0, 0), 1e18, 0), ((1e9, 0, 4e8), (0, 10, 0), 0.0, 0),
+                                ((2e8, -1e8, 0), (0, 0, 0), 1e16, 1)],
+    # a heavy device that pulls the asteroid into the planet: destroying it in time avoids the hit
+    "device_causes_hit": [PLANET, ((4e8, 6e7, 0), (-2e3, 0, 0), 1e12, 0), ((1e8, -2e8, 0), (0, 0, 0), 3e24, 1),
+                          ((-9e8, 9e8, 0), (0, 0, 0), 1e10, 1)],
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_solve_matches_oracle(nb, oracle, name, tmp_path):
+    s = _system(oracle, CASES[name])
+    ref_min = oracle.problem1(s)
+    ref, details = oracle.problem23(s)
+    got = nb.capi.solve(s.n, s.planet, s.asteroid, s.q, s.v, s.m, s.is_device)
+    assert got[1] == ref.hit_time_step and got[2] == ref.gravity_device_id, (name, got, details)
+    assert got[3] == ref.missile_cost
+    assert abs(got[0] - ref_min) <= 1e-9 * ref_min
+    # and through the CLI, against the oracle's CLI
+    inp, out, out_ref = tmp_path / "c.in", tmp_path / "c.out", tmp_path / "c.ref"
+    _write_in(s, inp)
+    subprocess.run([os.path.join(ROOT, "bin", "hw5"), str(inp), str(out)], check=True, timeout=300)
+    oracle.solve_file(str(inp), str(out_ref))
+    a, b = out.read_text().split("\n"), out_ref.read_text().split("\n")
+    assert a[1:] == b[1:], (name, a, b)            # hit step, device id and cost: exactly
+    assert abs(float(a[0]) - float(b[0])) <= 1e-9 * float(b[0])
+
+
+def test_expected_shapes_of_the_edge_cases(oracle):
+    """Make sure the hand-made systems really exercise what their names say (guards against a vacuous test)."""
+    res = {k: oracle.problem23(_system(oracle, v)) for k, v in CASES.items()}
+    assert res["no_hit"][0].hit_time_step == -2
+    assert res["hit_at_step_0"][0].hit_time_step == 0
+    assert res["hit_no_devices"][0].hit_time_step > 0 and res["hit_no_devices"][0].gravity_device_id == -1
+    r, d = res["collision_device_useless"]
+    assert r.hit_time_step > 0 and d[0]["arrival_step"] >= 0 and not d[0]["feasible"] and r.gravity_device_id == -1
+    r, d = res["device_causes_hit"]
+    assert r.hit_time_step > 0 and d[0]["feasible"] and r.gravity_device_id == 2 and r.missile_cost > 0
+    assert d[1]["arrival_step"] > d[0]["arrival_step"] and not d[1]["feasible"]  # the far, light device cannot help
+
+
+def test_abi_error_paths(nb):
+    c = nb.capi
+    with c.Context(8) as ctx:
+        with pytest.raises(c.NBodyError) as e:
+            ctx.step(1, 1)                       # no state yet
+        assert e.value.code == c.NB_ERR_STATE
+        z = np.zeros((3, 8)); z[0] = np.arange(8)
+        ctx.set_state(z, z, np.ones(8))
+        with pytest.raises(c.NBodyError):
+            ctx.set_mass(8, 0.0)                 # index out of range
+        with pytest.raises(c.NBodyError):
+            ctx.run_scenario(c.NB_SCN_MIN_DIST, 0, 9, last_step=10)     # asteroid out of range
+        with pytest.raises(c.NBodyError):
+            ctx.run_scenario(c.NB_SCN_FIRST_HIT, 0, 1, last_step=10, watch=[99])
+        with pytest.raises(c.NBodyError):
+            ctx.run_scenario(7, 0, 1, last_step=10)                     # unknown kind
+        with pytest.raises(c.NBodyError):
+            ctx.run_scenario(c.NB_SCN_MIN_DIST, 0, 1, first_step=5, last_step=4)
+        with c.Context(8) as other, pytest.raises(c.NBodyError):
+            other.restore_snapshot_from(ctx, 0)  # no snapshot was taken
+    with pytest.raises(c.NBodyError) as e:
+        c.Context(8, device=64)
+    assert e.value.code == c.NB_ERR_NO_DEVICE
+    with pytest.raises(c.NBodyError):
+        c.Context(0)
+    with c.Context(8, c.NB_F32) as f32, pytest.raises(c.NBodyError):
+        z = np.zeros((3, 8)); z[0] = np.arange(8)
+        f32.set_state(z, z, np.ones(8))
+        f32.run_scenario(c.NB_SCN_MIN_DIST, 0, 1, last_step=3)          # scenarios are fp64-only
+
+
+def test_cli_unreadable_input(nb, tmp_path):
+    p = subprocess.run([os.path.join(ROOT, "bin", "hw5"), str(tmp_path / "nope.in"), str(tmp_path / "o")],
+                       capture_output=True)
+    assert p.returncode == 1 and b"cannot read" in p.stderr
+
+
+def test_permutation_invariance(nb, oracle):
+    """Reordering the bodies (what hw5.cu:110-130 does to put planet/asteroid/devices first) must not change the
+    physics: same accelerations for the same bodies, to rounding."""
+    from conftest import case_path
+    s = oracle.read_input(case_path("b200", "in"))
+    perm = np.random.default_rng(3).permutation(s.n)
+    with nb.capi.Context(s.n) as a, nb.capi.Context(s.n) as b:
+        a.set_state(s.q, s.v, s.m, s.is_device)
+        b.set_state(s.q[:, perm], s.v[:, perm], s.m[perm], s.is_device[perm])
+        acc_a, acc_b = a.accel(1234), b.accel(1234)
+    assert np.all(np.abs(acc_a[:, perm] - acc_b) <= 1e-12 * np.abs(acc_a).max())
+    # Newton's third law on the effective masses of that step
+    me = oracle.effective_mass(1234, s.m, s.is_device, 60.0)
+    p = (acc_a * me).sum(axis=1)
+    assert np.all(np.abs(p) <= 1e-10 * (np.abs(acc_a) * me).sum(axis=1))
