@@ -13,8 +13,8 @@ LIB      := $(PKG)/libnbody_amd.so
 KSRC := $(SRC)/nbody_kernels_f32.hip $(SRC)/nbody_kernels_f64.hip
 HDR  := $(SRC)/nbody_kernels.h include/nbody_amd.h
 
-.PHONY: all lib hw5 oracle ubench clean
-all: lib hw5
+.PHONY: all lib hw5 nbody_bench oracle ubench asan clean
+all: lib hw5 nbody_bench
 
 lib: $(LIB)
 $(LIB): $(KSRC) $(SRC)/nbody_capi.cpp $(HDR)
@@ -26,12 +26,26 @@ bin/hw5: $(SRC)/main_hw5.cpp $(SRC)/nbody_io.cpp $(SRC)/nbody_io.h $(LIB)
 	$(HIPCC) -O3 -std=c++17 -o $@ $(SRC)/main_hw5.cpp $(SRC)/nbody_io.cpp -L$(PKG) -lnbody_amd -Wl,-rpath,'$$ORIGIN/../$(PKG):$$ORIGIN/$(PKG)' -lpthread
 	cp $@ hw5
 
+nbody_bench: bin/nbody_bench
+bin/nbody_bench: $(SRC)/main_nbody_bench.cpp $(LIB)
+	@mkdir -p bin
+	$(HIPCC) -O3 -std=c++17 -o $@ $(SRC)/main_nbody_bench.cpp -L$(PKG) -lnbody_amd -Wl,-rpath,'$$ORIGIN/../$(PKG)' -lpthread
+
 oracle:
 	$(MAKE) -C oracle
 
-ubench: bench/ubench/valu_rate
+# host-side sanitizer builds (GPU AddressSanitizer is not available on the pool): text I/O + the CPU checker
+asan: bin/io_check_asan
+	$(MAKE) -C oracle asan
+bin/io_check_asan: $(SRC)/io_check.cpp $(SRC)/nbody_io.cpp $(SRC)/nbody_io.h
+	@mkdir -p bin
+	g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=all -o $@ $(SRC)/io_check.cpp $(SRC)/nbody_io.cpp
+
+ubench: bench/ubench/valu_rate bench/ubench/force_variants
+bench/ubench/force_variants: bench/ubench/force_variants.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -o $@ $<
 bench/ubench/valu_rate: bench/ubench/valu_rate.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
 
 clean:
-	rm -f $(LIB) bin/hw5 hw5 bench/ubench/valu_rate
+	rm -f $(LIB) bin/hw5 bin/nbody_bench hw5 bench/ubench/valu_rate bench/ubench/force_variants

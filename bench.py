@@ -83,6 +83,10 @@ def main():
     ap.add_argument("--source-path", type=int, default=0, help="0 auto, 1 LDS tile, 2 SGPR/scalar loads")
     ap.add_argument("--wg-size", type=int, default=0, help="0 auto, 256, 512 (with --targets-per-lane 8), 1024 (4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--report-every", type=int, default=0, help="sustained runs (configs[4]): every R steps synchronise "
+                    "and print steps done + running pairs/s to stderr")
+    ap.add_argument("--time-box", type=float, default=0.0, help="sustained runs: stop at a report point once this many "
+                    "seconds have elapsed; the JSON then carries the steps actually completed")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; gloo + --single-device rehearses "
                     "the multi-rank path on a one-GPU box (RCCL refuses two ranks on one device)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
@@ -148,10 +152,25 @@ def main():
         sysm.step()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    steps_done = 0
+    for k in range(args.steps):
         timed_step()
+        steps_done += 1
+        if args.report_every and steps_done % args.report_every == 0 and steps_done < args.steps:
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            stop = torch.tensor([1.0 if (args.time_box and el > args.time_box) else 0.0])
+            if world > 1:
+                stop = stop.to(device if args.backend == "nccl" else "cpu")
+                dist.all_reduce(stop, op=dist.ReduceOp.MAX)  # every rank stops at the same step
+            if rank == 0:
+                print(f"[bench] {steps_done}/{args.steps} steps, {el:.1f} s, "
+                      f"{n * (n - 1) * steps_done / el:.4e} pairs/s sustained", file=sys.stderr, flush=True)
+            if float(stop.item()) > 0:
+                break
     barrier()
     wall = time.perf_counter() - t0
+    args.steps = steps_done
     if world > 1:
         t = torch.tensor([wall], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

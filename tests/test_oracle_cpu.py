@@ -93,3 +93,34 @@ def test_host_io_roundtrip(nb, tmp_path):
     assert nb.host.param.get_missile_cost(60.0) == 1e5 + 6e4
     with pytest.raises(RuntimeError, match="must supply 2 arguments"):
         nb.host.main(["prog"])
+
+
+def test_host_code_under_sanitizers(tmp_path):
+    """ASan + UBSan over the host-side code: the product's text I/O on every testcase input, and the oracle on a
+    small full run (GPU AddressSanitizer is unavailable on the pool; the reference's equivalent was cuda-memcheck)."""
+    from conftest import ALL_CASES
+    subprocess.run(["make", "-C", ROOT, "asan"], check=True, stdout=subprocess.DEVNULL)
+    io = os.path.join(ROOT, "bin", "io_check_asan")
+    for case in ALL_CASES:
+        p = subprocess.run([io, case_path(case, "in")], capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+        n, planet, asteroid, ndev = [int(x) for x in p.stdout.split()[:4]]
+        assert n == int(case[1:]) and ndev in (2, 3, 4)
+    out = tmp_path / "w.out"
+    g = read_golden("b40")
+    p = subprocess.run([io, case_path("b40", "in"), str(out), repr(g[0]), str(g[1]), str(g[2]), repr(g[3])],
+                       capture_output=True, text=True)
+    assert p.returncode == 0 and out.read_text() == g[4], p.stderr
+    # truncated input: must fail cleanly, not read out of bounds
+    bad = tmp_path / "bad.in"
+    bad.write_text("5 0 1\n1 2 3 4 5 6 7 rock\n1 2 3\n")
+    assert subprocess.run([io, str(bad)], capture_output=True).returncode == 1
+    # the oracle itself on a 4-body system through all three problems
+    small = tmp_path / "s.in"
+    small.write_text("4 0 1\n0 0 0 0 0 0 6e24 planet\n4e8 6e7 0 -2e3 0 0 1e12 asteroid\n"
+                     "1e8 -2e8 0 0 0 0 3e24 device\n-9e8 9e8 0 0 0 0 1e10 device\n")
+    so = tmp_path / "s.out"
+    p = subprocess.run([os.path.join(ROOT, "oracle", "_build", "nbody_oracle_asan"), str(small), str(so)],
+                       capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+    assert p.returncode == 0, p.stderr
+    assert so.read_text().split("\n")[1:3] == ["2506", "2 4.0000000000000000e+05"]
