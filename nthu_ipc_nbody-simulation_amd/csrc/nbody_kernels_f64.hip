@@ -91,6 +91,17 @@ __global__ __launch_bounds__(WG) void nbody_step_f64(F64Args a) {
     };
     issue_loads(0);
 
+    constexpr int TPB = WG / S;  // targets per workgroup
+    const int ls = t % S;        // this lane's slice of the source range
+    const int i = blockIdx.x * TPB + t / S;
+    const bool owner = (ls == 0) && (i < n);
+    const int ic = i < n ? i : n - 1;
+    // the target's own position and (owner lanes) velocity are requested now too: nothing below may add another
+    // dependent memory round trip to the launch's critical path
+    const double xi = a.qin[ic], yi = a.qin[n + ic], zi = a.qin[2 * n + ic];
+    double vx0 = 0, vy0 = 0, vz0 = 0;
+    if (owner) { vx0 = a.v[i]; vy0 = a.v[n + i]; vz0 = a.v[2 * n + i]; }
+
     // ---- monitor on the state after step-1 (index step-1), evaluated identically by every workgroup;
     //      only workgroup 0 records it.  A value another workgroup of THIS launch may already have written
     //      (arrival_step == step-1, hit_step == step-1) leads to the same decision as re-deriving it.
@@ -135,12 +146,6 @@ __global__ __launch_bounds__(WG) void nbody_step_f64(F64Args a) {
         sh_snap = snap;
     }
 
-    constexpr int TPB = WG / S;  // targets per workgroup
-    const int ls = t % S;        // this lane's slice of the source range
-    const int i = blockIdx.x * TPB + t / S;
-    const bool owner = (ls == 0) && (i < n);
-    const int ic = i < n ? i : n - 1;
-    const double xi = a.qin[ic], yi = a.qin[n + ic], zi = a.qin[2 * n + ic];
     double ax = 0, ay = 0, az = 0;
 
     // stage a pass into LDS: G*m_eff with the device-mass law m0 + 0.5*m0*|sin(t/6000)| (nbody.cc:14-16,61-64), rounded
@@ -167,10 +172,8 @@ __global__ __launch_bounds__(WG) void nbody_step_f64(F64Args a) {
             if (snap & (1u << k)) {
                 double* dq = a.snap_q + (size_t)k * 3 * n;
                 double* dv = a.snap_v + (size_t)k * 3 * n;
-                for (int c = 0; c < 3; ++c) {
-                    dq[c * n + i] = a.qin[c * n + i];
-                    dv[c * n + i] = a.v[c * n + i];
-                }
+                dq[i] = xi; dq[n + i] = yi; dq[2 * n + i] = zi;
+                dv[i] = vx0; dv[n + i] = vy0; dv[2 * n + i] = vz0;
             }
     }
     if (skip) return;  // workgroup-uniform
@@ -218,9 +221,9 @@ __global__ __launch_bounds__(WG) void nbody_step_f64(F64Args a) {
             a.acc_out[i] = ax; a.acc_out[n + i] = ay; a.acc_out[2 * n + i] = az;
         } else {
             // kick, then drift with the NEW velocity (nbody.cc:76-88), written without contraction
-            double vx = __dadd_rn(a.v[i], __dmul_rn(ax, a.dt));
-            double vy = __dadd_rn(a.v[n + i], __dmul_rn(ay, a.dt));
-            double vz = __dadd_rn(a.v[2 * n + i], __dmul_rn(az, a.dt));
+            double vx = __dadd_rn(vx0, __dmul_rn(ax, a.dt));
+            double vy = __dadd_rn(vy0, __dmul_rn(ay, a.dt));
+            double vz = __dadd_rn(vz0, __dmul_rn(az, a.dt));
             a.v[i] = vx; a.v[n + i] = vy; a.v[2 * n + i] = vz;
             a.qout[i] = __dadd_rn(xi, __dmul_rn(vx, a.dt));
             a.qout[n + i] = __dadd_rn(yi, __dmul_rn(vy, a.dt));
