@@ -1,5 +1,5 @@
-// nbody_kernels_f32.hip — K1: LDS-tiled all-pairs force accumulation in fp32 with the kick-drift update fused
-// into its epilogue, hand-written for gfx950 (CDNA4, wave64).
+// nbody_kernels_f32.hip — K1: all-pairs force accumulation in fp32 (sources broadcast from SGPRs, or staged through an
+// LDS tile) with the kick-drift update fused into its epilogue, hand-written for gfx950 (CDNA4, wave64).
 //
 // Replaces the reference's compute_accelerations_gpu (hw5.cu:159-215: one thread per (i,j) pair, three global
 // fp64 atomics per pair) + update_positions_gpu (hw5.cu:231-239) + clear_a_gpu (hw5.cu:224-229), i.e. the
@@ -18,7 +18,7 @@
 //      L2) into SGPRs and used directly as the broadcast operand of the packed VALU ops
 //      (v_pk_add_f32 v, s[n:n+1], v op_sel_hi:[0,1]).  No ds_read, no v_mov, no barrier, no s_nop in the
 //      loop: exactly 12 packed VALU + 2 v_rsq_f32 per 2 pairs.  Measured (bench/ubench/force_variants.hip,
-//      profiles/r01_force_variants.txt): 58 % of peak vs 52 % for the LDS path.
+//      profiles/r01_force_variants.txt; bench.py --source-path): 55.5 % of peak vs 52 % for the LDS path.
 //  * targets are held two-per-register-pair (ext_vector float2) so the loop is PACKED fp32:
 //    per source and target pair 3 v_pk_add, 3 v_pk_fma, 2 v_rsq_f32, 3 v_pk_mul, 3 v_pk_fma
 //    = 12 packed VALU + 2 transcendentals per 2 pairs.
