@@ -59,6 +59,32 @@ def cpu_baseline(n_sample=16384, steps=2):
                       f"({pairs:.3g} pairs, {dt:.1f} s)"}
 
 
+def cpu_baseline_all_cores(n_total, rows=2048):
+    """The oracle port (bit-identical restatement of run_step's accel phase), OpenMP over target rows on every host
+    core, on `rows` strided targets against ALL n_total sources of the bench input."""
+    import numpy as np
+    from nbody_amd import synthetic
+    from oracle import oracle as O
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))  # the box's CPU share for one GPU
+    os.environ["OMP_NUM_THREADS"] = str(cores)  # read by libgomp when the OpenMP build of the oracle is first loaded
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+    q, _, m = synthetic.bodies(n_total)
+    lo = (n_total // 2 // rows) * rows  # a contiguous block in the middle of the index range
+    O.accel_rows(q, m, synthetic.G, synthetic.EPS, lo, lo + 8, omp=True)  # thread pool warm-up
+    t0 = time.perf_counter()
+    a = O.accel_rows(q, m, synthetic.G, synthetic.EPS, lo, lo + rows, omp=True)
+    dt = time.perf_counter() - t0
+    assert np.isfinite(a).all()
+    pairs = rows * (n_total - 1)
+    return {"value": pairs / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/nbody_oracle.c accel rows (OpenMP, {cores} threads), {rows} targets x {n_total} sources "
+                      f"of the same input ({pairs:.3g} pairs, {dt:.1f} s)"}
+
+
 def load_traffic(n_bodies, world):
     """HBM bytes per force-kernel launch from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -214,6 +240,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(n)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

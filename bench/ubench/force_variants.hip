@@ -93,7 +93,7 @@ __device__ __forceinline__ void interact_staged(const float4* s, const v2f* xi, 
 #undef ST
 }
 
-template <int P, int VAR, int U, int MINW, int WGS = 256, bool SYNC = false>
+template <int P, int VAR, int U, int MINW, int WGS = 256, bool SYNC = false, int STAG = 0>
 __global__ __launch_bounds__(WGS, MINW) void force(const float4* __restrict__ src_all, long n_src_all, long n_tgt,
                                                   float4* __restrict__ acc_all, float eps2s) {
     const long n_src = n_src_all / gridDim.y;
@@ -154,6 +154,12 @@ __global__ __launch_bounds__(WGS, MINW) void force(const float4* __restrict__ sr
             if (((j + U) & (TILE - 1)) == 0) {
                 A.flush();
                 if (SYNC) __syncthreads();  // keep the workgroup's waves within one tile of each other (L2 locality)
+                if (STAG) {  // de-phase the waves that share a SIMD (waves w, w+4, w+8, w+12) by STAG*64 cycles each
+                    const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
+                    if (g == 1) __builtin_amdgcn_s_sleep(STAG);
+                    if (g == 2) __builtin_amdgcn_s_sleep(2 * STAG);
+                    if (g == 3) __builtin_amdgcn_s_sleep(3 * STAG);
+                }
             }
         }
     } else {
@@ -189,10 +195,10 @@ __global__ __launch_bounds__(WGS, MINW) void force(const float4* __restrict__ sr
 
 static std::vector<float4> ref_acc;
 
-template <int P, int VAR, int U, int MINW, int WGS = 256, bool SYNC = false>
+template <int P, int VAR, int U, int MINW, int WGS = 256, bool SYNC = false, int STAG = 0>
 static void run(const char* name, const float4* d_src, long n_src, long n_tgt, float4* d_acc, int js = 1) {
     const long blocks = (n_tgt + WGS * 2 * P - 1) / (WGS * 2 * P);
-    auto launch = [&] { hipLaunchKernelGGL((force<P, VAR, U, MINW, WGS, SYNC>), dim3(blocks, js), dim3(WGS), 0, 0, d_src, n_src, n_tgt, d_acc, 1e-6f); };
+    auto launch = [&] { hipLaunchKernelGGL((force<P, VAR, U, MINW, WGS, SYNC, STAG>), dim3(blocks, js), dim3(WGS), 0, 0, d_src, n_src, n_tgt, d_acc, 1e-6f); };
     launch();
     CK(hipDeviceSynchronize());
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -229,12 +235,12 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&d_src, n_tgt * sizeof(float4))); CK(hipMalloc(&d_acc, 4 * n_tgt * sizeof(float4)));
     CK(hipMemcpy(d_src, h.data(), n_tgt * sizeof(float4), hipMemcpyHostToDevice));
     printf("n_tgt=%ld n_src=%ld\n", n_tgt, n_src);
-    run<4, V_SMEM, 8, 2>("SMEM P=4 U=8 wg256", d_src, n_src, n_tgt, d_acc);
-    run<4, V_SMEM, 8, 2, 256, true>("SMEM P=4 U=8 wg256 sync", d_src, n_src, n_tgt, d_acc);
-    run<4, V_SMEM, 8, 2, 512, false>("SMEM P=4 U=8 wg512", d_src, n_src, n_tgt, d_acc);
-    run<4, V_SMEM, 8, 2, 512, true>("SMEM P=4 U=8 wg512 sync", d_src, n_src, n_tgt, d_acc);
-    run<4, V_SMEM, 8, 1, 1024, true>("SMEM P=4 U=8 wg1024 sync", d_src, n_src, n_tgt, d_acc);
     run<2, V_SMEM, 8, 4, 1024, true>("SMEM P=2 U=8 wg1024 sync", d_src, n_src, n_tgt, d_acc);
-    run<2, V_SMEM, 8, 4, 256, false>("SMEM P=2 U=8 wg256", d_src, n_src, n_tgt, d_acc);
+    run<2, V_SMEM, 8, 4, 1024, true, 1>("SMEM P=2 U=8 wg1024 sync stag1", d_src, n_src, n_tgt, d_acc);
+    run<2, V_SMEM, 8, 4, 1024, true, 2>("SMEM P=2 U=8 wg1024 sync stag2", d_src, n_src, n_tgt, d_acc);
+    run<2, V_SMEM, 8, 4, 1024, true, 4>("SMEM P=2 U=8 wg1024 sync stag4", d_src, n_src, n_tgt, d_acc);
+    run<2, V_SMEM, 8, 4, 1024, false>("SMEM P=2 U=8 wg1024 nosync", d_src, n_src, n_tgt, d_acc);
+    run<2, V_SMEM, 8, 4, 1024, true>("SMEM P=2 U=8 wg1024 sync (again)", d_src, n_src, n_tgt, d_acc);
+    run<2, V_SMEM, 4, 4, 1024, true>("SMEM P=2 U=4 wg1024 sync", d_src, n_src, n_tgt, d_acc);
     return 0;
 }
