@@ -157,6 +157,16 @@ def test_full_size_properties_n2e20(nb, oracle):
     assert np.array_equal(a, a2)
 
 
+def test_spot_check_n2e22(nb, oracle):
+    """BASELINE configs[3] size (N=2^22, the 8-GPU case) on one GPU, fp32 pair math with fp64 accumulation
+    (configs[4]'s arithmetic): 64-bit indexing, 16 strided targets against all 4.2M sources vs the oracle."""
+    n = 1 << 22
+    rows = np.arange(16) * (n // 16) + 5
+    err, a, m = _accel_err(nb, oracle, n, nb.capi.NB_F32_ACC64, rows=rows)
+    assert err < TOL_ACC64, err
+    assert np.isfinite(a).all()
+
+
 def test_fp32_rejects_eps_zero_and_devices(nb):
     with pytest.raises(nb.capi.NBodyError):
         nb.capi.Context(16, nb.capi.NB_F32, 0, eps=0.0)
