@@ -210,7 +210,7 @@ def main():
         # dominant kernel: this rank's force+kick-drift launch = n_tgt x N pair evaluations, 20 flop each
         flops_launch = FLOP_PER_PAIR * sysm.n_tgt * (n - 1)
         achieved = flops_launch / (k_ms * 1e-3) / 1e12
-        ws_bytes = capi.workspace_bytes_f32(sysm.n_tgt, acc64)
+        ws_bytes = capi.workspace_bytes_f32(sysm.n_tgt, acc64)  # what hip_compute sizes its workspace from
         kname = capi.kernel_name_f32(n, sysm.n_tgt, acc64, args.targets_per_lane, args.j_split, ws_bytes,
                                      source_path=args.source_path, wg_size=args.wg_size)
         tpl, jsp, wgs = capi.plan_f32(n, sysm.n_tgt, acc64, args.targets_per_lane, args.j_split, ws_bytes,

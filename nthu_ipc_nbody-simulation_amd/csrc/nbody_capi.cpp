@@ -57,7 +57,7 @@ struct nb_context {
     double4* pos64 = nullptr;
     double4* vel64 = nullptr;
     void* acc32 = nullptr;
-    void* partial = nullptr;  // j-split workspace [MAX_JSPLIT][n] double4
+    void* partial = nullptr;  // j-split workspace [plan.j_split][n] double4 (only when the plan splits)
 };
 
 namespace {
@@ -232,8 +232,8 @@ int nb_create(nb_context** out, const nb_config* cfg) {
         NB_HIP(c, hipMalloc(&c->pos[1], n * sizeof(float4)));
         NB_HIP(c, hipMalloc(&c->vel, n * sizeof(float4)));
         NB_HIP(c, hipMalloc(&c->acc32, n * sizeof(double4)));
-        if (plan_f32(c->n, c->n, c->n_cus, 0, 0, true).j_split > 1)
-            NB_HIP(c, hipMalloc(&c->partial, (size_t)MAX_JSPLIT * n * sizeof(double4)));
+        const int js = plan_f32(c->n, c->n, c->n_cus, 0, 0, true).j_split;  // the split the step launches will use
+        if (js > 1) NB_HIP(c, hipMalloc(&c->partial, (size_t)js * n * sizeof(double4)));
         if (cfg->precision == NB_F32_ACC64) {
             NB_HIP(c, hipMalloc(&c->pos64, n * sizeof(double4)));
             NB_HIP(c, hipMalloc(&c->vel64, n * sizeof(double4)));
