@@ -63,7 +63,7 @@ def hip_compute(acc64=False, targets_per_lane=0, j_split=0, source_path=0, wg_si
 class ShardedSystem:
     """N bodies sharded by index over the ranks of the default process group (or unsharded when world == 1)."""
 
-    def __init__(self, n, pos_shard, vel_shard, eps, dt, device, compute=None, acc64=False, group=None):
+    def __init__(self, n, pos_shard, vel_shard, eps, dt, device, compute=None, acc64=False, group=None, trace=False):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.group = group
@@ -73,6 +73,7 @@ class ShardedSystem:
         assert tuple(pos_shard.shape) == (self.n_tgt, 4) and tuple(vel_shard.shape) == (self.n_tgt, 4)
         self.eps2, self.dt = float(eps) * float(eps), float(dt)
         self.acc64 = acc64
+        self.trace = trace and torch.cuda.is_available()  # roctx ranges (torch.cuda.nvtx -> roctx on ROCm) for rocprofv3
         self.compute = compute or hip_compute(acc64)
         self.pos = [torch.zeros((n, 4), dtype=torch.float32, device=device) for _ in range(2)]
         self.vel = vel_shard.to(device=device, dtype=torch.float32).contiguous()
@@ -100,8 +101,15 @@ class ShardedSystem:
 
     def step(self):
         src, out = self.pos[self.cur], self.pos[self.cur ^ 1]
+        if self.trace:
+            torch.cuda.nvtx.range_push("nbody.force_kick_drift")
         self.compute(src, out, self.vel, self.lo, self.n_tgt, self.eps2, self.dt, self.pos64, self.vel64)
+        if self.trace:
+            torch.cuda.nvtx.range_pop()
+            torch.cuda.nvtx.range_push("nbody.allgather_positions")
         self._exchange(out)
+        if self.trace:
+            torch.cuda.nvtx.range_pop()
         self.cur ^= 1
 
     @property
