@@ -160,8 +160,8 @@ typedef struct nb_launch_f32 {
     void* pos64; /* NULL unless acc64 */
     void* vel64; /* NULL unless acc64 */
     void* acc;   /* nb_launch_accel_f32 only: float4[n_tgt] {ax,ay,az,0} (acc64: double4[n_tgt]) */
-    void* workspace; /* optional scratch for the j-split (partial sums); NULL -> never split */
-    int64_t workspace_bytes; /* its size; nb_workspace_bytes_f32() is always enough */
+    void* workspace; /* optional scratch for source slicing (partial + running sums); NULL -> never slice */
+    int64_t workspace_bytes; /* its size; must be >= nb_workspace_bytes_f32() or the sources are not sliced */
     int64_t n_src;
     int64_t tgt_off;
     int64_t n_tgt;
@@ -169,7 +169,8 @@ typedef struct nb_launch_f32 {
     float dt;
     int32_t acc64;            /* 0 = NB_F32, 1 = NB_F32_ACC64 */
     int32_t targets_per_lane; /* 0 = auto; 2, 4 or 8 (packed pairs of targets per lane) */
-    int32_t j_split;          /* 0 = auto; 1..16 workgroups share a target block, each over a slice of the sources */
+    int32_t j_split;          /* 0 = auto; 1..1024 source slices (~1 MiB each when auto): workgroups sharing a target
+                                 block each take one slice; 16 slices per launch, partial sums folded by a reducer */
     int32_t source_path;      /* 0 = auto; 1 = sources through the LDS tile; 2 = sources through scalar loads/SGPRs */
     int32_t wg_size;          /* 0 = auto; 256, 512 (targets_per_lane 8) or 1024 (targets_per_lane 4) */
     int32_t reserved;
@@ -180,7 +181,7 @@ int nb_launch_accel_f32(const nb_launch_f32* a, void* hip_stream); /* force only
 const char* nb_kernel_name_f32(const nb_launch_f32* a, int accel_only);
 /* the register blocking, source split and workgroup size the launches above will use for these arguments */
 int nb_plan_f32(const nb_launch_f32* a, int* targets_per_lane, int* j_split, int* wg_size);
-/* workspace size that allows any split for n_tgt targets */
+/* workspace size that allows source slicing for n_tgt targets: 18 records per target */
 int64_t nb_workspace_bytes_f32(int64_t n_tgt, int acc64);
 
 #ifdef __cplusplus

@@ -57,7 +57,7 @@ struct nb_context {
     double4* pos64 = nullptr;
     double4* vel64 = nullptr;
     void* acc32 = nullptr;
-    void* partial = nullptr;  // j-split workspace [plan.j_split][n] double4 (only when the plan splits)
+    void* partial = nullptr;  // source-slice workspace [SLICES_PER_LAUNCH + 2][n] float4 (double4 for ACC64)
 };
 
 namespace {
@@ -232,8 +232,10 @@ int nb_create(nb_context** out, const nb_config* cfg) {
         NB_HIP(c, hipMalloc(&c->pos[1], n * sizeof(float4)));
         NB_HIP(c, hipMalloc(&c->vel, n * sizeof(float4)));
         NB_HIP(c, hipMalloc(&c->acc32, n * sizeof(double4)));
-        const int js = plan_f32(c->n, c->n, c->n_cus, 0, 0, true).j_split;  // the split the step launches will use
-        if (js > 1) NB_HIP(c, hipMalloc(&c->partial, (size_t)js * n * sizeof(double4)));
+        if (plan_f32(c->n, c->n, c->n_cus, 0, 0, true).j_split > 1) {  // the step launches will slice the sources
+            const size_t rec = cfg->precision == NB_F32_ACC64 ? sizeof(double4) : sizeof(float4);
+            NB_HIP(c, hipMalloc(&c->partial, (size_t)(SLICES_PER_LAUNCH + 2) * n * rec));
+        }
         if (cfg->precision == NB_F32_ACC64) {
             NB_HIP(c, hipMalloc(&c->pos64, n * sizeof(double4)));
             NB_HIP(c, hipMalloc(&c->vel64, n * sizeof(double4)));
@@ -771,9 +773,9 @@ static F32Plan resolve_plan(const nb_launch_f32* a) {
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     F32Plan p = plan_f32(a->n_tgt, a->n_src, cus, a->targets_per_lane, a->j_split, a->workspace != nullptr,
                          a->source_path, a->wg_size);
-    // the caller's workspace must hold j_split slices of n_tgt records
+    // the caller's workspace must hold SLICES_PER_LAUNCH partial records + running sum + compensation per target
     const size_t rec = a->acc64 ? sizeof(double4) : sizeof(float4);
-    while (p.j_split > 1 && (size_t)p.j_split * (size_t)a->n_tgt * rec > (size_t)a->workspace_bytes) p.j_split >>= 1;
+    if ((size_t)(SLICES_PER_LAUNCH + 2) * (size_t)a->n_tgt * rec > (size_t)a->workspace_bytes) p.j_split = 1;
     return p;
 }
 
@@ -821,7 +823,7 @@ int nb_plan_f32(const nb_launch_f32* a, int* targets_per_lane, int* j_split, int
 }
 
 int64_t nb_workspace_bytes_f32(int64_t n_tgt, int acc64) {
-    return (int64_t)MAX_JSPLIT * n_tgt * (int64_t)(acc64 ? sizeof(double4) : sizeof(float4));
+    return (int64_t)(SLICES_PER_LAUNCH + 2) * n_tgt * (int64_t)(acc64 ? sizeof(double4) : sizeof(float4));
 }
 
 }  // extern "C"

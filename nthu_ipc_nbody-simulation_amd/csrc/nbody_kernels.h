@@ -19,14 +19,18 @@ struct F32Args {
     double4* pos64;     // [n_tgt] fp64 masters (ACC64 only)
     double4* vel64;     // [n_tgt]
     void* acc;          // accel-only output
-    void* partial;      // j-split workspace: float4 (double4 if acc64) [j_split][n_tgt]
+    void* partial;      // source-slice workspace, records float4 (double4 if acc64):
+                        //   [SLICES_PER_LAUNCH][n_tgt] partial sums of one launch + [2][n_tgt] running sum / compensation
     long n_src, tgt_off, n_tgt;
+    long tiles_per_slice;  // SPLIT launches: 256-source tiles per source slice ...
+    int slice0;            // ... and the index of the slice blockIdx.y == 0 works on
     float eps2, dt;
 };
-constexpr int MAX_JSPLIT = 16;
+constexpr int SLICES_PER_LAUNCH = 16;  // blockIdx.y extent of one split launch = partial-sum slots in the workspace
+constexpr int MAX_JSPLIT = 1024;       // source slices per step (processed SLICES_PER_LAUNCH at a time)
 struct F32Plan {
     int targets_per_lane = 4;  // 2, 4 or 8 (one, two or four packed pairs per lane)
-    int j_split = 1;           // workgroups sharing one target block, each over 1/j_split of the sources
+    int j_split = 1;           // source slices: workgroups sharing one target block, each over 1/j_split of the sources
     bool sgpr_sources = true;  // sources via scalar loads into SGPRs (default) instead of the LDS tile
     int wg_size = 256;         // threads per workgroup: 256, 512 (R = 8) or 1024 (R = 4); LDS path: 256
 };

@@ -31,8 +31,12 @@
 //  * summation is two-level: the 256 contributions of a tile are summed in fp32 registers, then the tile's
 //    partial is added to the running sum — compensated (Kahan) in NB_F32, in fp64 in NB_F32_ACC64 — so the
 //    rounding error does not grow with sqrt(N) (plain fp32 running sums measured 2.6e-5 * sum|a_ij| at N=2^20).
-//  * j-split: when the targets alone cannot fill the chip (multi-GPU shards), blockIdx.y splits the source
-//    range; partial sums go to a workspace and nbody_reduce_update_f32 combines them and does the update.
+//  * source slices (j-split): the source range is cut into slices of ~1 MiB (65 536 bodies) and blockIdx.y of a
+//    launch walks 16 of them; partial sums go to a workspace and nbody_reduce_update_f32 folds them into a running
+//    (compensated) sum, the last fold doing the update.  Two reasons, both measured: (1) all workgroups resident at
+//    one time then stream the SAME L2-resident megabyte instead of a 16.8 MB array that no 4 MiB L2 can hold —
+//    +3 points of peak at N = 2^20 (55.6 -> 58.9 %, bench.py --j-split); (2) a multi-GPU shard's targets alone
+//    cannot give every CU a workgroup, the slices can.
 //  * MFMA deliberately unused: the only GEMM-shaped reformulation (sum_j s_ij x_j - x_i sum_j s_ij) cancels
 //    catastrophically for close pairs; the loop is rsqrt-bound VALU work.
 //  * every workgroup streams the whole source array at the same pace, so a tile is fetched once per XCD and
@@ -163,9 +167,8 @@ __global__ __launch_bounds__(WGS, (WGS == 1024 ? 4 : WGS == 512 ? 2 : (P >= 4 ? 
     const long ntiles_all = (a.n_src + TILE - 1) / TILE;
     long k0 = 0, k1 = ntiles_all;
     if (SPLIT) {
-        const long per = (ntiles_all + gridDim.y - 1) / gridDim.y;
-        k0 = (long)blockIdx.y * per;
-        k1 = k0 + per < ntiles_all ? k0 + per : ntiles_all;
+        k0 = ((long)a.slice0 + blockIdx.y) * a.tiles_per_slice;
+        k1 = k0 + a.tiles_per_slice < ntiles_all ? k0 + a.tiles_per_slice : ntiles_all;
         if (k0 > k1) k0 = k1;
     }
 
@@ -236,46 +239,73 @@ __global__ __launch_bounds__(WGS, (WGS == 1024 ? 4 : WGS == 512 ? 2 : (P >= 4 ? 
     }
 }
 
-// combine the j-split partials (a.partial[js][n_tgt]) and run the epilogue
+// fold the partial sums of one split launch (a.partial[gy][n_tgt]) into the running sum kept behind them in the
+// workspace (compensated in fp32, plain in fp64); the last fold of a step runs the epilogue instead of storing
 template <bool ACC64, bool ACCEL_ONLY>
-__global__ __launch_bounds__(WG) void nbody_reduce_update_f32(F32Args a, int js) {
+__global__ __launch_bounds__(WG) void nbody_reduce_update_f32(F32Args a, int gy, int first, int last) {
     const long i = (long)blockIdx.x * WG + threadIdx.x;
     if (i >= a.n_tgt) return;
-    const float4 b = a.src[a.tgt_off + i];
+    const long run_at = (long)SLICES_PER_LAUNCH * a.n_tgt + i, comp_at = run_at + a.n_tgt;
     if (ACC64) {
-        double x = 0, y = 0, z = 0;
-        for (int s = 0; s < js; ++s) {
-            double4 p = ((const double4*)a.partial)[(long)s * a.n_tgt + i];
-            x += p.x; y += p.y; z += p.z;
+        double4* ws = (double4*)a.partial;
+        double4 run = first ? make_double4(0, 0, 0, 0) : ws[run_at];
+        for (int s = 0; s < gy; ++s) {
+            const double4 p = ws[(long)s * a.n_tgt + i];
+            run.x += p.x; run.y += p.y; run.z += p.z;
         }
-        finish_target<true, ACCEL_ONLY>(a, i, x, y, z, b.x, b.y, b.z, b.w);
+        if (last) {
+            const float4 b = a.src[a.tgt_off + i];
+            finish_target<true, ACCEL_ONLY>(a, i, run.x, run.y, run.z, b.x, b.y, b.z, b.w);
+        } else {
+            ws[run_at] = run;
+        }
     } else {
-        float x = 0, y = 0, z = 0;
-        for (int s = 0; s < js; ++s) {
-            float4 p = ((const float4*)a.partial)[(long)s * a.n_tgt + i];
-            x += p.x; y += p.y; z += p.z;
+        float4* ws = (float4*)a.partial;
+        float4 run = first ? make_float4(0, 0, 0, 0) : ws[run_at];
+        float4 c = first ? make_float4(0, 0, 0, 0) : ws[comp_at];
+        for (int s = 0; s < gy; ++s) {  // Kahan, like the in-kernel second level
+            const float4 p = ws[(long)s * a.n_tgt + i];
+            float y, t;
+            y = p.x - c.x; t = run.x + y; c.x = (t - run.x) - y; run.x = t;
+            y = p.y - c.y; t = run.y + y; c.y = (t - run.y) - y; run.y = t;
+            y = p.z - c.z; t = run.z + y; c.z = (t - run.z) - y; run.z = t;
         }
-        finish_target<false, ACCEL_ONLY>(a, i, x, y, z, b.x, b.y, b.z, b.w);
+        if (last) {
+            const float4 b = a.src[a.tgt_off + i];
+            finish_target<false, ACCEL_ONLY>(a, i, run.x, run.y, run.z, b.x, b.y, b.z, b.w);
+        } else {
+            ws[run_at] = run;
+            ws[comp_at] = c;
+        }
     }
 }
 
 template <int P, bool ACC64, bool ACCEL_ONLY, bool SGPR, int WGS>
-static int launch_one(const F32Args& a, int js, hipStream_t stream) {
+static int launch_one(const F32Args& a0, int js, hipStream_t stream) {
     const long per_block = (long)WGS * 2 * P;
-    const long blocks = (a.n_tgt + per_block - 1) / per_block;
+    const long blocks = (a0.n_tgt + per_block - 1) / per_block;
     if (blocks <= 0 || blocks > 0x7fffffffL) return (int)hipErrorInvalidValue;
     if (js <= 1) {
         hipLaunchKernelGGL((nbody_force_f32<P, ACC64, ACCEL_ONLY, false, SGPR, WGS>), dim3((unsigned)blocks), dim3(WGS), 0,
-                           stream, a);
+                           stream, a0);
         return (int)hipGetLastError();
     }
-    if (!a.partial) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL((nbody_force_f32<P, ACC64, ACCEL_ONLY, true, SGPR, WGS>), dim3((unsigned)blocks, (unsigned)js),
-                       dim3(WGS), 0, stream, a);
-    if (hipError_t e = hipGetLastError()) return (int)e;
+    if (!a0.partial) return (int)hipErrorInvalidValue;
+    F32Args a = a0;
+    const long ntiles = (a.n_src + TILE - 1) / TILE;
+    a.tiles_per_slice = (ntiles + js - 1) / js;
     const long rblocks = (a.n_tgt + WG - 1) / WG;
-    hipLaunchKernelGGL((nbody_reduce_update_f32<ACC64, ACCEL_ONLY>), dim3((unsigned)rblocks), dim3(WG), 0, stream, a, js);
-    return (int)hipGetLastError();
+    for (int s0 = 0; s0 < js; s0 += SLICES_PER_LAUNCH) {  // 16 slices per launch; the running sum carries across
+        const int gy = js - s0 < SLICES_PER_LAUNCH ? js - s0 : SLICES_PER_LAUNCH;
+        a.slice0 = s0;
+        hipLaunchKernelGGL((nbody_force_f32<P, ACC64, ACCEL_ONLY, true, SGPR, WGS>), dim3((unsigned)blocks, (unsigned)gy),
+                           dim3(WGS), 0, stream, a);
+        if (hipError_t e = hipGetLastError()) return (int)e;
+        hipLaunchKernelGGL((nbody_reduce_update_f32<ACC64, ACCEL_ONLY>), dim3((unsigned)rblocks), dim3(WG), 0, stream, a, gy,
+                           (int)(s0 == 0), (int)(s0 + gy >= js));
+        if (hipError_t e = hipGetLastError()) return (int)e;
+    }
+    return (int)hipSuccess;
 }
 
 template <int P, bool SGPR, int WGS>
@@ -312,30 +342,30 @@ const char* kernel_name_f32(const F32Plan& plan, bool acc64, bool accel_only) {
     return s;
 }
 
-// Workgroup shape, register blocking and j-split for n_tgt targets against n_src sources on n_cus CUs
-// (measured: profiles/r01_force_variants*.txt, bench.py --targets-per-lane/--j-split/--wg-size):
-//  * SGPR path, plenty of targets: ONE 1024-thread workgroup per CU (16 waves = 4 per SIMD), R = 4 targets per
-//    lane (2 packed pairs, <= 128 VGPRs) — fastest variant measured and half the L2/fabric traffic of two
-//    independent workgroups per CU; 512 threads x R = 8 ties;
-//  * fewer targets (multi-GPU shards): first split the source range over blockIdx.y (partials + reducer) so that
-//    every CU still gets a workgroup, then fall back to 256-thread workgroups, then to R = 2;
-//  * LDS path: 256 threads (one source per thread per tile), R = 4, >= 4 workgroups per CU.
+// Workgroup shape, register blocking and source slicing for n_tgt targets against n_src sources on n_cus CUs
+// (measured: profiles/r01_force_variants*.txt, profiles/r01_jsplit_search.txt, bench.py --targets-per-lane/--j-split/--wg-size):
+//  * with a workspace: 512-thread workgroups, R = 8 targets per lane (4 packed pairs, ~150 VGPRs, one workgroup =
+//    2 waves per SIMD per CU) and source slices of <= 65 536 bodies (1 MiB, L2-resident): 58.9 % of peak at N = 2^20;
+//    the slice count is raised further when the targets alone cannot give every CU a workgroup (multi-GPU shards);
+//  * without a workspace (no partial sums possible): one 1024-thread workgroup per CU, R = 4, whole source range,
+//    a barrier per 256 sources to keep the CU's waves on the same lines (55.6 %);
+//  * small systems: 256-thread workgroups, R = 4 or 2;  LDS path: 256 threads (one source per thread per tile).
 F32Plan plan_f32(long n_tgt, long n_src, int n_cus, int force_tpl, int force_js, bool have_workspace, int source_path,
                  int force_wg) {
     F32Plan p;
     p.sgpr_sources = source_path != 1;
     const long ntiles = (n_src + TILE - 1) / TILE;
-    const int max_js = have_workspace ? MAX_JSPLIT : 1;
     int wg = force_wg, R = force_tpl;
     if (!p.sgpr_sources) wg = 256;
     if (wg != 256 && wg != 512 && wg != 1024) wg = 0;
     if (R != 2 && R != 4 && R != 8) R = 0;
-    const bool big_ok = p.sgpr_sources && n_tgt * max_js >= 4096L * n_cus;  // a 4096-target workgroup for every CU
+    const bool many = p.sgpr_sources && n_tgt >= 4096L * 8;  // enough targets for 4096-target workgroups at all
     if (wg == 0 && R == 0) {
-        if (big_ok) { wg = 1024; R = 4; }
+        if (many && have_workspace) { wg = 512; R = 8; }
+        else if (many && n_tgt >= 4096L * n_cus) { wg = 1024; R = 4; }
         else { wg = 256; R = n_tgt < 1024 ? 2 : 4; }
     } else if (wg == 0) {
-        wg = (big_ok && R == 4) ? 1024 : (big_ok && R == 8) ? 512 : 256;
+        wg = (many && R == 8) ? 512 : (many && R == 4 && n_tgt >= 4096L * n_cus) ? 1024 : 256;
     } else if (R == 0) {
         R = wg == 1024 ? 4 : wg == 512 ? 8 : (n_tgt < 1024 ? 2 : 4);
     }
@@ -343,17 +373,22 @@ F32Plan plan_f32(long n_tgt, long n_src, int n_cus, int force_tpl, int force_js,
     p.wg_size = wg;
     p.targets_per_lane = R;
     const long bx = (n_tgt + (long)wg * R - 1) / ((long)wg * R);
-    int js = force_js;
+    long js = force_js;
     if (js <= 0) {
         js = 1;
-        // workgroups wanted per CU: 1 x 1024 or 1 x 512 threads (that is all their registers admit), 4 x 256 (2 x 256 for R = 8)
-        const long want = (wg >= 512 ? 1L : (R == 8 ? 2L : 4L)) * n_cus;
-        while (bx * js < want && js < MAX_JSPLIT && (long)js * 2 * 8 <= ntiles) js <<= 1;  // keep >= 8 tiles per slice
+        if (have_workspace) {
+            // locality: slices of <= 256 tiles (65 536 bodies = 1 MiB of float4)
+            while (js * 256 < ntiles && js < MAX_JSPLIT) js <<= 1;
+            // granularity: at least four rounds of resident workgroups (resident per CU: 1 x 1024 or 1 x 512 threads,
+            // 4 x 256, 2 x 256 for R = 8) — measured at N = 2^18: 4 slices 55.3 %, 16 slices 58.2 % (r01_jsplit_search.txt)
+            const long want = 4 * (wg >= 512 ? 1L : (R == 8 ? 2L : 4L)) * n_cus;
+            while (bx * js < want && js < MAX_JSPLIT && js * 2 * 8 <= ntiles) js <<= 1;  // keep >= 8 tiles per slice
+        }
     }
     if (js > MAX_JSPLIT) js = MAX_JSPLIT;
-    if ((long)js > ntiles) js = (int)(ntiles > 0 ? ntiles : 1);
+    if (js > ntiles) js = ntiles > 0 ? ntiles : 1;
     if (!have_workspace) js = 1;
-    p.j_split = js;
+    p.j_split = (int)js;
     return p;
 }
 

@@ -41,11 +41,8 @@ def hip_compute(acc64=False, targets_per_lane=0, j_split=0, source_path=0, wg_si
             raise RuntimeError("nbody_amd has no CPU compute path: tensors must live on a HIP device")
         key = (src.device, src.shape[0], n_tgt)
         if key not in ws:
-            # ask the library which source split it would use with an unlimited workspace, then allocate exactly that
-            _, js, _ = capi.plan_f32(src.shape[0], n_tgt, acc64, targets_per_lane, j_split,
-                                     capi.workspace_bytes_f32(n_tgt, acc64), source_path, wg_size)
-            nbytes = js * n_tgt * (32 if acc64 else 16) if js > 1 else 0
-            ws[key] = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=src.device) if nbytes else None
+            # 18 records per target: 16 partial-sum slots of one launch + running sum + compensation
+            ws[key] = torch.empty(capi.workspace_bytes_f32(n_tgt, acc64), dtype=torch.uint8, device=src.device)
         w = ws[key]
         stream = torch.cuda.current_stream(src.device).cuda_stream
         capi.launch_f32(src.data_ptr(), out.data_ptr(), src.shape[0], off, n_tgt, eps2, dt, stream,
