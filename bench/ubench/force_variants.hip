@@ -93,7 +93,7 @@ __device__ __forceinline__ void interact_staged(const float4* s, const v2f* xi, 
 #undef ST
 }
 
-template <int P, int VAR, int U, int MINW, int WGS = 256, bool SYNC = false, int STAG = 0>
+template <int P, int VAR, int U, int MINW, int WGS = 256, bool SYNC = false, int STAG = 0, int PF = 0>
 __global__ __launch_bounds__(WGS, MINW) void force(const float4* __restrict__ src_all, long n_src_all, long n_tgt,
                                                   float4* __restrict__ acc_all, float eps2s) {
     const long n_src = n_src_all / gridDim.y;
@@ -147,6 +147,11 @@ __global__ __launch_bounds__(WGS, MINW) void force(const float4* __restrict__ sr
             const long jn = (j + U < n_src) ? j + U : 0;
 #pragma unroll
             for (int u = 0; u < U; ++u) nxt[u] = src[jn + u];
+            if (PF) {  // touch the line PF bytes ahead with a vector load whose result is never used: pulls it into L2
+                const long jp = (j + PF / 16 < n_src) ? j + PF / 16 : 0;
+                float junk;
+                asm volatile("global_load_dword %0, %1, off" : "=v"(junk) : "v"(src + jp) : "memory");
+            }
 #pragma unroll
             for (int u = 0; u < U; ++u) interact<P>(cur[u], xi, yi, zi, eps2, A);
 #pragma unroll
@@ -195,10 +200,10 @@ __global__ __launch_bounds__(WGS, MINW) void force(const float4* __restrict__ sr
 
 static std::vector<float4> ref_acc;
 
-template <int P, int VAR, int U, int MINW, int WGS = 256, bool SYNC = false, int STAG = 0>
+template <int P, int VAR, int U, int MINW, int WGS = 256, bool SYNC = false, int STAG = 0, int PF = 0>
 static void run(const char* name, const float4* d_src, long n_src, long n_tgt, float4* d_acc, int js = 1) {
     const long blocks = (n_tgt + WGS * 2 * P - 1) / (WGS * 2 * P);
-    auto launch = [&] { hipLaunchKernelGGL((force<P, VAR, U, MINW, WGS, SYNC, STAG>), dim3(blocks, js), dim3(WGS), 0, 0, d_src, n_src, n_tgt, d_acc, 1e-6f); };
+    auto launch = [&] { hipLaunchKernelGGL((force<P, VAR, U, MINW, WGS, SYNC, STAG, PF>), dim3(blocks, js), dim3(WGS), 0, 0, d_src, n_src, n_tgt, d_acc, 1e-6f); };
     launch();
     CK(hipDeviceSynchronize());
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -232,15 +237,17 @@ int main(int argc, char** argv) {
                      z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31; return (double)(z >> 11) * (1.0 / 9007199254740992.0); };
     for (long i = 0; i < n_tgt; ++i) h[i] = make_float4(2 * rnd() - 1, 2 * rnd() - 1, 2 * rnd() - 1, (0.5 + rnd()) / n_tgt);
     float4 *d_src, *d_acc;
-    CK(hipMalloc(&d_src, n_tgt * sizeof(float4))); CK(hipMalloc(&d_acc, 4 * n_tgt * sizeof(float4)));
+    CK(hipMalloc(&d_src, n_tgt * sizeof(float4))); CK(hipMalloc(&d_acc, 16 * n_tgt * sizeof(float4)));
     CK(hipMemcpy(d_src, h.data(), n_tgt * sizeof(float4), hipMemcpyHostToDevice));
     printf("n_tgt=%ld n_src=%ld\n", n_tgt, n_src);
+    run<4, V_SMEM, 8, 2, 512, true>("SMEM P=4 U=8 wg512 sync", d_src, n_src, n_tgt, d_acc);
+    run<4, V_SMEM, 8, 2, 512, true, 0, 4096>("SMEM P=4 U=8 wg512 sync pf4K", d_src, n_src, n_tgt, d_acc);
+    run<4, V_SMEM, 8, 2, 512, true, 0, 16384>("SMEM P=4 U=8 wg512 sync pf16K", d_src, n_src, n_tgt, d_acc);
+    run<4, V_SMEM, 8, 2, 512, true, 0, 65536>("SMEM P=4 U=8 wg512 sync pf64K", d_src, n_src, n_tgt, d_acc);
+    run<4, V_SMEM, 8, 2, 512, true, 0, 262144>("SMEM P=4 U=8 wg512 sync pf256K", d_src, n_src, n_tgt, d_acc);
+    run<4, V_SMEM, 8, 2, 512, true>("SMEM P=4 U=8 wg512 sync (again)", d_src, n_src, n_tgt, d_acc);
+    run<4, V_SMEM, 8, 2, 512, true, 0, 0>("SMEM P=4 U=8 wg512 sync js16", d_src, n_src, n_tgt, d_acc, 16);
+    run<2, V_SMEM, 8, 4, 1024, true, 0, 16384>("SMEM P=2 U=8 wg1024 sync pf16K", d_src, n_src, n_tgt, d_acc);
     run<2, V_SMEM, 8, 4, 1024, true>("SMEM P=2 U=8 wg1024 sync", d_src, n_src, n_tgt, d_acc);
-    run<2, V_SMEM, 8, 4, 1024, true, 1>("SMEM P=2 U=8 wg1024 sync stag1", d_src, n_src, n_tgt, d_acc);
-    run<2, V_SMEM, 8, 4, 1024, true, 2>("SMEM P=2 U=8 wg1024 sync stag2", d_src, n_src, n_tgt, d_acc);
-    run<2, V_SMEM, 8, 4, 1024, true, 4>("SMEM P=2 U=8 wg1024 sync stag4", d_src, n_src, n_tgt, d_acc);
-    run<2, V_SMEM, 8, 4, 1024, false>("SMEM P=2 U=8 wg1024 nosync", d_src, n_src, n_tgt, d_acc);
-    run<2, V_SMEM, 8, 4, 1024, true>("SMEM P=2 U=8 wg1024 sync (again)", d_src, n_src, n_tgt, d_acc);
-    run<2, V_SMEM, 4, 4, 1024, true>("SMEM P=2 U=4 wg1024 sync", d_src, n_src, n_tgt, d_acc);
     return 0;
 }

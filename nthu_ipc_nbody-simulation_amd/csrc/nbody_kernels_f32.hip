@@ -31,12 +31,14 @@
 //  * summation is two-level: the 256 contributions of a tile are summed in fp32 registers, then the tile's
 //    partial is added to the running sum — compensated (Kahan) in NB_F32, in fp64 in NB_F32_ACC64 — so the
 //    rounding error does not grow with sqrt(N) (plain fp32 running sums measured 2.6e-5 * sum|a_ij| at N=2^20).
-//  * source slices (j-split): the source range is cut into slices of ~1 MiB (65 536 bodies) and blockIdx.y of a
-//    launch walks 16 of them; partial sums go to a workspace and nbody_reduce_update_f32 folds them into a running
-//    (compensated) sum, the last fold doing the update.  Two reasons, both measured: (1) all workgroups resident at
-//    one time then stream the SAME L2-resident megabyte instead of a 16.8 MB array that no 4 MiB L2 can hold —
-//    +3 points of peak at N = 2^20 (55.6 -> 58.9 %, bench.py --j-split); (2) a multi-GPU shard's targets alone
-//    cannot give every CU a workgroup, the slices can.
+//  * source slices (j-split): the source range is cut into slices and blockIdx.y of a launch walks 16 of them;
+//    partial sums go to a workspace and nbody_reduce_update_f32 folds them into a running (compensated) sum, the
+//    last fold doing the update.  Why (all measured, same-device A/B in profiles/r01_jsplit_search.txt): at N = 2^20
+//    an R = 8 kernel has only 2^20/(64*8) = 2048 waves — two per SIMD, one single round of workgroups that all run
+//    for the whole 250 ms.  Slicing multiplies the workgroups: the slice kernel needs no epilogue state (122 VGPRs
+//    -> 4 waves per SIMD), the rounds of short workgroups let faster CUs take more work, and each round streams one
+//    L2-resident megabyte: 54.9 % (1 slice) -> 57.4 % (2) -> 58.7 % (8) -> 58.9 % (16) of peak.  The same mechanism
+//    gives a multi-GPU shard (N/P targets) enough workgroups to fill the chip.
 //  * MFMA deliberately unused: the only GEMM-shaped reformulation (sum_j s_ij x_j - x_i sum_j s_ij) cancels
 //    catastrophically for close pairs; the loop is rsqrt-bound VALU work.
 //  * every workgroup streams the whole source array at the same pace, so a tile is fetched once per XCD and
@@ -377,11 +379,11 @@ F32Plan plan_f32(long n_tgt, long n_src, int n_cus, int force_tpl, int force_js,
     if (js <= 0) {
         js = 1;
         if (have_workspace) {
-            // locality: slices of <= 256 tiles (65 536 bodies = 1 MiB of float4)
-            while (js * 256 < ntiles && js < MAX_JSPLIT) js <<= 1;
-            // granularity: at least four rounds of resident workgroups (resident per CU: 1 x 1024 or 1 x 512 threads,
-            // 4 x 256, 2 x 256 for R = 8) — measured at N = 2^18: 4 slices 55.3 %, 16 slices 58.2 % (r01_jsplit_search.txt)
-            const long want = 4 * (wg >= 512 ? 1L : (R == 8 ? 2L : 4L)) * n_cus;
+            // locality: slices of <= 512 tiles (131 072 bodies = 2 MiB of float4, half an XCD's L2)
+            while (js * 512 < ntiles && js < MAX_JSPLIT) js <<= 1;
+            // granularity: at least eight rounds of 512-thread workgroups (two fit a CU at 122 VGPRs), or the equivalent
+            // for 256-thread ones — N = 2^18: 4 slices 55.3 %, 16 slices 58.2 %; N = 2^20: 2 -> 57.4 %, 8 -> 58.7 %
+            const long want = 8 * (wg >= 512 ? 1L : 2L) * n_cus;
             while (bx * js < want && js < MAX_JSPLIT && js * 2 * 8 <= ntiles) js <<= 1;  // keep >= 8 tiles per slice
         }
     }
