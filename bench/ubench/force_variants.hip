@@ -5,7 +5,11 @@
 //   V_LDS      the product loop: LDS tile, broadcast ds_read_b128, packed pairs, source-major order
 //   V_STAGE    same data path, but U sources x P pairs advanced stage by stage (dependent ops >= U*P apart)
 //   V_SMEM     no LDS: sources are wave-uniform, fetched with scalar loads (s_load_dwordx4..16) into SGPRs,
-//              software-prefetched one batch ahead
+//              software-prefetched one batch ahead (compiler-scheduled)
+//   V_SMEM_PF  the same with the s_load / s_waitcnt placed by hand (inline asm, explicit SGPR ping-pong)
+//   template knobs: WGS (workgroup size), SYNC (barrier per 256 sources), STAG (de-phase waves sharing a SIMD),
+//   PF (touch-load L2 prefetch distance), js argument of run() (source slices over blockIdx.y)
+// Results of every round of experiments: profiles/r01_force_variants*.txt, profiles/r01_jsplit_search.txt
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o force_variants force_variants.hip
 #include <hip/hip_runtime.h>
 #include <algorithm>
