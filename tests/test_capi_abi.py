@@ -71,3 +71,32 @@ def test_state_file_header_errors(nb, tmp_path):
     good = tmp_path / "hdr.nbst"
     good.write_bytes(b"NBODYST1" + struct.pack("<qiiddd", 7, 0, 123, 6.674e-11, 1e-3, 60.0))
     assert nb.capi.state_file_info(str(good)) == (7, 0, 123)
+
+
+def test_header_is_plain_c_and_links_from_c(nb, tmp_path):
+    """The boundary is a C ABI: the header must compile as C99 and a C program must link and call it (no GPU needed
+    for the calls made here)."""
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text(r"""
+#include <stdio.h>
+#include "nbody_amd.h"
+int main(void) {
+    nb_config cfg;
+    nb_scenario scn; nb_scenario_result res; nb_answer ans; nb_launch_f32 l;
+    (void)scn; (void)res; (void)ans; (void)l;
+    if (nb_abi_version() != NB_ABI_VERSION) return 1;
+    if (nb_config_default(&cfg) != NB_OK || cfg.dt != 60.0 || cfg.G != 6.674e-11 || cfg.eps != 1e-3) return 2;
+    if (nb_config_default(0) != NB_ERR_INVALID) return 3;
+    if (nb_workspace_bytes_f32(1000, 0) != 18 * 1000 * 16 || nb_workspace_bytes_f32(1000, 1) != 18 * 1000 * 32) return 4;
+    printf("%s|%s\n", nb_strerror(NB_OK), nb_strerror(NB_ERR_NO_DEVICE));
+    return 0;
+}
+""")
+    exe = tmp_path / "abi"
+    libdir = os.path.dirname(nb.capi.library_path())
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                    "-o", str(exe), str(src), "-L", libdir, "-lnbody_amd", f"-Wl,-rpath,{libdir}"], check=True)
+    p = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert p.returncode == 0, (p.returncode, p.stderr)
+    assert p.stdout.startswith("ok|no usable HIP device")
