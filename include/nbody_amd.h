@@ -117,7 +117,9 @@ int nb_accel(nb_context* ctx, int step, double* ax, double* ay, double* az);
  * recorded on the context's own stream around the `count` steps */
 int nb_step_timed(nb_context* ctx, int first_step, int count, float* ms_per_step);
 
-/* ---- scenario drivers (monitors evaluated on the GPU, no per-step host round trip) ---- */
+/* ---- scenario drivers (monitors evaluated on the GPU, no per-step host round trip) ----
+ * After a scenario that ends in a hit the context's (q,v) are unspecified — the reference discards that state too
+ * (nbody.cc:136 breaks out of the loop); reload with nb_set_state / nb_restore_snapshot / nb_load_state. */
 int nb_run_scenario(nb_context* ctx, const nb_scenario* scn, nb_scenario_result* res);
 /* load the (q,v) snapshot that the last FIRST_HIT scenario on `src` took at watched device `watch_slot`'s
  * missile arrival into `dst` (same n, precision F64, same GPU or not); hw5.cu:482-484 */

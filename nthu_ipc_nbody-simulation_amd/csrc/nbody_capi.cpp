@@ -421,6 +421,8 @@ int nb_run_scenario(nb_context* c, const nb_scenario* s, nb_scenario_result* res
     if (s->last_step < s->first_step) return NB_ERR_INVALID;
     for (int k = 0; k < s->n_watch; ++k)
         if (s->watch[k] < 0 || s->watch[k] >= c->n) return NB_ERR_INVALID;
+    if (s->engine < 0 || s->engine > 2) return NB_ERR_INVALID;
+    if (s->engine == 2 && c->n > SMALL_N_MAX) return NB_ERR_INVALID;
     if (int rc = bind(c)) return rc;
 
     const size_t n = (size_t)c->n;
@@ -450,8 +452,6 @@ int nb_run_scenario(nb_context* c, const nb_scenario* s, nb_scenario_result* res
     NB_HIP(c, hipMemcpyAsync(c->mon, mh, sizeof(F64Monitor), hipMemcpyHostToDevice, c->stream));
     NB_HIP(c, hipStreamSynchronize(c->stream));
 
-    if (s->engine < 0 || s->engine > 2) return NB_ERR_INVALID;
-    if (s->engine == 2 && c->n > SMALL_N_MAX) return NB_ERR_INVALID;
     const bool small_engine = (s->engine == 2) || (s->engine == 0 && c->n <= SMALL_N_MAX);
     if (small_engine) {
         // K3: the whole step loop inside one single-workgroup kernel, in chunks so the host can stop after a hit

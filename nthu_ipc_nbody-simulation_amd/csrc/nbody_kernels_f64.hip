@@ -387,7 +387,8 @@ int launch_f64_small(const F64SmallArgs& a, hipStream_t stream) {
 template <int S>
 static int launch_s(const F64Args& a, hipStream_t stream) {
     constexpr int TPB = WG / S;
-    int blocks = a.do_update ? (a.n + TPB - 1) / TPB : 1;
+    // a monitor-only launch (do_update == 0) still needs every owner lane when a missile-arrival snapshot may be due
+    int blocks = (a.do_update || a.snap_q) ? (a.n + TPB - 1) / TPB : 1;
     hipLaunchKernelGGL((nbody_step_f64<S>), dim3(blocks), dim3(WG), 0, stream, a);
     return (int)hipGetLastError();
 }

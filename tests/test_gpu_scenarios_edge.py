@@ -132,3 +132,22 @@ def test_permutation_invariance(nb, oracle):
     me = oracle.effective_mass(1234, s.m, s.is_device, 60.0)
     p = (acc_a * me).sum(axis=1)
     assert np.all(np.abs(p) <= 1e-10 * (np.abs(acc_a) * me).sum(axis=1))
+
+
+@pytest.mark.parametrize("engine", [1, 2])
+def test_arrival_on_the_final_state_takes_a_complete_snapshot(nb, oracle, engine):
+    """The missile reaches the device exactly at last_step: the arrival is found by the final (monitor-only) evaluation,
+    whose snapshot must still cover every body."""
+    s = _system(oracle, CASES["collision_device_useless"] + [((5e9, 0, 0), (0, 1, 0), 1e10, 0)] * 70)  # 73 bodies
+    _, details = oracle.problem23(s)
+    arr = details[0]["arrival_step"]
+    assert arr == 3
+    ref = s.copy()
+    oracle.run_steps(ref, 1, arr)
+    with nb.capi.Context(s.n) as ctx, nb.capi.Context(s.n) as c3:
+        ctx.set_state(s.q, s.v, s.m, s.is_device)
+        r = ctx.run_scenario(nb.capi.NB_SCN_FIRST_HIT, s.planet, s.asteroid, watch=[2], last_step=arr, engine=engine)
+        assert r["arrival_step"] == [arr] and r["hit_step"] == -2 and r["steps_done"] == arr
+        c3.restore_snapshot_from(ctx, 0)
+        q, v = c3.get_state()
+    assert np.all(np.abs(q - ref.q) <= 1e-12 * np.abs(ref.q).max()) and np.all(np.abs(v - ref.v) <= 1e-12 * np.abs(ref.v).max())
