@@ -365,6 +365,7 @@ F32Plan plan_f32(long n_tgt, long n_src, int n_cus, int force_tpl, int force_js,
     if (wg == 0 && R == 0) {
         if (many && have_workspace) { wg = 512; R = 8; }
         else if (many && n_tgt >= 4096L * n_cus) { wg = 1024; R = 4; }
+        else if (!p.sgpr_sources && n_tgt >= 4096L * 8 && have_workspace) { wg = 256; R = 8; }  // LDS path: 55.3 vs 54.4 %
         else { wg = 256; R = n_tgt < 1024 ? 2 : 4; }
     } else if (wg == 0) {
         wg = (many && R == 8) ? 512 : (many && R == 4 && n_tgt >= 4096L * n_cus) ? 1024 : 256;
