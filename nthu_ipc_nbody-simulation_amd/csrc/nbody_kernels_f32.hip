@@ -365,12 +365,12 @@ F32Plan plan_f32(long n_tgt, long n_src, int n_cus, int force_tpl, int force_js,
     if (wg == 0 && R == 0) {
         if (many && have_workspace) { wg = 512; R = 8; }
         else if (many && n_tgt >= 4096L * n_cus) { wg = 1024; R = 4; }
-        else if (!p.sgpr_sources && n_tgt >= 4096L * 8 && have_workspace) { wg = 256; R = 8; }  // LDS path: 55.3 vs 54.4 %
         else { wg = 256; R = n_tgt < 1024 ? 2 : 4; }
     } else if (wg == 0) {
         wg = (many && R == 8) ? 512 : (many && R == 4 && n_tgt >= 4096L * n_cus) ? 1024 : 256;
     } else if (R == 0) {
         R = wg == 1024 ? 4 : wg == 512 ? 8 : (n_tgt < 1024 ? 2 : 4);
+        if (!p.sgpr_sources && n_tgt >= 4096L * 8 && have_workspace) R = 8;  // LDS path, sliced: 55.3 % vs 54.4 % for R = 4
     }
     if ((wg == 1024 && R != 4) || (wg == 512 && R != 8)) wg = 256;  // beyond 256 threads only (1024,4) and (512,8) exist
     p.wg_size = wg;
