@@ -92,6 +92,30 @@ def library_path():
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One process must not initialise two HIP runtimes.  libnbody_amd.so needs `libamdhip64.so.7`; a PyTorch-ROCm wheel
+    ships its own copy and loads it by path.  If this library pulled in /opt/rocm's copy first, a later `import torch`
+    would bring up a second runtime that reports "No HIP GPUs are available".  So when torch is installed but not yet
+    imported, load ITS runtime first (cheap: no torch import); our library then binds to it by SONAME and a later
+    `import torch` finds it already loaded.  Pure C/C++ hosts (bin/hw5, bin/nbody_bench) use /opt/rocm's runtime."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    hip = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(hip):
+        try:
+            C.CDLL(hip, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Load libnbody_amd.so.  Raises if it has not been built (`make` / __graft_entry__.build())."""
     global _lib
@@ -99,6 +123,7 @@ def lib():
         path = library_path()
         if not os.path.exists(path):
             raise ImportError(f"{path} not built — run `make` (there is no CPU fallback)")
+        _share_hip_runtime_with_torch()
         L = C.CDLL(path)
         for name, (res, args) in SYMBOLS.items():
             f = getattr(L, name)  # AttributeError if the ABI lost a symbol
