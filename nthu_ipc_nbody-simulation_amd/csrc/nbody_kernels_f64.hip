@@ -410,7 +410,8 @@ int launch_f64(const F64Args& a, int S, hipStream_t stream) {
 // and every workgroup stages the whole system, so more workgroups only add L2 traffic: measured at n = 1024,
 // S = 32 (128 workgroups) 5.9 us/step, S = 64 (256 workgroups) 6.2 us/step (profiles/r01_f64_step_timing.txt).
 int auto_split_f64(int n, int n_cus) {
-    long want = (long)n_cus * WG;
+    // beyond the testcase sizes the launch is compute-bound instead: give every SIMD ~4 waves of fp64 work
+    long want = (long)n_cus * WG * (n > K2_TILE ? 8 : 1);
     int S = 1;
     while (S < 64 && (long)n * S * 2 <= want) S <<= 1;
     return S;
