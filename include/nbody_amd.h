@@ -50,7 +50,7 @@ typedef struct nb_config {
     int32_t n;         /* bodies */
     int32_t precision; /* nb_precision */
     int32_t device;    /* HIP device ordinal */
-    int32_t reserved;
+    int32_t f64_large_min; /* NB_F64: from this many bodies on, nb_step/nb_accel use the large-n kernel; 0 = default (32768) */
     double G;   /* 6.674e-11 */
     double eps; /* 1e-3  (Plummer softening; r2 + eps*eps) */
     double dt;  /* 60 */

@@ -16,7 +16,7 @@ _u8p = C.POINTER(C.c_uint8)
 
 
 class NbConfig(C.Structure):
-    _fields_ = [("n", C.c_int32), ("precision", C.c_int32), ("device", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("n", C.c_int32), ("precision", C.c_int32), ("device", C.c_int32), ("f64_large_min", C.c_int32),
                 ("G", C.c_double), ("eps", C.c_double), ("dt", C.c_double)]
 
 
@@ -159,10 +159,11 @@ def _d(a):
 class Context:
     """One nb_context: a system of n bodies resident on one GPU."""
 
-    def __init__(self, n, precision=NB_F64, device=0, G=None, eps=None, dt=None):
+    def __init__(self, n, precision=NB_F64, device=0, G=None, eps=None, dt=None, f64_large_min=0):
         cfg = NbConfig()
         _check(lib().nb_config_default(C.byref(cfg)), "nb_config_default")
         cfg.n, cfg.precision, cfg.device = n, precision, device
+        cfg.f64_large_min = f64_large_min
         if G is not None:
             cfg.G = G
         if eps is not None:

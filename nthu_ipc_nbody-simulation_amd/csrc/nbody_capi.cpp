@@ -44,6 +44,9 @@ struct nb_context {
     double* snap_v = nullptr;
     int snap_slots = 0;
     int split = 1;
+    double* gm_large = nullptr;       // K1-f64 (n > F64_LARGE_MIN): G*m_eff scratch [n]
+    double* partial_large = nullptr;  // ... and partial sums [slices][3][n]
+    int slices_large = 1;
     double* fst_dev = nullptr;  // K3: |sin(step*dt/6000)| table, steps 0 .. fst_len-1
     int fst_len = 0;
     int* done_dev = nullptr;
@@ -91,6 +94,7 @@ void free_dev(T*& p) {
 void release(nb_context* c) {
     free_dev(c->q[0]); free_dev(c->q[1]); free_dev(c->v); free_dev(c->m); free_dev(c->coef); free_dev(c->acc);
     free_dev(c->mon); free_dev(c->snap_q); free_dev(c->snap_v); free_dev(c->fst_dev); free_dev(c->done_dev);
+    free_dev(c->gm_large); free_dev(c->partial_large);
     if (c->done_host) (void)hipHostFree(c->done_host);
     free_dev(c->pos[0]); free_dev(c->pos[1]); free_dev(c->vel); free_dev(c->pos64); free_dev(c->vel64);
     free_dev(c->acc32);
@@ -120,7 +124,33 @@ F64Args base_args(nb_context* c, int step) {
     return a;
 }
 
+F64LargeArgs large_args(nb_context* c, int step) {
+    F64LargeArgs a{};
+    a.q = c->q[c->cur];
+    a.qout = c->q[c->cur ^ 1];
+    a.v = c->v;
+    a.m = c->m;
+    a.coef = c->coef;
+    a.gm = c->gm_large;
+    a.partial = c->partial_large;
+    a.n = c->n;
+    a.j_split = c->slices_large;
+    a.fst = fst_of(step, c->cfg.dt);
+    a.G = c->cfg.G;
+    a.eps2 = c->cfg.eps * c->cfg.eps;
+    a.dt = c->cfg.dt;
+    return a;
+}
+
 int step_f64(nb_context* c, int first_step, int count) {
+    if (c->gm_large) {  // n >= F64_LARGE_MIN (or the config's override)
+        for (int s = 0; s < count; ++s) {
+            F64LargeArgs a = large_args(c, first_step + s);
+            NB_HIP(c, (hipError_t)launch_f64_large(a, c->stream));
+            c->cur ^= 1;
+        }
+        return NB_OK;
+    }
     for (int s = 0; s < count; ++s) {
         F64Args a = base_args(c, first_step + s);
         NB_HIP(c, (hipError_t)launch_f64(a, c->split, c->stream));
@@ -227,6 +257,13 @@ int nb_create(nb_context** out, const nb_config* cfg) {
         NB_HIP(c, hipMalloc(&c->mon, sizeof(F64Monitor)));
         NB_HIP(c, hipHostMalloc(&c->mon_host, sizeof(F64Monitor)));
         c->split = auto_split_f64(c->n, c->n_cus);
+        const int large_min = cfg->f64_large_min > 0 ? cfg->f64_large_min : F64_LARGE_MIN;
+        if (c->n >= large_min) {  // plain steps of a large fp64 system go through K1-f64
+            c->slices_large = plan_f64_large_slices(c->n, c->n_cus);
+            NB_HIP(c, hipMalloc(&c->gm_large, n * sizeof(double)));
+            if (c->slices_large > 1)
+                NB_HIP(c, hipMalloc(&c->partial_large, (size_t)c->slices_large * 3 * n * sizeof(double)));
+        }
     } else {
         NB_HIP(c, hipMalloc(&c->pos[0], n * sizeof(float4)));
         NB_HIP(c, hipMalloc(&c->pos[1], n * sizeof(float4)));
@@ -383,9 +420,15 @@ int nb_accel(nb_context* c, int step, double* ax, double* ay, double* az) {
     if (int rc = bind(c)) return rc;
     const size_t n = (size_t)c->n;
     if (c->cfg.precision == NB_F64) {
-        F64Args a = base_args(c, step);
-        a.acc_out = c->acc;
-        NB_HIP(c, (hipError_t)launch_f64(a, c->split, c->stream));
+        if (c->gm_large) {
+            F64LargeArgs a = large_args(c, step);
+            a.acc_out = c->acc;
+            NB_HIP(c, (hipError_t)launch_f64_large(a, c->stream));
+        } else {
+            F64Args a = base_args(c, step);
+            a.acc_out = c->acc;
+            NB_HIP(c, (hipError_t)launch_f64(a, c->split, c->stream));
+        }
         const size_t B = n * sizeof(double);
         NB_HIP(c, hipMemcpyAsync(ax, c->acc, B, hipMemcpyDeviceToHost, c->stream));
         NB_HIP(c, hipMemcpyAsync(ay, c->acc + n, B, hipMemcpyDeviceToHost, c->stream));

@@ -78,6 +78,25 @@ struct F64Args {
 int launch_f64(const F64Args& a, int S, hipStream_t stream);  // S = lanes sharing one target (1..64, pow2)
 int auto_split_f64(int n, int n_cus);
 
+// K1-f64: fp64 force + kick-drift for LARGE n (plain nb_step / nb_accel from F64_LARGE_MIN bodies up): sources broadcast
+// from SGPRs like the fp32 K1, R = 2 targets per lane, source slices over blockIdx.y with a reducer
+constexpr int F64_LARGE_MIN = 32768;  // measured crossover with K2 ~ 2e4 bodies (profiles/r01_f64_step_timing.txt)
+struct F64LargeArgs {
+    const double* q;    // [3][n] state after step-1
+    double* qout;       // [3][n]
+    double* v;          // [3][n] in place
+    const double* m;    // [n]
+    const double* coef; // [n]
+    double* gm;         // [n] scratch: G*m_eff of this step (written by the launch sequence itself)
+    double* acc_out;    // [3][n] accel-only, or nullptr
+    double* partial;    // [j_split][3][n] partial sums (j_split > 1)
+    int n;
+    int j_split;
+    double fst, G, eps2, dt;
+};
+int launch_f64_large(const F64LargeArgs& a, hipStream_t stream);
+int plan_f64_large_slices(int n, int n_cus);
+
 // K3: whole scenario of a small system (n <= SMALL_N_MAX) in ONE persistent single-workgroup launch
 constexpr int SMALL_N_MAX = 128;
 struct F64SmallArgs {

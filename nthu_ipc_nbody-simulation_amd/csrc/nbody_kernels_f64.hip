@@ -384,6 +384,151 @@ int launch_f64_small(const F64SmallArgs& a, hipStream_t stream) {
     return launch_small_s<S>(a, threads, stream);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// K1-f64 nbody_force_f64_large: the fp64 member of the large-N family (SURVEY §2.1 K1 "fp32, fp32+fp64-accumulate, fp64
+// variants").  K2 stages the whole system in every workgroup and shares a target between lanes — right for n <= 1024,
+// wasteful beyond.  Here, as in the fp32 K1: a lane owns R = 2 whole targets, the sources of a batch are wave-uniform
+// and arrive through scalar loads (s_load_dwordx8 from each SoA plane) as SGPR operands of the fp64 VALU ops, the
+// source range is sliced over blockIdx.y for enough workgroups, partial sums are combined by a reducer that also does
+// the non-contracted kick-drift.  Pair cost: 3 add + 3 fma + v_rsq_f64 + 5 (Halley) + 3 mul + 3 fma = 17 fp64 VALU
+// (4 cycles each) + 16 => ceiling 1024 SIMDs x 2.4 GHz x 64 / 84 = 1.87e12 pairs/s.
+__global__ __launch_bounds__(WG) void nbody_gm_f64(const double* __restrict__ m, const double* __restrict__ coef,
+                                                   double* __restrict__ gm, int n, double fst, double G) {
+    const int j = blockIdx.x * WG + threadIdx.x;
+    if (j < n) gm[j] = __dmul_rn(G, __dadd_rn(m[j], __dmul_rn(__dmul_rn(coef[j], m[j]), fst)));  // as K2 / nbody.cc:14-16,70
+}
+
+constexpr int F64L_R = 2;      // targets per lane
+constexpr int F64L_BATCH = 4;  // sources per scalar-load batch: 4 planes x 8 dwords = 32 SGPRs, two batches live
+
+template <bool SPLIT, bool ACCEL_ONLY, bool SELFCHECK>
+__global__ __launch_bounds__(WG, 4) void nbody_force_f64_large(F64LargeArgs a) {
+    constexpr int R = F64L_R, U = F64L_BATCH;
+    const int t = threadIdx.x, n = a.n;
+    const long base = (long)blockIdx.x * (WG * R);
+    const double* __restrict__ qx = a.q;
+    const double* __restrict__ qy = a.q + n;
+    const double* __restrict__ qz = a.q + 2 * (size_t)n;
+    const double* __restrict__ gm = a.gm;
+    int idx[R];
+    double xi[R], yi[R], zi[R], ax[R], ay[R], az[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        long i = base + (long)r * WG + t;
+        idx[r] = (int)(i < n ? i : n - 1);
+        xi[r] = qx[idx[r]]; yi[r] = qy[idx[r]]; zi[r] = qz[idx[r]];
+        ax[r] = ay[r] = az[r] = 0.0;
+    }
+    // slice of the sources for this blockIdx.y, in 256-source tiles
+    const int ntiles = (n + TILE - 1) / TILE;
+    const int per = (ntiles + (int)gridDim.y - 1) / (int)gridDim.y;
+    int j0 = (int)blockIdx.y * per * TILE, j1 = j0 + per * TILE;
+    if (j0 > n) j0 = n;
+    if (j1 > n) j1 = n;
+
+    auto interact = [&](double sx, double sy, double sz, double sg, int j) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            double dx = sx - xi[r], dy = sy - yi[r], dz = sz - zi[r];
+            double r2 = dx * dx + dy * dy + dz * dz + a.eps2;
+            double y = rsqrt_fast(r2);
+            double s = sg * y * y * y;
+            if (SELFCHECK) s = (j == idx[r]) ? 0.0 : s;  // only needed when eps == 0: otherwise the self pair is s*0 = 0
+            ax[r] += s * dx; ay[r] += s * dy; az[r] += s * dz;
+        }
+    };
+
+    const int jb = j0 + (j1 - j0) / U * U;
+    if (jb > j0) {
+        double cx[U], cy[U], cz[U], cg[U], nx[U], ny[U], nz[U], ng[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { cx[u] = qx[j0 + u]; cy[u] = qy[j0 + u]; cz[u] = qz[j0 + u]; cg[u] = gm[j0 + u]; }
+        for (int j = j0; j < jb; j += U) {
+            const int jn = (j + U < jb) ? j + U : j0;  // last prefetch wraps (harmless re-read)
+#pragma unroll
+            for (int u = 0; u < U; ++u) { nx[u] = qx[jn + u]; ny[u] = qy[jn + u]; nz[u] = qz[jn + u]; ng[u] = gm[jn + u]; }
+#pragma unroll
+            for (int u = 0; u < U; ++u) interact(cx[u], cy[u], cz[u], cg[u], j + u);
+#pragma unroll
+            for (int u = 0; u < U; ++u) { cx[u] = nx[u]; cy[u] = ny[u]; cz[u] = nz[u]; cg[u] = ng[u]; }
+        }
+    }
+    for (int j = jb; j < j1; ++j) interact(qx[j], qy[j], qz[j], gm[j], j);
+
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        long i = base + (long)r * WG + t;
+        if (i >= n) continue;
+        if (SPLIT) {
+            double* p = a.partial + (size_t)blockIdx.y * 3 * n;
+            p[i] = ax[r]; p[n + i] = ay[r]; p[2 * (size_t)n + i] = az[r];
+        } else if (ACCEL_ONLY) {
+            a.acc_out[i] = ax[r]; a.acc_out[n + i] = ay[r]; a.acc_out[2 * (size_t)n + i] = az[r];
+        } else {  // kick, drift (nbody.cc:76-88), non-contracted like K2
+            double vx = __dadd_rn(a.v[i], __dmul_rn(ax[r], a.dt));
+            double vy = __dadd_rn(a.v[n + i], __dmul_rn(ay[r], a.dt));
+            double vz = __dadd_rn(a.v[2 * (size_t)n + i], __dmul_rn(az[r], a.dt));
+            a.v[i] = vx; a.v[n + i] = vy; a.v[2 * (size_t)n + i] = vz;
+            a.qout[i] = __dadd_rn(xi[r], __dmul_rn(vx, a.dt));
+            a.qout[n + i] = __dadd_rn(yi[r], __dmul_rn(vy, a.dt));
+            a.qout[2 * (size_t)n + i] = __dadd_rn(zi[r], __dmul_rn(vz, a.dt));
+        }
+    }
+}
+
+template <bool ACCEL_ONLY>
+__global__ __launch_bounds__(WG) void nbody_reduce_update_f64(F64LargeArgs a, int js) {
+    const int i = blockIdx.x * WG + threadIdx.x, n = a.n;
+    if (i >= n) return;
+    double ax = 0, ay = 0, az = 0;
+    for (int s = 0; s < js; ++s) {
+        const double* p = a.partial + (size_t)s * 3 * n;
+        ax += p[i]; ay += p[n + i]; az += p[2 * (size_t)n + i];
+    }
+    if (ACCEL_ONLY) {
+        a.acc_out[i] = ax; a.acc_out[n + i] = ay; a.acc_out[2 * (size_t)n + i] = az;
+    } else {
+        double vx = __dadd_rn(a.v[i], __dmul_rn(ax, a.dt));
+        double vy = __dadd_rn(a.v[n + i], __dmul_rn(ay, a.dt));
+        double vz = __dadd_rn(a.v[2 * (size_t)n + i], __dmul_rn(az, a.dt));
+        a.v[i] = vx; a.v[n + i] = vy; a.v[2 * (size_t)n + i] = vz;
+        a.qout[i] = __dadd_rn(a.q[i], __dmul_rn(vx, a.dt));
+        a.qout[n + i] = __dadd_rn(a.q[n + i], __dmul_rn(vy, a.dt));
+        a.qout[2 * (size_t)n + i] = __dadd_rn(a.q[2 * (size_t)n + i], __dmul_rn(vz, a.dt));
+    }
+}
+
+// slices so that the grid has >= 8 workgroups per CU, each slice >= 8 tiles, at most 64
+int plan_f64_large_slices(int n, int n_cus) {
+    const long bx = (n + WG * F64L_R - 1) / (WG * F64L_R);
+    const long ntiles = (n + TILE - 1) / TILE;
+    long js = 1;
+    while (bx * js < 8L * n_cus && js < 64 && js * 2 * 8 <= ntiles) js <<= 1;
+    return (int)js;
+}
+
+template <bool ACCEL_ONLY, bool SELFCHECK>
+static int launch_large(const F64LargeArgs& a, hipStream_t stream) {
+    const int n = a.n, js = a.j_split;
+    const unsigned bx = (unsigned)((n + WG * F64L_R - 1) / (WG * F64L_R)), b1 = (unsigned)((n + WG - 1) / WG);
+    hipLaunchKernelGGL(nbody_gm_f64, dim3(b1), dim3(WG), 0, stream, a.m, a.coef, a.gm, n, a.fst, a.G);
+    if (js <= 1) {
+        hipLaunchKernelGGL((nbody_force_f64_large<false, ACCEL_ONLY, SELFCHECK>), dim3(bx), dim3(WG), 0, stream, a);
+        return (int)hipGetLastError();
+    }
+    if (!a.partial) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL((nbody_force_f64_large<true, ACCEL_ONLY, SELFCHECK>), dim3(bx, (unsigned)js), dim3(WG), 0, stream, a);
+    if (hipError_t e = hipGetLastError()) return (int)e;
+    hipLaunchKernelGGL((nbody_reduce_update_f64<ACCEL_ONLY>), dim3(b1), dim3(WG), 0, stream, a, js);
+    return (int)hipGetLastError();
+}
+
+int launch_f64_large(const F64LargeArgs& a, hipStream_t stream) {
+    const bool accel = a.acc_out != nullptr, selfcheck = !(a.eps2 > 0.0);
+    if (accel) return selfcheck ? launch_large<true, true>(a, stream) : launch_large<true, false>(a, stream);
+    return selfcheck ? launch_large<false, true>(a, stream) : launch_large<false, false>(a, stream);
+}
+
 template <int S>
 static int launch_s(const F64Args& a, hipStream_t stream) {
     constexpr int TPB = WG / S;

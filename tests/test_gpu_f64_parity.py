@@ -216,3 +216,35 @@ def test_persistent_engine_full_scenarios_b20(nb, oracle):
         q = np.zeros((3, 200)); q[0] = np.arange(200)
         big.set_state(q, q, np.ones(200))
         big.run_scenario(nb.capi.NB_SCN_MIN_DIST, 0, 1, last_step=10, engine=2)  # n > 128: refused
+
+
+@pytest.mark.parametrize("n,eps", [(2049, 1e-3), (5000, 1e-3), (3000, 0.0), (20000, 1e-3)])
+def test_large_n_fp64_kernel(nb, oracle, n, eps):
+    """Large systems in NB_F64 go through K1-f64 (SGPR-fed, sliced, reducer; by default from 32768 bodies, forced here
+    from 1024): accelerations and two steps vs the oracle, with `device` bodies (time-varying masses) present, ragged
+    n, and eps = 0 (explicit self-pair exclusion)."""
+    rng = np.random.default_rng(n)
+    s = oracle.System(n)
+    s.q[:] = rng.uniform(-1e12, 1e12, (3, n))
+    s.v[:] = rng.uniform(-1e4, 1e4, (3, n))
+    s.m[:] = rng.uniform(1e20, 1e26, n)
+    s.is_device[-7:] = 1
+    p = oracle.make_params(eps=eps)
+    step = 4321
+    me = oracle.effective_mass(step, s.m, s.is_device, 60.0)
+    rows = slice(0, n) if n <= 5000 else None
+    with _ctx(nb, s, eps=eps, f64_large_min=1024) as ctx:
+        a = ctx.accel(step)
+        ctx.step(step, 2)
+        q, v = ctx.get_state()
+    if rows is not None:
+        ref = oracle.accel_rows(s.q, me, 6.674e-11, eps)
+        assert np.all(np.abs(a - ref) <= 1e-12 * np.abs(ref).max())
+        r = s.copy()
+        oracle.run_steps(r, step, 2, params=p, omp=True)
+        assert _close(q, r.q, 1e-12) and _close(v, r.v, 1e-12)
+    else:  # 20 000 bodies: spot rows only (4e8 pairs per full oracle pass)
+        for i0 in (0, n // 2, n - 64):
+            ref = oracle.accel_rows(s.q, me, 6.674e-11, eps, i0, i0 + 64)
+            assert np.all(np.abs(a[:, i0:i0 + 64] - ref) <= 1e-12 * np.abs(ref).max())
+        assert np.isfinite(q).all() and np.isfinite(v).all()
