@@ -498,7 +498,7 @@ int nb_run_scenario(nb_context* c, const nb_scenario* s, nb_scenario_result* res
     const bool small_engine = (s->engine == 2) || (s->engine == 0 && c->n <= SMALL_N_MAX);
     if (small_engine) {
         // K3: the whole step loop inside one single-workgroup kernel, in chunks so the host can stop after a hit
-        const int need = s->last_step + 2;
+        const int need = s->last_step + 3;  // the kernel prefetches |sin| two steps ahead
         if (c->fst_len < need) {
             free_dev(c->fst_dev);
             std::vector<double> tab((size_t)need);

@@ -104,7 +104,7 @@ struct F64SmallArgs {
     double* v;           // [3][n] in/out
     const double* m;     // [n]
     const double* coef;  // [n]
-    const double* fst;   // [>= last_step + 2] |sin(step*dt/6000)| by step index, host-computed (glibc)
+    const double* fst;   // [>= last_step + 3] |sin(step*dt/6000)| by step index, host-computed (glibc)
     double* snap_q;      // [n_watch][3][n] or nullptr
     double* snap_v;
     F64Monitor* mon;     // in/out (carries min_d2 / hit / arrivals across launches)

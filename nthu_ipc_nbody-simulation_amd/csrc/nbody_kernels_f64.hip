@@ -317,9 +317,12 @@ __global__ __launch_bounds__(SMALL_N_MAX * S) void nbody_scenario_small_f64(F64S
     int cur = 0;
     int step = a.first_step + 1;
     bool stopped = false;
+    // |sin| of the step after next is requested two iterations before it is needed: a global (L2) load takes about
+    // as long as one whole iteration of this loop, so a one-deep prefetch would still stall the owners' update
+    double fst_next = owner ? a.fst[step + 1] : 0.0;
     for (; step <= a.last_step; ++step) {
         if (monitor(cur, step - 1)) { stopped = true; break; }
-        const double fst_next = owner ? a.fst[step + 1] : 0.0;  // in flight during the pair loop
+        const double fst_after = owner ? a.fst[step + 2] : 0.0;
         const double xi = sq[cur][0][ic], yi = sq[cur][1][ic], zi = sq[cur][2][ic];
         double ax = 0, ay = 0, az = 0;
 #pragma unroll 2
@@ -352,6 +355,7 @@ __global__ __launch_bounds__(SMALL_N_MAX * S) void nbody_scenario_small_f64(F64S
         }
         __syncthreads();  // the only barrier of the step: buffer cur^1 complete, buffer cur free for step+1's writes
         cur ^= 1;
+        fst_next = fst_after;
     }
     int done = stopped ? step - 1 : a.last_step;
     if (!stopped && a.final_monitor) (void)monitor(cur, a.last_step);
