@@ -1,4 +1,4 @@
-"""Rehearsal of the sharded path with the REAL kernel: 2 ranks share the one GPU of the box and exchange through
+"""Rehearsal of the sharded path with the REAL kernel: 2 and 4 ranks share the one GPU of the box and exchange through
 gloo (RCCL refuses two ranks on one device; the 8-GPU RCCL run is the driver's).  Checks tgt_off != 0 launches,
 the ping-pong and the in-place exchange against the unsharded run."""
 import os
@@ -45,13 +45,14 @@ def _run(rank, world, port, path):
         dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_match_single(nb, tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_on_one_gpu_match_single(nb, tmp_path, world):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
     mp.spawn(_run, args=(1, 0, one), nprocs=1, join=True)
-    mp.spawn(_run, args=(2, port, two), nprocs=2, join=True)
+    mp.spawn(_run, args=(world, port, two), nprocs=world, join=True)
     a, b = np.load(one), np.load(two)
     # the sharded launch may pick another register blocking / source split: equal to fp32 rounding, not bitwise
     assert np.abs(a["pos"] - b["pos"]).max() < 5e-7 and np.abs(a["vel"] - b["vel"]).max() < 1e-5
