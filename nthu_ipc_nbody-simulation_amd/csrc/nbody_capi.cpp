@@ -734,12 +734,35 @@ int nb_solve(int n, int planet, int asteroid, const double* qx, const double* qy
             rc1 = nb_run_scenario(c1, &s, &r1);
         }
     });
+    // Small systems (the persistent single-workgroup engine: one CU per scenario) also start every Problem-3 run NOW,
+    // from step 0, next to P1 and P2: until its missile arrives a device's run IS the P2 trajectory (the literal
+    // definition of hw5.cu:289-309 applied to every step), so nothing depends on P2's snapshots and the critical path
+    // of the whole program is one 200 000-step scenario.  Larger systems would only compete for CUs: they wait for
+    // P2 and resume from its arrival snapshots below (hw5.cu:265-287,482-489).
+    const size_t D = dev_idx.size();
+    // ... as long as every scenario gets a hardware queue of its own (HIP multiplexes streams onto 4 by default; with
+    // more, the long persistent launches queue behind each other — measured on b80/b90, 4 devices: slower than waiting)
+    const bool speculative_p3 = n <= SMALL_N_MAX && D > 0 && D + 2 <= 4;
+    std::vector<nb_context*> cs(D, nullptr);
+    std::vector<int> rcs(D, NB_OK);
+    std::vector<nb_scenario_result> rs(D);
+    std::vector<std::thread> ts;
+    if (speculative_p3)
+        for (size_t k = 0; k < D; ++k)
+            ts.emplace_back([&, k] {
+                rcs[k] = make_ctx(gpus[k % gpus.size()], &cs[k]);
+                if (rcs[k]) return;
+                nb_scenario s = base_scn(NB_SCN_MISSILE);
+                s.n_watch = 1;
+                s.watch[0] = dev_idx[k];
+                rcs[k] = nb_run_scenario(cs[k], &s, &rs[k]);
+            });
     {
         rc2 = make_ctx(gpus[gpus.size() > 1 ? 1 : 0], &c2);
         if (!rc2) {
             nb_scenario s = base_scn(NB_SCN_FIRST_HIT);
-            s.n_watch = (int)dev_idx.size();
-            for (size_t k = 0; k < dev_idx.size(); ++k) s.watch[k] = dev_idx[k];
+            s.n_watch = (int)D;
+            for (size_t k = 0; k < D; ++k) s.watch[k] = dev_idx[k];
             rc2 = nb_run_scenario(c2, &s, &r2);
         }
     }
@@ -750,12 +773,7 @@ int nb_solve(int n, int planet, int asteroid, const double* qx, const double* qy
     out->gravity_device_id = -1;
     out->missile_cost = 0;
     int rc3 = NB_OK;
-    if (!rc2 && r2.hit_step != -2) {
-        const size_t D = dev_idx.size();
-        std::vector<nb_context*> cs(D, nullptr);
-        std::vector<int> rcs(D, NB_OK);
-        std::vector<nb_scenario_result> rs(D);
-        std::vector<std::thread> ts;
+    if (!rc2 && r2.hit_step != -2 && !speculative_p3) {
         for (size_t k = 0; k < D; ++k) {
             if (r2.arrival_step[k] == -2) continue;
             // restore on this thread (reads c2), simulate on a worker
@@ -774,19 +792,22 @@ int nb_solve(int n, int planet, int asteroid, const double* qx, const double* qy
                 rcs[k] = nb_run_scenario(cs[k], &s, &rs[k]);
             });
         }
-        for (auto& t : ts) t.join();
+    }
+    for (auto& t : ts) t.join();
+    if (!rc2 && r2.hit_step != -2) {
         double best = std::numeric_limits<double>::infinity();
         for (size_t k = 0; k < D; ++k) {
             if (rcs[k]) rc3 = rcs[k];
-            if (r2.arrival_step[k] != -2 && !rcs[k] && rs[k].hit_step == -2 && rs[k].arrival_step[0] != -2 &&
-                rs[k].missile_cost[0] < best) {
+            // feasible: the missile arrived (before the P2 hit, hence before any hit of this run) and no hit followed
+            if (cs[k] && !rcs[k] && rs[k].hit_step == -2 && rs[k].arrival_step[0] != -2 && rs[k].missile_cost[0] < best) {
                 best = rs[k].missile_cost[0];
                 out->gravity_device_id = dev_idx[k];
                 out->missile_cost = best;
             }
-            if (cs[k]) nb_destroy(cs[k]);
         }
     }
+    for (size_t k = 0; k < D; ++k)
+        if (cs[k]) nb_destroy(cs[k]);
     t1.join();
     out->min_dist = std::sqrt(r1.min_dist2);  // nbody.cc:121 takes min of sqrt; sqrt is monotone
     if (c1) nb_destroy(c1);
