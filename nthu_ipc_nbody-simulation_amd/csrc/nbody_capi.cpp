@@ -742,7 +742,7 @@ int nb_solve(int n, int planet, int asteroid, const double* qx, const double* qy
     const size_t D = dev_idx.size();
     // ... as long as every scenario gets a hardware queue of its own (HIP multiplexes streams onto 4 by default; with
     // more, the long persistent launches queue behind each other — measured on b80/b90, 4 devices: slower than waiting)
-    const bool speculative_p3 = n <= SMALL_N_MAX && D > 0 && D + 2 <= 4;
+    const bool speculative_p3 = n <= SMALL_N_MAX && D > 0 && D + 2 <= 4 * gpus.size();
     std::vector<nb_context*> cs(D, nullptr);
     std::vector<int> rcs(D, NB_OK);
     std::vector<nb_scenario_result> rs(D);
