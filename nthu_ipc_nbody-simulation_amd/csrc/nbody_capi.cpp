@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -742,7 +743,9 @@ int nb_solve(int n, int planet, int asteroid, const double* qx, const double* qy
     const size_t D = dev_idx.size();
     // ... as long as every scenario gets a hardware queue of its own (HIP multiplexes streams onto 4 by default; with
     // more, the long persistent launches queue behind each other — measured on b80/b90, 4 devices: slower than waiting)
-    const bool speculative_p3 = n <= SMALL_N_MAX && D > 0 && D + 2 <= 4 * gpus.size();
+    int hw_queues = 4;  // ROCclr's default number of hardware queues per device; GPU_MAX_HW_QUEUES overrides it
+    if (const char* e = getenv("GPU_MAX_HW_QUEUES")) hw_queues = std::max(1, atoi(e));
+    const bool speculative_p3 = n <= SMALL_N_MAX && D > 0 && D + 2 <= (size_t)hw_queues * gpus.size();
     std::vector<nb_context*> cs(D, nullptr);
     std::vector<int> rcs(D, NB_OK);
     std::vector<nb_scenario_result> rs(D);
