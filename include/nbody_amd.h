@@ -121,6 +121,11 @@ int nb_step_timed(nb_context* ctx, int first_step, int count, float* ms_per_step
  * After a scenario that ends in a hit the context's (q,v) are unspecified — the reference discards that state too
  * (nbody.cc:136 breaks out of the loop); reload with nb_set_state / nb_restore_snapshot / nb_load_state. */
 int nb_run_scenario(nb_context* ctx, const nb_scenario* scn, nb_scenario_result* res);
+/* `count` (<= 8) scenarios of equally sized NB_F64 systems on ONE GPU in lock step: one launch per step serves all of
+ * them, each with its own context (state), step range and monitors — hw5.cu's one-thread-per-device Problem-3 loop
+ * (hw5.cu:587-588) without one launch stream per device.  MIN_DIST and MISSILE scenarios (and FIRST_HIT without
+ * watched devices); results[k] as nb_run_scenario would give for (ctxs[k], scns[k]). */
+int nb_run_scenarios_batched(nb_context** ctxs, const nb_scenario* scns, nb_scenario_result* results, int count);
 /* load the (q,v) snapshot that the last FIRST_HIT scenario on `src` took at watched device `watch_slot`'s
  * missile arrival into `dst` (same n, precision F64, same GPU or not); hw5.cu:482-484 */
 int nb_restore_snapshot(nb_context* dst, nb_context* src, int watch_slot);

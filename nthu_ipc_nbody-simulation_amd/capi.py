@@ -62,6 +62,8 @@ SYMBOLS = {
     "nb_accel": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp]),
     "nb_step_timed": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "nb_run_scenario": (C.c_int, [C.c_void_p, C.POINTER(NbScenario), C.POINTER(NbScenarioResult)]),
+    "nb_run_scenarios_batched": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(NbScenario), C.POINTER(NbScenarioResult),
+                                          C.c_int]),
     "nb_restore_snapshot": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "nb_save_state": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "nb_load_state": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]),
@@ -253,6 +255,30 @@ class Context:
 
     def restore_snapshot_from(self, src, slot):
         _check(lib().nb_restore_snapshot(self._h, src._h, slot), "nb_restore_snapshot", self._h)
+
+
+def _scenario_struct(kind, planet, asteroid, first_step=0, last_step=200000, watch=(), sync_every=2000,
+                     planet_radius=1e7, missile_speed=1e6, engine=0):
+    s = NbScenario()
+    s.kind, s.first_step, s.last_step, s.planet, s.asteroid = kind, first_step, last_step, planet, asteroid
+    s.n_watch = len(watch)
+    for k, w in enumerate(watch):
+        s.watch[k] = w
+    s.sync_every, s.planet_radius, s.missile_speed, s.engine = sync_every, planet_radius, missile_speed, engine
+    return s
+
+
+def run_scenarios_batched(contexts, scenarios):
+    """contexts: list of Context (same n, same GPU); scenarios: list of dicts with run_scenario's keyword arguments.
+    One launch per step serves all of them.  -> list of result dicts."""
+    n = len(contexts)
+    hs = (C.c_void_p * n)(*[c._h for c in contexts])
+    ss = (NbScenario * n)(*[_scenario_struct(**kw) for kw in scenarios])
+    rs = (NbScenarioResult * n)()
+    _check(lib().nb_run_scenarios_batched(hs, ss, rs, n), "nb_run_scenarios_batched", contexts[0]._h)
+    return [dict(min_dist2=r.min_dist2, hit_step=r.hit_step, steps_done=r.steps_done,
+                 arrival_step=list(r.arrival_step[:len(kw.get("watch", ()))]),
+                 missile_cost=list(r.missile_cost[:len(kw.get("watch", ()))])) for r, kw in zip(rs, scenarios)]
 
 
 def state_file_info(path):

@@ -597,6 +597,105 @@ int nb_run_scenario(nb_context* c, const nb_scenario* s, nb_scenario_result* res
     return NB_OK;
 }
 
+// Several scenarios of equally sized systems in lock step: ONE launch per step serves all of them (blockIdx.y), each
+// with its own state, step index, |sin| and monitor.  What hw5.cu does with one host thread + launch stream per
+// device (hw5.cu:587-588), without the streams contending for the command processor.
+int nb_run_scenarios_batched(nb_context** ctxs, const nb_scenario* scns, nb_scenario_result* results, int count) {
+    if (!ctxs || !scns || !results || count <= 0 || count > MAX_BATCH) return NB_ERR_INVALID;
+    nb_context* c0 = ctxs[0];
+    for (int b = 0; b < count; ++b) {
+        nb_context* c = ctxs[b];
+        const nb_scenario* s = &scns[b];
+        if (!c || c->cfg.precision != NB_F64 || c->n != c0->n || c->cfg.device != c0->cfg.device) return NB_ERR_INVALID;
+        if (!c->have_state) return NB_ERR_STATE;
+        if (s->kind < NB_SCN_MIN_DIST || s->kind > NB_SCN_MISSILE || s->n_watch < 0 || s->n_watch > NB_MAX_WATCH)
+            return NB_ERR_INVALID;
+        if (s->planet < 0 || s->planet >= c->n || s->asteroid < 0 || s->asteroid >= c->n || s->last_step < s->first_step)
+            return NB_ERR_INVALID;
+        if (s->kind == NB_SCN_FIRST_HIT && s->n_watch > 0) return NB_ERR_INVALID;  // snapshots: use nb_run_scenario
+        for (int k = 0; k < s->n_watch; ++k)
+            if (s->watch[k] < 0 || s->watch[k] >= c->n) return NB_ERR_INVALID;
+        for (int b2 = 0; b2 < b; ++b2)
+            if (ctxs[b2] == c) return NB_ERR_INVALID;
+    }
+    if (int rc = bind(c0)) return rc;
+    hipStream_t stream = c0->stream;
+
+    F64Scenario sc[MAX_BATCH];
+    int done_at[MAX_BATCH];  // -1 while running; else the index of the last state computed
+    for (int b = 0; b < count; ++b) {
+        nb_context* c = ctxs[b];
+        const nb_scenario* s = &scns[b];
+        sc[b] = F64Scenario{};
+        sc[b].kind = s->kind;
+        sc[b].planet = s->planet;
+        sc[b].asteroid = s->asteroid;
+        sc[b].n_watch = (s->kind == NB_SCN_MIN_DIST) ? 0 : s->n_watch;
+        for (int k = 0; k < sc[b].n_watch; ++k) sc[b].watch[k] = s->watch[k];
+        sc[b].destroy_on_arrival = (s->kind == NB_SCN_MISSILE);
+        sc[b].R2 = s->planet_radius * s->planet_radius;
+        sc[b].missile_dstep = s->missile_speed * c->cfg.dt;
+        done_at[b] = -1;
+        F64Monitor* mh = c->mon_host;
+        mh->min_d2 = std::numeric_limits<double>::infinity();
+        mh->hit_step = -2;
+        for (int k = 0; k < MAX_WATCH; ++k) mh->arrival_step[k] = -2;
+        NB_HIP(c0, hipStreamSynchronize(c->stream));  // earlier work of this context (uploads) is complete
+        NB_HIP(c0, hipMemcpyAsync(c->mon, mh, sizeof(F64Monitor), hipMemcpyHostToDevice, stream));
+    }
+    NB_HIP(c0, hipStreamSynchronize(stream));
+
+    const int sync_every = scns[0].sync_every > 0 ? scns[0].sync_every : 2000;
+    int running = count;
+    for (int t = 1; running > 0; ++t) {  // t-th step of every scenario still running
+        F64BatchArgs args{};
+        args.count = count;
+        for (int b = 0; b < count; ++b) {
+            if (done_at[b] >= 0) continue;  // idle slot: item[b].n stays 0
+            nb_context* c = ctxs[b];
+            const int step = scns[b].first_step + t;
+            F64Args a = base_args(c, step);
+            a.scn = sc[b];
+            if (step > scns[b].last_step) {  // the state last_step exists: only its monitor is left
+                a.do_update = 0;
+                done_at[b] = scns[b].last_step;
+                --running;
+            }
+            args.item[b] = a;
+            if (a.do_update) c->cur ^= 1;
+        }
+        NB_HIP(c0, (hipError_t)launch_f64_batched(args, c0->n, c0->split, stream));
+        if (t % sync_every == sync_every - 1) {  // poll the hit flags (hw5.cu:398-402,503-507)
+            for (int b = 0; b < count; ++b)
+                if (done_at[b] < 0 && scns[b].kind != NB_SCN_MIN_DIST)
+                    NB_HIP(c0, hipMemcpyAsync(&ctxs[b]->mon_host->hit_step, &ctxs[b]->mon->hit_step, sizeof(int),
+                                              hipMemcpyDeviceToHost, stream));
+            NB_HIP(c0, hipStreamSynchronize(stream));
+            for (int b = 0; b < count; ++b)
+                if (done_at[b] < 0 && scns[b].kind != NB_SCN_MIN_DIST && ctxs[b]->mon_host->hit_step != -2) {
+                    done_at[b] = scns[b].first_step + t;
+                    --running;
+                }
+        }
+    }
+    for (int b = 0; b < count; ++b)
+        NB_HIP(c0, hipMemcpyAsync(ctxs[b]->mon_host, ctxs[b]->mon, sizeof(F64Monitor), hipMemcpyDeviceToHost, stream));
+    NB_HIP(c0, hipStreamSynchronize(stream));
+    for (int b = 0; b < count; ++b) {
+        nb_context* c = ctxs[b];
+        nb_scenario_result* res = &results[b];
+        memset(res, 0, sizeof *res);
+        res->min_dist2 = c->mon_host->min_d2;
+        res->hit_step = c->mon_host->hit_step;
+        res->steps_done = done_at[b];
+        for (int k = 0; k < NB_MAX_WATCH; ++k) {
+            res->arrival_step[k] = (k < sc[b].n_watch) ? c->mon_host->arrival_step[k] : -2;
+            res->missile_cost[k] = (res->arrival_step[k] != -2) ? 1e5 + 1e3 * ((res->arrival_step[k] + 1) * c->cfg.dt) : 0.0;
+        }
+    }
+    return NB_OK;
+}
+
 int nb_restore_snapshot(nb_context* dst, nb_context* src, int slot) {
     if (!dst || !src || slot < 0 || slot >= src->snap_slots) return NB_ERR_INVALID;
     if (dst->n != src->n || dst->cfg.precision != NB_F64 || src->cfg.precision != NB_F64) return NB_ERR_INVALID;
@@ -777,23 +876,38 @@ int nb_solve(int n, int planet, int asteroid, const double* qx, const double* qy
     out->missile_cost = 0;
     int rc3 = NB_OK;
     if (!rc2 && r2.hit_step != -2 && !speculative_p3) {
+        std::vector<size_t> todo;
         for (size_t k = 0; k < D; ++k) {
             if (r2.arrival_step[k] == -2) continue;
-            // restore on this thread (reads c2), simulate on a worker
             nb_config cfg;
             nb_config_default(&cfg);
             cfg.n = n;
-            cfg.device = gpus[k % gpus.size()];
+            cfg.device = gpus.size() > 1 ? gpus[k % gpus.size()] : gpus[0];
             rcs[k] = nb_create(&cs[k], &cfg);
             if (!rcs[k]) rcs[k] = nb_restore_snapshot(cs[k], c2, (int)k);
-            if (rcs[k]) continue;
-            ts.emplace_back([&, k] {
-                nb_scenario s = base_scn(NB_SCN_MISSILE);
-                s.first_step = r2.arrival_step[k];
-                s.n_watch = 1;
-                s.watch[0] = dev_idx[k];
-                rcs[k] = nb_run_scenario(cs[k], &s, &rs[k]);
-            });
+            if (!rcs[k]) todo.push_back(k);
+        }
+        auto missile_scn = [&](size_t k) {
+            nb_scenario s = base_scn(NB_SCN_MISSILE);
+            s.first_step = r2.arrival_step[k];
+            s.n_watch = 1;
+            s.watch[0] = dev_idx[k];
+            return s;
+        };
+        if (gpus.size() == 1 && n > SMALL_N_MAX && todo.size() >= 2 && todo.size() <= (size_t)MAX_BATCH) {
+            // one GPU, per-step launches: all devices in ONE launch per step instead of one launch stream each
+            std::vector<nb_context*> bc;
+            std::vector<nb_scenario> bs;
+            for (size_t k : todo) { bc.push_back(cs[k]); bs.push_back(missile_scn(k)); }
+            std::vector<nb_scenario_result> br(todo.size());
+            int rcb = nb_run_scenarios_batched(bc.data(), bs.data(), br.data(), (int)todo.size());
+            for (size_t j = 0; j < todo.size(); ++j) { rcs[todo[j]] = rcb; rs[todo[j]] = br[j]; }
+        } else {
+            for (size_t k : todo)
+                ts.emplace_back([&, k] {
+                    nb_scenario s = missile_scn(k);
+                    rcs[k] = nb_run_scenario(cs[k], &s, &rs[k]);
+                });
         }
     }
     for (auto& t : ts) t.join();

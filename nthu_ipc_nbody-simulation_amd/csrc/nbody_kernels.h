@@ -76,6 +76,12 @@ struct F64Args {
     F64Scenario scn;
 };
 int launch_f64(const F64Args& a, int S, hipStream_t stream);  // S = lanes sharing one target (1..64, pow2)
+constexpr int MAX_BATCH = 8;
+struct F64BatchArgs {  // up to MAX_BATCH independent systems of the same n, one step each per launch (blockIdx.y)
+    F64Args item[MAX_BATCH];  // item[k].n == 0 marks an idle slot
+    int count;
+};
+int launch_f64_batched(const F64BatchArgs& b, int n, int S, hipStream_t stream);
 int auto_split_f64(int n, int n_cus);
 
 // K1-f64: fp64 force + kick-drift for LARGE n (plain nb_step / nb_accel from F64_LARGE_MIN bodies up): sources broadcast

@@ -63,7 +63,7 @@ __device__ __forceinline__ double dist2_bodies(const double* q, int n, int i, in
 constexpr int K2_TILE = 1024;  // sources staged per pass: 4 per thread, 32 KB of LDS; n <= 1024 needs ONE pass
 
 template <int S>
-__global__ __launch_bounds__(WG) void nbody_step_f64(F64Args a) {
+__device__ __forceinline__ void step_f64_body(const F64Args& a) {
     __shared__ double sx[K2_TILE], sy[K2_TILE], sz[K2_TILE], sg[K2_TILE];
     __shared__ int sh_skip;
     __shared__ unsigned sh_destroyed;  // bit k: watched device k has mass 0 for this step
@@ -230,6 +230,21 @@ __global__ __launch_bounds__(WG) void nbody_step_f64(F64Args a) {
             a.qout[2 * n + i] = __dadd_rn(zi, __dmul_rn(vz, a.dt));
         }
     }
+}
+
+template <int S>
+__global__ __launch_bounds__(WG) void nbody_step_f64(F64Args a) {
+    step_f64_body<S>(a);
+}
+
+// One launch advances up to MAX_BATCH independent systems of the same n by one step each (blockIdx.y = system): the
+// scenarios hw5 runs side by side (P3 per device: hw5.cu:587-588) then share ONE launch per step instead of contending
+// for the command processor with one launch stream each.  Every system carries its own step index, |sin| and monitor.
+template <int S>
+__global__ __launch_bounds__(WG) void nbody_step_f64_batched(F64BatchArgs b) {
+    const F64Args& a = b.item[blockIdx.y];
+    if (a.n <= 0) return;  // finished / not started: nothing to do for this slot
+    step_f64_body<S>(a);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -540,6 +555,27 @@ static int launch_s(const F64Args& a, hipStream_t stream) {
     int blocks = (a.do_update || a.snap_q) ? (a.n + TPB - 1) / TPB : 1;
     hipLaunchKernelGGL((nbody_step_f64<S>), dim3(blocks), dim3(WG), 0, stream, a);
     return (int)hipGetLastError();
+}
+
+template <int S>
+static int launch_batched_s(const F64BatchArgs& b, int n, hipStream_t stream) {
+    constexpr int TPB = WG / S;
+    hipLaunchKernelGGL((nbody_step_f64_batched<S>), dim3((n + TPB - 1) / TPB, b.count), dim3(WG), 0, stream, b);
+    return (int)hipGetLastError();
+}
+
+int launch_f64_batched(const F64BatchArgs& b, int n, int S, hipStream_t stream) {
+    if (b.count <= 0 || b.count > MAX_BATCH) return (int)hipErrorInvalidValue;
+    switch (S) {
+        case 1: return launch_batched_s<1>(b, n, stream);
+        case 2: return launch_batched_s<2>(b, n, stream);
+        case 4: return launch_batched_s<4>(b, n, stream);
+        case 8: return launch_batched_s<8>(b, n, stream);
+        case 16: return launch_batched_s<16>(b, n, stream);
+        case 32: return launch_batched_s<32>(b, n, stream);
+        case 64: return launch_batched_s<64>(b, n, stream);
+    }
+    return (int)hipErrorInvalidValue;
 }
 
 int launch_f64(const F64Args& a, int S, hipStream_t stream) {

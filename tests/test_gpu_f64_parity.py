@@ -248,3 +248,44 @@ def test_large_n_fp64_kernel(nb, oracle, n, eps):
             ref = oracle.accel_rows(s.q, me, 6.674e-11, eps, i0, i0 + 64)
             assert np.all(np.abs(a[:, i0:i0 + 64] - ref) <= 1e-12 * np.abs(ref).max())
         assert np.isfinite(q).all() and np.isfinite(v).all()
+
+
+def test_batched_scenarios_equal_individual_runs(nb, oracle):
+    """nb_run_scenarios_batched (one launch per step for several systems) vs one nb_run_scenario each: b200's three
+    Problem-3 runs from their arrival snapshots plus a Problem-1 run with its own step range — identical results and
+    bitwise identical final states (same kernel body, same arithmetic)."""
+    s = oracle.read_input(case_path("b200", "in"))
+    devs = [int(i) for i in np.flatnonzero(s.is_device)]
+    c = nb.capi
+    with _ctx(nb, s) as p2:
+        r2 = p2.run_scenario(c.NB_SCN_FIRST_HIT, s.planet, s.asteroid, watch=devs, engine=1)
+        assert r2["hit_step"] == 102281 and r2["arrival_step"][0] == 19248        # SURVEY §4 / Appendix B-4
+        arrived = [(a, d, k) for k, (a, d) in enumerate(zip(r2["arrival_step"], devs)) if a >= 0]
+        assert len(arrived) >= 2
+        last = max(a for a, _, _ in arrived) + 4000   # well before the hit: no scenario stops early
+        kws = [dict(kind=c.NB_SCN_MISSILE, planet=s.planet, asteroid=s.asteroid, first_step=a, last_step=last, watch=[d])
+               for a, d, _ in arrived]
+        kws.append(dict(kind=c.NB_SCN_MIN_DIST, planet=s.planet, asteroid=s.asteroid, first_step=0, last_step=5000))
+        single, batched = [], []
+        for mode in ("single", "batched"):
+            ctxs = []
+            for _, _, k in arrived:
+                x = c.Context(s.n)
+                x.restore_snapshot_from(p2, k)
+                ctxs.append(x)
+            x = c.Context(s.n)
+            x.set_state(s.q, s.v, s.m, s.is_device)
+            ctxs.append(x)
+            if mode == "single":
+                res = [x.run_scenario(engine=1, **kw) for x, kw in zip(ctxs, kws)]
+            else:
+                res = c.run_scenarios_batched(ctxs, kws)
+            states = [x.get_state() for x in ctxs]
+            for x in ctxs:
+                x.close()
+            (single if mode == "single" else batched).extend(zip(res, states))
+    for (ra, (qa, va)), (rb, (qb, vb)) in zip(single, batched):
+        assert ra == rb, (ra, rb)
+        assert np.array_equal(qa, qb) and np.array_equal(va, vb)
+    assert [r["steps_done"] for r, _ in batched] == [last] * len(arrived) + [5000]
+    assert all(r["hit_step"] == -2 and r["arrival_step"][0] == a for (r, _), (a, _, _) in zip(batched, arrived))
