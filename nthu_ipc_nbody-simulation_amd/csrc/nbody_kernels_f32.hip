@@ -361,7 +361,7 @@ F32Plan plan_f32(long n_tgt, long n_src, int n_cus, int force_tpl, int force_js,
     if (!p.sgpr_sources) wg = 256;
     if (wg != 256 && wg != 512 && wg != 1024) wg = 0;
     if (R != 2 && R != 4 && R != 8) R = 0;
-    const bool many = p.sgpr_sources && n_tgt >= 4096L * 8;  // enough targets for 4096-target workgroups at all
+    const bool many = p.sgpr_sources && n_tgt >= 4096L * 32;  // enough targets for 4096-target workgroups (N = 32768: 512x8 2.1e12, 256x4 3.9e12 pairs/s)
     if (wg == 0 && R == 0) {
         if (many && have_workspace) { wg = 512; R = 8; }
         else if (many && n_tgt >= 4096L * n_cus) { wg = 1024; R = 4; }
@@ -386,6 +386,10 @@ F32Plan plan_f32(long n_tgt, long n_src, int n_cus, int force_tpl, int force_js,
             // for 256-thread ones — N = 2^18: 4 slices 55.3 %, 16 slices 58.2 %; N = 2^20: 2 -> 57.4 %, 8 -> 58.7 %
             const long want = 8 * (wg >= 512 ? 1L : 2L) * n_cus;
             while (bx * js < want && js < MAX_JSPLIT && js * 2 * 8 <= ntiles) js <<= 1;  // keep >= 8 tiles per slice
+            // small systems (a few thousand bodies: too few workgroups either way): 16 slices of >= 2 tiles measured
+            // best — N = 8192: 0.158 -> 0.048 ms/step, N = 16384: 0.161 -> 0.086 ms/step (r01_jsplit_search.txt)
+            if (n_tgt < 4096L * 32)
+                while (js < 16 && js * 2 * 2 <= ntiles) js <<= 1;
         }
     }
     if (js > MAX_JSPLIT) js = MAX_JSPLIT;
