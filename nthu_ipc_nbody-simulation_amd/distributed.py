@@ -79,6 +79,7 @@ class ShardedSystem:
             self.pos64 = pos_shard.to(device=device, dtype=torch.float64).contiguous()
             self.vel64 = vel_shard.to(device=device, dtype=torch.float64).contiguous()
         self.cur = 0
+        self._inplace_ok = True
         self.pos[0][self.lo:self.hi] = pos_shard.to(device=device, dtype=torch.float32)
         self._exchange(self.pos[0])
         self.pos[1].copy_(self.pos[0])  # G*m column of the other buffer for slots this rank never writes
@@ -88,8 +89,14 @@ class ShardedSystem:
         if self.world == 1:
             return
         if dist.get_backend(self.group) == "nccl":
-            # RCCL: in place, send buffer = this rank's slot of the receive buffer
-            dist.all_gather_into_tensor(buf, buf[self.lo:self.hi], group=self.group)
+            # RCCL: in place, send buffer = this rank's slot of the receive buffer (ncclAllGather's in-place form)
+            if self._inplace_ok:
+                try:
+                    dist.all_gather_into_tensor(buf, buf[self.lo:self.hi], group=self.group)
+                    return
+                except (RuntimeError, ValueError):  # a torch build that refuses aliased buffers: stage the shard once
+                    self._inplace_ok = False
+            dist.all_gather_into_tensor(buf, buf[self.lo:self.hi].clone(), group=self.group)
         else:
             # gloo (CPU tests / single-GPU rehearsal): same exchange through the list form
             per = self.n_tgt
