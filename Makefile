@@ -13,23 +13,28 @@ LIB      := $(PKG)/libnbody_amd.so
 KSRC := $(SRC)/nbody_kernels_f32.hip $(SRC)/nbody_kernels_f64.hip
 HDR  := $(SRC)/nbody_kernels.h include/nbody_amd.h
 
-.PHONY: all lib hw5 nbody_bench oracle ubench asan clean
-all: lib hw5 nbody_bench
+.PHONY: all lib hw5 nbody_bench nbconv oracle ubench asan clean
+all: lib hw5 nbody_bench nbconv
 
 lib: $(LIB)
-$(LIB): $(KSRC) $(SRC)/nbody_capi.cpp $(HDR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(KSRC) -x hip $(SRC)/nbody_capi.cpp -lpthread
+$(LIB): $(KSRC) $(SRC)/nbody_capi.cpp $(SRC)/nbody_sharded.cpp $(HDR)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(KSRC) -x hip $(SRC)/nbody_capi.cpp $(SRC)/nbody_sharded.cpp -lpthread -ldl
 
 hw5: bin/hw5
-bin/hw5: $(SRC)/main_hw5.cpp $(SRC)/nbody_io.cpp $(SRC)/nbody_io.h $(LIB)
+bin/hw5: $(SRC)/main_hw5.cpp $(SRC)/nbody_io.cpp $(SRC)/nbody_io_state.cpp $(SRC)/nbody_io.h $(LIB)
 	@mkdir -p bin
-	$(HIPCC) -O3 -std=c++17 -o $@ $(SRC)/main_hw5.cpp $(SRC)/nbody_io.cpp -L$(PKG) -lnbody_amd -Wl,-rpath,'$$ORIGIN/../$(PKG):$$ORIGIN/$(PKG)' -lpthread
+	$(HIPCC) -O3 -std=c++17 -o $@ $(SRC)/main_hw5.cpp $(SRC)/nbody_io.cpp $(SRC)/nbody_io_state.cpp -L$(PKG) -lnbody_amd -Wl,-rpath,'$$ORIGIN/../$(PKG):$$ORIGIN/$(PKG)' -lpthread
 	cp $@ hw5
 
 nbody_bench: bin/nbody_bench
 bin/nbody_bench: $(SRC)/main_nbody_bench.cpp $(LIB)
 	@mkdir -p bin
 	$(HIPCC) -O3 -std=c++17 -o $@ $(SRC)/main_nbody_bench.cpp -L$(PKG) -lnbody_amd -Wl,-rpath,'$$ORIGIN/../$(PKG)' -lpthread
+
+nbconv: bin/nbconv
+bin/nbconv: $(SRC)/main_nbconv.cpp $(SRC)/nbody_io.cpp $(SRC)/nbody_io.h $(LIB)
+	@mkdir -p bin
+	$(HIPCC) -O3 -std=c++17 -o $@ $(SRC)/main_nbconv.cpp $(SRC)/nbody_io.cpp -L$(PKG) -lnbody_amd -Wl,-rpath,'$$ORIGIN/../$(PKG)' -lpthread
 
 oracle:
 	$(MAKE) -C oracle
@@ -48,4 +53,4 @@ bench/ubench/valu_rate: bench/ubench/valu_rate.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
 
 clean:
-	rm -f $(LIB) bin/hw5 bin/nbody_bench hw5 bench/ubench/valu_rate bench/ubench/force_variants
+	rm -f $(LIB) bin/hw5 bin/nbody_bench bin/nbconv hw5 bench/ubench/valu_rate bench/ubench/force_variants

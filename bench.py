@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_PAIR = 20            # GPU Gems 3 ch.31 convention
 PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz
+ISSUE_CEILING_FRAC = 0.62     # what the pair loop's instruction mix can issue (derivation in the JSON and DESIGN.md §3)
 
 
 def cpu_baseline(n_sample=16384, steps=2):
@@ -85,16 +86,54 @@ def cpu_baseline_all_cores(n_total, rows=2048):
                       f"of the same input ({pairs:.3g} pairs, {dt:.1f} s)"}
 
 
-def load_traffic(n_bodies, world):
-    """HBM bytes per force-kernel launch from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json)."""
+def load_traffic(n_bodies, world, kernel, j_split):
+    """HBM bytes per step of the force + reducer launches from the committed rocprofv3 PMC passes
+    (profiles/pmc_traffic.json, written by bench/parse_profile.py) — only when that profile was taken on THIS kernel,
+    body count, rank count and source split; any other configuration reports null (and the reducer's share likewise)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
             t = json.load(f)
-        key = f"n{n_bodies}_p{world}"
-        return t.get(key, {}).get("hbm_bytes_per_launch")
     except Exception:
-        return None
+        return None, None
+    e = t.get(f"n{n_bodies}_p{world}", {})
+    if e.get("kernel") != kernel or e.get("j_split") != j_split:
+        return None, None
+    return e.get("hbm_bytes_per_launch"), e.get("reduce_share_of_span")
+
+
+def sharded_check(torch, dist, world, rank, device, dev_index):
+    """world > 1 only, after the timed region: the same sharded stepper (index shards, tgt_off != 0 launches, in-place
+    RCCL all-gather, ping-pong) on a small system, against the UNSHARDED run of the same bodies on rank 0's GPU through
+    nb_step.  Proves on the real multi-GPU node what tests/test_gpu_distributed.py rehearses on one GPU."""
+    import numpy as np
+    from nbody_amd import capi, synthetic
+    from nbody_amd.distributed import ShardedSystem, shard_range
+    n, steps, dt = 32768, 3, 1e-2
+    lo, hi = shard_range(n, rank, world)
+    pos, vel = synthetic.body4_f32(n, lo, hi)
+    s = ShardedSystem(n, torch.from_numpy(pos), torch.from_numpy(vel), synthetic.EPS, dt, device)
+    for _ in range(steps):
+        s.step()
+    torch.cuda.synchronize()
+    bits = s.positions.contiguous().view(torch.int32).to(torch.int64).sum().reshape(1)  # checksum of the gathered array
+    hi_, lo_ = bits.clone(), bits.clone()
+    dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+    dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+    agree = bool((hi_ == lo_).item())
+    out = None
+    if rank == 0:
+        q, v, m = synthetic.bodies(n)
+        with capi.Context(n, capi.NB_F32, dev_index, G=synthetic.G, eps=synthetic.EPS, dt=dt) as ctx:
+            ctx.set_state(q, v, m)
+            ctx.step(1, steps)
+            q1, _ = ctx.get_state()
+        diff = float(np.abs(s.positions[:, :3].cpu().numpy().T.astype(np.float64) - q1).max())
+        moved = float(np.abs(q1 - q.astype(np.float32)).max())
+        out = {"bodies": n, "steps": steps, "ranks_hold_identical_positions": agree,
+               "max_abs_diff_vs_unsharded": diff, "max_displacement": moved,
+               "ok": bool(agree and diff < 5e-7 and moved > 1e-6), "exchange": s.exchange_mode}
+    return out
 
 
 def main():
@@ -108,6 +147,8 @@ def main():
     ap.add_argument("--j-split", type=int, default=0)
     ap.add_argument("--source-path", type=int, default=0, help="0 auto, 1 LDS tile, 2 SGPR/scalar loads")
     ap.add_argument("--wg-size", type=int, default=0, help="0 auto, 256, 512 (with --targets-per-lane 8), 1024 (4)")
+    ap.add_argument("--overlap", action="store_true", help="multi-GPU: two-phase step, own-shard sources while the "
+                    "all-gather of the other shards is in flight (SURVEY 8(f)-3); default off, see overlap_ab in the JSON")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--report-every", type=int, default=0, help="sustained runs (configs[4]): every R steps synchronise "
                     "and print steps done + running pairs/s to stderr")
@@ -153,20 +194,11 @@ def main():
         vel = np.concatenate([v.T, np.zeros((hi - lo, 1))], axis=1)
     compute = hip_compute(acc64, args.targets_per_lane, args.j_split, args.source_path, args.wg_size)
     sysm = ShardedSystem(n, torch.from_numpy(pos), torch.from_numpy(vel), synthetic.EPS, synthetic.DT, device,
-                         compute=compute, acc64=acc64)
+                         compute=compute, acc64=acc64, overlap=args.overlap)
 
-    # --- kernel-only timing: HIP events on the stream the kernel is launched on (torch's current stream)
-    kern_ms = []
-
-    def timed_step():
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        src, out = sysm.pos[sysm.cur], sysm.pos[sysm.cur ^ 1]
-        e0.record()
-        sysm.compute(src, out, sysm.vel, sysm.lo, sysm.n_tgt, sysm.eps2, sysm.dt, sysm.pos64, sysm.vel64)
-        e1.record()
-        sysm._exchange(out)
-        sysm.cur ^= 1
-        kern_ms.append((e0, e1))
+    # --- kernel-only timing: HIP events on the stream the kernel is launched on (torch's current stream), recorded by
+    #     ShardedSystem.step() around its launches
+    kern_ms = sysm.kernel_events = []
 
     def barrier():
         torch.cuda.synchronize()
@@ -177,10 +209,11 @@ def main():
     for _ in range(args.warmup):
         sysm.step()
     barrier()
+    kern_ms.clear()
     t0 = time.perf_counter()
     steps_done = 0
     for k in range(args.steps):
-        timed_step()
+        sysm.step()
         steps_done += 1
         if args.report_every and steps_done % args.report_every == 0 and steps_done < args.steps:
             torch.cuda.synchronize()
@@ -204,6 +237,41 @@ def main():
     k_ms = sum(a.elapsed_time(b) for a, b in kern_ms) / len(kern_ms)
     assert torch.isfinite(sysm.positions).all(), "non-finite positions"
 
+    # --- untimed diagnostics of the multi-GPU path (after the timed region; not part of `value`)
+    exchange_ms = check = overlap_ab = None
+    if world > 1:
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        barrier()
+        ev[0].record()
+        for _ in range(20):
+            sysm._exchange(sysm.positions)  # re-gathers the current positions: a no-op on the data
+        ev[1].record()
+        torch.cuda.synchronize()
+        exchange_ms = ev[0].elapsed_time(ev[1]) / 20
+        if args.backend == "nccl":
+            check = sharded_check(torch, dist, world, rank, device, dev_index)
+        # the same system stepped with the other setting of --overlap, a few steps, wall clock (max over ranks)
+        sysm.kernel_events = None
+        ab = {}
+        for mode in (False, True):
+            if mode and sysm.n_tgt % 256:
+                continue
+            sysm._wait_gather()
+            sysm.overlap = mode
+            sysm.step()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(min(5, max(2, args.steps))):
+                sysm.step()
+            barrier()
+            w = torch.tensor([(time.perf_counter() - t1) / min(5, max(2, args.steps))], dtype=torch.float64,
+                             device=device if args.backend == "nccl" else "cpu")
+            dist.all_reduce(w, op=dist.ReduceOp.MAX)
+            ab["on" if mode else "off"] = float(w.item()) * 1e3
+        sysm._wait_gather()
+        sysm.overlap = args.overlap and world > 1
+        overlap_ab = ab
+
     if rank == 0:
         pairs_step = n * (n - 1)
         value = pairs_step * args.steps / wall
@@ -215,6 +283,8 @@ def main():
                                      source_path=args.source_path, wg_size=args.wg_size)
         tpl, jsp, wgs = capi.plan_f32(n, sysm.n_tgt, acc64, args.targets_per_lane, args.j_split, ws_bytes,
                                       args.source_path, args.wg_size)
+        reducer = f"nbody_reduce_update_f32<{'true' if acc64 else 'false'}, false>"
+        traffic, reduce_share = load_traffic(n, world, kname, jsp)
         out = {
             "metric": "body-pair interactions/sec",
             "value": value,
@@ -232,12 +302,31 @@ def main():
                                    f"force + fused kick-drift, eps=1e-3, dt=1e-4", "bodies": n,
                        "parallelism": f"index-sharded x{world}, 1 RCCL all-gather of float4 positions/step"
                        if world > 1 else "single GPU"},
+            "exchange": sysm.exchange_mode,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": load_traffic(n, world),
-                         "kernel": kname, "kernel_ms": k_ms, "targets_per_lane": tpl, "j_split": jsp, "wg_size": wgs, "flop_per_pair": FLOP_PER_PAIR,
-                         "bound_detail": "compute roofline = fp32 vector-FMA peak 157.3 TFLOP/s (== dense f32 MFMA "
-                                         "peak); kernel is VALU + v_rsq_f32, MFMA deliberately unused"},
+                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
+                         "kernel": kname, "kernel_ms": k_ms,
+                         "kernel_ms_spans": [kname] + ([reducer] if jsp > 1 else []),
+                         "reduce_share_of_span": reduce_share,
+                         "targets_per_lane": tpl, "j_split": jsp, "wg_size": wgs, "flop_per_pair": FLOP_PER_PAIR,
+                         "issue_ceiling_frac": ISSUE_CEILING_FRAC,
+                         "frac_of_issue_ceiling": achieved / PEAK_FP32_TFLOPS / ISSUE_CEILING_FRAC,
+                         "issue_ceiling_detail": "per 64 pairs a SIMD issues 12 fp32 VALU ops (2 cycles each, packed: 6 x 4) "
+                                                 "+ 1 v_rsq_f32 (8 cycles, does not overlap VALU) = 32 cycles -> 1024 SIMDs "
+                                                 "x 2.4 GHz x 64/32 = 4.9e12 pairs/s = 0.62 of peak at 20 flop/pair "
+                                                 "(profiles/r01_ubench_valu_rate.txt)",
+                         "bound_detail": "the contract's enum is hbm|mfma: the compute roofline used is the fp32 "
+                                         "vector-FMA (VALU) peak 157.3 TFLOP/s (numerically the dense f32 MFMA peak); the "
+                                         "kernel is VALU + v_rsq_f32 issue-bound, MFMA deliberately unused"},
         }
+        if exchange_ms is not None:
+            out["exchange_ms"] = exchange_ms  # one all-gather of float4[N] by itself, mean of 20
+        if check is not None:
+            out["sharded_check"] = check
+        if overlap_ab:
+            out["overlap"] = bool(args.overlap)
+            out["overlap_ab"] = {"ms_per_step": overlap_ab, "note": "two-phase step (own-shard sources during the "
+                                 "all-gather) on vs off, same system, untimed diagnostic after the timed region"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(n)

@@ -26,13 +26,19 @@ def main():
     # 1. kernel stats
     stats = list(rows(f"{out}/stats/**/*kernel_stats.csv"))
     lines += ["## --kernel-trace --stats", "", "| kernel | calls | total ms | avg ms | % |", "|---|---|---|---|---|"]
-    avg_ms = None
+    avg_ms = kernel = None
+    reduce_total = force_total = 0.0
     for r in stats:
         name = r.get("Name", "")
         avg = float(r.get("AverageNs", 0)) / 1e6
         lines.append(f"| `{name[:90]}` | {r.get('Calls')} | {float(r.get('TotalDurationNs', 0)) / 1e6:.3f} | {avg:.4f} | {r.get('Percentage')} |")
         if KERNEL in name and avg_ms is None:
             avg_ms = avg
+            kernel = name.replace("void nbk::", "").replace("(nbk::F32Args)", "")
+        if KERNEL in name:
+            force_total += float(r.get("TotalDurationNs", 0))
+        if "nbody_reduce_update_f32" in name:
+            reduce_total += float(r.get("TotalDurationNs", 0))
     # per-dispatch registers from the trace
     for r in rows(f"{out}/stats/**/*kernel_trace.csv"):
         if KERNEL in r.get("Kernel_Name", ""):
@@ -84,8 +90,10 @@ def main():
         except Exception:
             t = {}
         key = os.environ.get("NB_TRAFFIC_KEY", "n1048576_p1")
+        # bench.py only quotes these numbers for the configuration they were measured on
         t[key] = {"hbm_bytes_per_launch": traffic, "fetch_kib_raw": f_kib, "write_kib": w_kib, "tag": tag,
-                  "kernel_avg_ms": avg_ms}
+                  "kernel_avg_ms": avg_ms, "kernel": kernel, "j_split": int(os.environ.get("NB_TRAFFIC_JSPLIT", "8")),
+                  "reduce_share_of_span": reduce_total / (reduce_total + force_total) if force_total else None}
         json.dump(t, open(tpath, "w"), indent=1)
     print("\n".join(lines))
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NB_ABI_VERSION 1
+#define NB_ABI_VERSION 2
 
 typedef enum nb_status {
     NB_OK = 0,
@@ -73,14 +73,18 @@ typedef struct nb_scenario {
     int32_t last_step;   /* inclusive; reference: n_steps = 200000 */
     int32_t planet;      /* body indices (file order) */
     int32_t asteroid;
-    int32_t n_watch;               /* devices watched for missile arrival (FIRST_HIT: all; MISSILE: 1) */
+    int32_t n_watch;               /* devices watched for missile arrival (FIRST_HIT: up to NB_MAX_WATCH; MISSILE: 0 or 1 —
+                                      one device is destroyed per run, hw5.cu:289-309; more is NB_ERR_INVALID) */
     int32_t watch[NB_MAX_WATCH];   /* their body indices */
     int32_t sync_every;            /* host polls the hit flag every this many steps (hw5.cu:72: 2000); <=0 -> 2000 */
     int32_t engine;                /* 0 = auto; 1 = one launch per step (any n); 2 = whole step loop inside one
                                       persistent single-workgroup launch (n <= 128) */
+    int32_t flags;                 /* NB_SCN_NO_SNAPSHOT: FIRST_HIT records arrival steps but keeps no (q,v) snapshots */
+    int32_t reserved;
     double planet_radius;          /* 1e7   nbody.cc:17 */
     double missile_speed;          /* 1e6   nbody.cc:18 */
 } nb_scenario;
+#define NB_SCN_NO_SNAPSHOT 1
 
 typedef struct nb_scenario_result {
     double min_dist2;                     /* MIN_DIST: min squared planet–asteroid distance (sqrt on the host) */
@@ -99,7 +103,9 @@ int nb_config_default(nb_config* cfg); /* fills the reference's param:: values, 
 int nb_create(nb_context** out, const nb_config* cfg);
 int nb_destroy(nb_context* ctx);
 const char* nb_strerror(int code);
-const char* nb_last_error(const nb_context* ctx); /* text of the last HIP failure on this context */
+/* text of the last failure on this context; ctx == NULL: of the last failed context-free call made by the calling
+ * thread (raw launches, state files, nb_solve, nb_sharded_create) */
+const char* nb_last_error(const nb_context* ctx);
 
 /* ---- state: the seven vectors of run_step + the `type[j]=="device"` predicate (nbody.cc:62) ---- */
 int nb_set_state(nb_context* ctx, const double* qx, const double* qy, const double* qz, const double* vx,
@@ -131,15 +137,42 @@ int nb_run_scenarios_batched(nb_context** ctxs, const nb_scenario* scns, nb_scen
 int nb_restore_snapshot(nb_context* dst, nb_context* src, int watch_slot);
 
 /* ---- binary state files (checkpoint / large-N input; the reference only has the text format, nbody.cc:22-49,
- *      and an in-memory snapshot, hw5.cu:265-287).  Layout, little endian:
- *        char magic[8] = "NBODYST1"; int64 n; int32 precision; int32 step; double G, eps, dt;
+ *      and an in-memory snapshot, hw5.cu:265-287).  Layout, little endian, version 2:
+ *        char magic[8] = "NBODYST2"; uint32 byte-order mark 0x01020304; int32 precision; int64 n; int32 step;
+ *        int32 planet; int32 asteroid; int32 reserved; double G, eps, dt;                              (64 bytes)
  *        double q[3][n]; double v[3][n]; double m[n]; uint8 is_device[n]
- *      q,v are the fp64 masters (F64 / F32_ACC64) or the widened fp32 state (F32). ---- */
+ *      q,v are the fp64 masters (F64 / F32_ACC64) or the widened fp32 state (F32); planet/asteroid = the header of the
+ *      text format (nbody.cc:27), -1 when the file is a plain checkpoint.  Version-1 files ("NBODYST1", 48-byte header
+ *      without byte-order mark and planet/asteroid) are still read.  bin/hw5 accepts such a file as <input>. ---- */
+typedef struct nb_state_header {
+    int64_t n;
+    int32_t precision; /* nb_precision of the run that wrote it */
+    int32_t step;      /* index of the state */
+    int32_t planet;    /* body indices of the scenario, -1 = not recorded */
+    int32_t asteroid;
+    double G, eps, dt;
+} nb_state_header;
 int nb_save_state(nb_context* ctx, const char* path, int step);
-int nb_load_state(nb_context* ctx, const char* path, int* step); /* n must match the context */
+/* resumes a checkpoint: n, precision, G, eps and dt of the file must equal the context's (NB_ERR_INVALID otherwise,
+ * nb_last_error(ctx) says which); to start a run from a state file under other parameters use nb_read_state_file +
+ * nb_set_state */
+int nb_load_state(nb_context* ctx, const char* path, int* step);
 int nb_state_file_info(const char* path, int64_t* n, int* precision, int* step);
+/* host-array access to a state file (no GPU involved).  Reading: all array pointers NULL -> header only; otherwise the
+ * seven double arrays must hold `capacity` >= n elements each (is_device may be NULL). */
+int nb_read_state_file(const char* path, nb_state_header* hdr, int64_t capacity, double* qx, double* qy, double* qz,
+                       double* vx, double* vy, double* vz, double* m, uint8_t* is_device);
+int nb_write_state_file(const char* path, const nb_state_header* hdr, const double* qx, const double* qy,
+                        const double* qz, const double* vx, const double* vy, const double* vz, const double* m,
+                        const uint8_t* is_device /* may be NULL */);
 
-/* ---- whole reference program: P1, P2, P3 (nbody.cc:106-146 ; hw5.cu:532-606) ---- */
+/* ---- whole reference program: P1, P2, P3 (nbody.cc:106-146 ; hw5.cu:532-606) ----
+ * All 2 + D scenarios (P1, P2, one Problem-3 run per gravity device) start at step 0 and advance together in one launch
+ * stream per GPU (a workgroup per scenario in one persistent launch for n <= 128; one batched launch per step
+ * otherwise), at most 8 per stream; scenarios beyond that are queued cheapest-first (ascending missile-arrival step,
+ * hw5.cu:574-585) and dropped once they cannot beat a feasible device (hw5.cu:490-493).  `devices` spreads the
+ * scenarios over several GPUs (the reference's task parallelism, hw5.cu:564-567,587-588).
+ * Environment: NB_SOLVE_MAX_BATCH=2..8 lowers the scenarios per launch stream (exercises the queue). */
 typedef struct nb_answer {
     double min_dist;
     int32_t hit_time_step;
@@ -180,8 +213,18 @@ typedef struct nb_launch_f32 {
                                  block each take one slice; 16 slices per launch, partial sums folded by a reducer */
     int32_t source_path;      /* 0 = auto; 1 = sources through the LDS tile; 2 = sources through scalar loads/SGPRs */
     int32_t wg_size;          /* 0 = auto; 256, 512 (targets_per_lane 8) or 1024 (targets_per_lane 4) */
-    int32_t reserved;
+    int32_t phase;            /* nb_launch_phase: a step may be cut into several launches over disjoint source ranges
+                                 (own shard while the all-gather of the other shards is still in flight);
+                                 the running sums live in `workspace` between them (required unless NB_PHASE_WHOLE) */
+    int64_t src_begin;        /* sources of this launch: src[src_begin .. src_end); 0,0 = all n_src.  src_begin must be */
+    int64_t src_end;          /* a multiple of 256, src_end a multiple of 256 or n_src */
 } nb_launch_f32;
+typedef enum nb_launch_phase {
+    NB_PHASE_WHOLE = 0,  /* the whole step in one call: start the sums, run the epilogue */
+    NB_PHASE_FIRST = 1,  /* start the sums, keep them in the workspace */
+    NB_PHASE_LAST = 2,   /* continue the sums, then the epilogue (accelerations out / kick-drift) */
+    NB_PHASE_MIDDLE = 3  /* continue the sums, keep them */
+} nb_launch_phase;
 int nb_launch_step_f32(const nb_launch_f32* a, void* hip_stream);  /* force + fused kick-drift */
 int nb_launch_accel_f32(const nb_launch_f32* a, void* hip_stream); /* force only -> a->acc */
 /* name of the kernel symbol the two launches above resolve to for these arguments (for matching rocprofv3 rows) */
@@ -190,6 +233,32 @@ const char* nb_kernel_name_f32(const nb_launch_f32* a, int accel_only);
 int nb_plan_f32(const nb_launch_f32* a, int* targets_per_lane, int* j_split, int* wg_size);
 /* workspace size that allows source slicing for n_tgt targets: 18 records per target */
 int64_t nb_workspace_bytes_f32(int64_t n_tgt, int acc64);
+
+/* ---- index-sharded multi-GPU stepping: ONE process, P GPUs of a node, RCCL over xGMI (csrc/nbody_sharded.cpp) ----
+ * The reference's only multi-GPU use is task parallelism (hw5.cu:564-567,587-588); this is the data-parallel scheme of
+ * GPU r owns targets [r*n/P, (r+1)*n/P) (velocities, fp64 masters), every GPU holds all positions twice
+ * (ping-pong float4[n] {x,y,z,G*m}); per step and GPU one force + fused kick-drift launch sequence on its own stream,
+ * then ONE in-place ncclAllGather(sendbuff = recvbuff + r*4n/P, ncclFloat) per GPU.  RCCL is loaded (dlopen) by the
+ * first nb_sharded_create.  The same scheme with one process per GPU: nbody_amd.distributed (torch.distributed).
+ * n must be divisible by n_devices; precision NB_F32 or NB_F32_ACC64; with one device the trajectory equals nb_step's
+ * bit for bit. */
+typedef struct nb_sharded nb_sharded;
+#define NB_SHARDED_OVERLAP 1 /* two-phase step: own-shard sources while the all-gather of the other shards is in flight
+                                on a second stream, remote sources after it; n/P must be a multiple of 256 */
+int nb_sharded_create(nb_sharded** out, const int* devices, int n_devices, int64_t n, int precision, double G,
+                      double eps, double dt, int flags);
+int nb_sharded_destroy(nb_sharded* s);
+const char* nb_sharded_last_error(const nb_sharded* s); /* s == NULL: the calling thread's last failed create */
+/* host arrays of ALL n bodies, as nb_set_state / nb_get_state (no `device` bodies in the fp32 modes) */
+int nb_sharded_set_state(nb_sharded* s, const double* qx, const double* qy, const double* qz, const double* vx,
+                         const double* vy, const double* vz, const double* m);
+int nb_sharded_get_state(nb_sharded* s, double* qx, double* qy, double* qz, double* vx, double* vy, double* vz);
+int nb_sharded_step(nb_sharded* s, int count); /* `count` run_steps of the whole system; returns with all GPUs idle */
+/* as nb_sharded_step, and reports the host wall time per step in milliseconds (all GPUs idle on both sides) */
+int nb_sharded_step_timed(nb_sharded* s, int count, double* ms_per_step);
+/* shard size and the launch plan each GPU uses for a whole step (any pointer may be NULL) */
+int nb_sharded_info(const nb_sharded* s, int* n_devices, int64_t* targets_per_device, int* targets_per_lane,
+                    int* j_split, int* wg_size);
 
 #ifdef __cplusplus
 }

@@ -23,13 +23,18 @@ class NbConfig(C.Structure):
 class NbScenario(C.Structure):
     _fields_ = [("kind", C.c_int32), ("first_step", C.c_int32), ("last_step", C.c_int32), ("planet", C.c_int32),
                 ("asteroid", C.c_int32), ("n_watch", C.c_int32), ("watch", C.c_int32 * NB_MAX_WATCH),
-                ("sync_every", C.c_int32), ("engine", C.c_int32), ("planet_radius", C.c_double),
-                ("missile_speed", C.c_double)]
+                ("sync_every", C.c_int32), ("engine", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32),
+                ("planet_radius", C.c_double), ("missile_speed", C.c_double)]
 
 
 class NbScenarioResult(C.Structure):
     _fields_ = [("min_dist2", C.c_double), ("hit_step", C.c_int32), ("steps_done", C.c_int32),
                 ("arrival_step", C.c_int32 * NB_MAX_WATCH), ("missile_cost", C.c_double * NB_MAX_WATCH)]
+
+
+class NbStateHeader(C.Structure):
+    _fields_ = [("n", C.c_int64), ("precision", C.c_int32), ("step", C.c_int32), ("planet", C.c_int32),
+                ("asteroid", C.c_int32), ("G", C.c_double), ("eps", C.c_double), ("dt", C.c_double)]
 
 
 class NbAnswer(C.Structure):
@@ -43,7 +48,7 @@ class NbLaunchF32(C.Structure):
                 ("workspace_bytes", C.c_int64), ("n_src", C.c_int64), ("tgt_off", C.c_int64),
                 ("n_tgt", C.c_int64), ("eps2", C.c_float), ("dt", C.c_float), ("acc64", C.c_int32),
                 ("targets_per_lane", C.c_int32), ("j_split", C.c_int32), ("source_path", C.c_int32),
-                ("wg_size", C.c_int32), ("reserved", C.c_int32)]
+                ("wg_size", C.c_int32), ("phase", C.c_int32), ("src_begin", C.c_int64), ("src_end", C.c_int64)]
 
 
 # every symbol include/nbody_amd.h declares: (restype, argtypes)
@@ -68,6 +73,9 @@ SYMBOLS = {
     "nb_save_state": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "nb_load_state": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]),
     "nb_state_file_info": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "nb_read_state_file": (C.c_int, [C.c_char_p, C.POINTER(NbStateHeader), C.c_int64, _dp, _dp, _dp, _dp, _dp, _dp, _dp,
+                                    _u8p]),
+    "nb_write_state_file": (C.c_int, [C.c_char_p, C.POINTER(NbStateHeader), _dp, _dp, _dp, _dp, _dp, _dp, _dp, _u8p]),
     "nb_solve": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _u8p,
                            C.POINTER(C.c_int), C.c_int, C.POINTER(NbAnswer)]),
     "nb_launch_step_f32": (C.c_int, [C.POINTER(NbLaunchF32), C.c_void_p]),
@@ -75,7 +83,18 @@ SYMBOLS = {
     "nb_kernel_name_f32": (C.c_char_p, [C.POINTER(NbLaunchF32), C.c_int]),
     "nb_plan_f32": (C.c_int, [C.POINTER(NbLaunchF32), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "nb_workspace_bytes_f32": (C.c_int64, [C.c_int64, C.c_int]),
+    "nb_sharded_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int64, C.c_int, C.c_double,
+                                   C.c_double, C.c_double, C.c_int]),
+    "nb_sharded_destroy": (C.c_int, [C.c_void_p]),
+    "nb_sharded_last_error": (C.c_char_p, [C.c_void_p]),
+    "nb_sharded_set_state": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
+    "nb_sharded_get_state": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _dp, _dp]),
+    "nb_sharded_step": (C.c_int, [C.c_void_p, C.c_int]),
+    "nb_sharded_step_timed": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
+    "nb_sharded_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int),
+                                 C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 }
+NB_SHARDED_OVERLAP = 1
 
 
 class NBodyError(RuntimeError):
@@ -143,7 +162,7 @@ def _strerror(code):
 
 def _check(rc, where, ctx=None):
     if rc != NB_OK:
-        detail = lib().nb_last_error(ctx).decode() if ctx else ""
+        detail = lib().nb_last_error(ctx).decode()  # ctx None: the calling thread's last context-free failure
         raise NBodyError(rc, where, detail)
 
 
@@ -232,14 +251,9 @@ class Context:
         return a
 
     def run_scenario(self, kind, planet, asteroid, first_step=0, last_step=200000, watch=(), sync_every=2000,
-                     planet_radius=1e7, missile_speed=1e6, engine=0):
-        s = NbScenario()
-        s.kind, s.first_step, s.last_step, s.planet, s.asteroid = kind, first_step, last_step, planet, asteroid
-        s.n_watch = len(watch)
-        for k, w in enumerate(watch):
-            s.watch[k] = w
-        s.sync_every, s.planet_radius, s.missile_speed = sync_every, planet_radius, missile_speed
-        s.engine = engine
+                     planet_radius=1e7, missile_speed=1e6, engine=0, flags=0):
+        s = _scenario_struct(kind, planet, asteroid, first_step, last_step, watch, sync_every, planet_radius,
+                             missile_speed, engine, flags)
         r = NbScenarioResult()
         _check(lib().nb_run_scenario(self._h, C.byref(s), C.byref(r)), "nb_run_scenario", self._h)
         return dict(min_dist2=r.min_dist2, hit_step=r.hit_step, steps_done=r.steps_done,
@@ -257,14 +271,18 @@ class Context:
         _check(lib().nb_restore_snapshot(self._h, src._h, slot), "nb_restore_snapshot", self._h)
 
 
+NB_SCN_NO_SNAPSHOT = 1
+
+
 def _scenario_struct(kind, planet, asteroid, first_step=0, last_step=200000, watch=(), sync_every=2000,
-                     planet_radius=1e7, missile_speed=1e6, engine=0):
+                     planet_radius=1e7, missile_speed=1e6, engine=0, flags=0):
     s = NbScenario()
     s.kind, s.first_step, s.last_step, s.planet, s.asteroid = kind, first_step, last_step, planet, asteroid
     s.n_watch = len(watch)
     for k, w in enumerate(watch):
         s.watch[k] = w
     s.sync_every, s.planet_radius, s.missile_speed, s.engine = sync_every, planet_radius, missile_speed, engine
+    s.flags = flags
     return s
 
 
@@ -288,6 +306,33 @@ def state_file_info(path):
     return n.value, prec.value, step.value
 
 
+def read_state_file(path):
+    """-> (header dict, q (3,n), v (3,n), m (n,), is_device (n,) uint8) of a binary state file; no GPU involved."""
+    h = NbStateHeader()
+    _check(lib().nb_read_state_file(os.fsencode(path), C.byref(h), 0, None, None, None, None, None, None, None, None),
+           "nb_read_state_file")
+    n = h.n
+    q, v, m, dev = np.empty((3, n)), np.empty((3, n)), np.empty(n), np.empty(n, dtype=np.uint8)
+    ptrs = [q[k].ctypes.data_as(_dp) for k in range(3)] + [v[k].ctypes.data_as(_dp) for k in range(3)]
+    _check(lib().nb_read_state_file(os.fsencode(path), C.byref(h), n, *ptrs, m.ctypes.data_as(_dp),
+                                    dev.ctypes.data_as(_u8p)), "nb_read_state_file")
+    hdr = dict(n=n, precision=h.precision, step=h.step, planet=h.planet, asteroid=h.asteroid, G=h.G, eps=h.eps, dt=h.dt)
+    return hdr, q, v, m, dev
+
+
+def write_state_file(path, q, v, m, is_device=None, planet=-1, asteroid=-1, precision=NB_F64, step=0, G=6.674e-11,
+                     eps=1e-3, dt=60.0):
+    """Binary (NBODYST2) form of the reference's text input (nbody.cc:22-39): bin/hw5 accepts it as <input>."""
+    n = len(m)
+    h = NbStateHeader(n, precision, step, planet, asteroid, G, eps, dt)
+    keep = [_d(q[0]), _d(q[1]), _d(q[2]), _d(v[0]), _d(v[1]), _d(v[2]), _d(m)]
+    dev = None
+    if is_device is not None:
+        dev_arr = np.ascontiguousarray(is_device, dtype=np.uint8)
+        dev = dev_arr.ctypes.data_as(_u8p)
+    _check(lib().nb_write_state_file(os.fsencode(path), C.byref(h), *[p for _, p in keep], dev), "nb_write_state_file")
+
+
 def solve(n, planet, asteroid, q, v, m, is_device, devices=None):
     """The whole reference program (P1, P2, P3) on the GPU: nb_solve."""
     keep = [_d(q[0]), _d(q[1]), _d(q[2]), _d(v[0]), _d(v[1]), _d(v[2]), _d(m)]
@@ -303,17 +348,85 @@ def solve(n, planet, asteroid, q, v, m, is_device, devices=None):
     return ans.min_dist, ans.hit_time_step, ans.gravity_device_id, ans.missile_cost
 
 
+NB_PHASE_WHOLE, NB_PHASE_FIRST, NB_PHASE_LAST, NB_PHASE_MIDDLE = 0, 1, 2, 3
+
+
+class Sharded:
+    """nb_sharded: N bodies sharded by index over the GPUs `devices` of this node, driven by this one process
+    (one stream + one in-place RCCL all-gather per GPU per step)."""
+
+    def __init__(self, n, devices=(0,), precision=NB_F32, G=6.674e-11, eps=1e-3, dt=60.0, overlap=False):
+        self.n = n
+        self._h = C.c_void_p()
+        devs = (C.c_int * len(devices))(*devices)
+        rc = lib().nb_sharded_create(C.byref(self._h), devs, len(devices), n, precision, G, eps, dt,
+                                     NB_SHARDED_OVERLAP if overlap else 0)
+        if rc != NB_OK:
+            h, self._h = self._h, C.c_void_p()
+            detail = lib().nb_sharded_last_error(h).decode()
+            if h:
+                lib().nb_sharded_destroy(h)
+            raise NBodyError(rc, "nb_sharded_create", detail)
+
+    def _check(self, rc, where):
+        if rc != NB_OK:
+            raise NBodyError(rc, where, lib().nb_sharded_last_error(self._h).decode())
+
+    def close(self):
+        if self._h:
+            lib().nb_sharded_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_state(self, q, v, m):
+        keep = [_d(q[0]), _d(q[1]), _d(q[2]), _d(v[0]), _d(v[1]), _d(v[2]), _d(m)]
+        self._check(lib().nb_sharded_set_state(self._h, *[p for _, p in keep]), "nb_sharded_set_state")
+
+    def get_state(self):
+        q, v = np.empty((3, self.n)), np.empty((3, self.n))
+        ptrs = [q[k].ctypes.data_as(_dp) for k in range(3)] + [v[k].ctypes.data_as(_dp) for k in range(3)]
+        self._check(lib().nb_sharded_get_state(self._h, *ptrs), "nb_sharded_get_state")
+        return q, v
+
+    def step(self, count=1):
+        self._check(lib().nb_sharded_step(self._h, count), "nb_sharded_step")
+
+    def step_timed(self, count):
+        ms = C.c_double()
+        self._check(lib().nb_sharded_step_timed(self._h, count, C.byref(ms)), "nb_sharded_step_timed")
+        return ms.value
+
+    def info(self):
+        p, per, r, j, w = C.c_int(), C.c_int64(), C.c_int(), C.c_int(), C.c_int()
+        self._check(lib().nb_sharded_info(self._h, C.byref(p), C.byref(per), C.byref(r), C.byref(j), C.byref(w)),
+                    "nb_sharded_info")
+        return dict(devices=p.value, targets_per_device=per.value, targets_per_lane=r.value, j_split=j.value,
+                    wg_size=w.value)
+
+
 def _launch_struct(src_ptr, out_ptr, n_src, tgt_off, n_tgt, eps2, dt, vel_ptr=0, pos64_ptr=0, vel64_ptr=0, acc_ptr=0,
                    acc64=False, targets_per_lane=0, j_split=0, workspace_ptr=0, workspace_bytes=0, source_path=0,
-                   wg_size=0):
+                   wg_size=0, phase=NB_PHASE_WHOLE, src_begin=0, src_end=0):
     return NbLaunchF32(src_ptr or None, out_ptr or None, vel_ptr or None, pos64_ptr or None, vel64_ptr or None,
                        acc_ptr or None, workspace_ptr or None, workspace_bytes, n_src, tgt_off, n_tgt, eps2, dt,
-                       int(acc64), targets_per_lane, j_split, source_path, wg_size, 0)
+                       int(acc64), targets_per_lane, j_split, source_path, wg_size, phase, src_begin, src_end)
 
 
 def launch_f32(src_ptr, out_ptr, n_src, tgt_off, n_tgt, eps2, dt, stream, accel_only=False, **kw):
     """Raw launch on caller-owned device memory (pointers as ints, e.g. torch.Tensor.data_ptr()).
-    kw: vel_ptr, pos64_ptr, vel64_ptr, acc_ptr, acc64, targets_per_lane, j_split, workspace_ptr, workspace_bytes."""
+    kw: vel_ptr, pos64_ptr, vel64_ptr, acc_ptr, acc64, targets_per_lane, j_split, workspace_ptr, workspace_bytes,
+    source_path, wg_size, phase, src_begin, src_end."""
     a = _launch_struct(src_ptr, out_ptr, n_src, tgt_off, n_tgt, eps2, dt, **kw)
     f = lib().nb_launch_accel_f32 if accel_only else lib().nb_launch_step_f32
     _check(f(C.byref(a), C.c_void_p(stream)), "nb_launch_accel_f32" if accel_only else "nb_launch_step_f32")

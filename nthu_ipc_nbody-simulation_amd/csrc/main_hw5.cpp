@@ -3,6 +3,8 @@
 // Same argv, same input and output formats, same three answers; all arithmetic runs on the MI355X through the
 // C ABI of libnbody_amd (nb_solve).  NB_DEVICES=0,1,... (optional) spreads the independent scenarios P1, P2 and
 // the per-device P3 runs over several GPUs, as the reference does over its two (hw5.cu:564-567,587-588).
+// <input> may also be the binary form of the same data (an NBODYST2 state file with planet/asteroid recorded, see
+// include/nbody_amd.h; bin/nbconv converts) — recognised by its magic, the text format stays the default.
 #include <cstdio>
 #include <cstdlib>
 #include <stdexcept>
@@ -17,7 +19,12 @@ int main(int argc, char** argv) {
         throw std::runtime_error("must supply 2 arguments");  // uncaught -> abort, like the reference
     }
     nbio::Input in;
-    if (!nbio::read_input(argv[1], in)) {
+    if (nbio::is_state_file(argv[1])) {
+        if (!nbio::read_state_input(argv[1], in)) {
+            fprintf(stderr, "hw5: cannot read state file %s: %s\n", argv[1], nb_last_error(nullptr));
+            return 1;
+        }
+    } else if (!nbio::read_input(argv[1], in)) {
         fprintf(stderr, "hw5: cannot read %s\n", argv[1]);
         return 1;
     }
@@ -37,7 +44,7 @@ int main(int argc, char** argv) {
                       in.vy.data(), in.vz.data(), in.m.data(), in.is_device.data(),
                       gpus.empty() ? nullptr : gpus.data(), (int)gpus.size(), &ans);
     if (rc != NB_OK) {
-        fprintf(stderr, "hw5: nb_solve failed: %s\n", nb_strerror(rc));
+        fprintf(stderr, "hw5: nb_solve failed: %s (%s)\n", nb_strerror(rc), nb_last_error(nullptr));
         return 2;
     }
     if (!nbio::write_output(argv[2], ans.min_dist, ans.hit_time_step, ans.gravity_device_id, ans.missile_cost)) {

@@ -1,5 +1,7 @@
 // main_nbody_bench.cpp — a compiled host of the C ABI for large N (no Python, no torch):
-//     bin/nbody_bench [N=1048576] [steps=10] [warmup=2] [precision: f32|f32acc64|f64]
+//     bin/nbody_bench [N=1048576] [steps=10] [warmup=2] [precision: f32|f32acc64|f64] [gpus=0] [overlap=0]
+// gpus >= 1 runs the index-sharded stepper (nb_sharded_*: this one process drives GPUs 0..gpus-1, one in-place RCCL
+// all-gather of positions per GPU per step; overlap=1 = two-phase step hiding the gather); gpus = 0 the plain context.
 // Generates the synthetic bodies of SURVEY §8(d) (same splitmix64 stream as nbody_amd/synthetic.py), uploads them with
 // nb_set_state, advances `steps` steps with nb_step_timed (HIP events on the context's stream) and prints pairs/s.
 // Shows what a C/C++ caller of libnbody_amd looks like and gives rocprofv3 a target without an interpreter in front.
@@ -25,6 +27,8 @@ int main(int argc, char** argv) {
     const int steps = argc > 2 ? atoi(argv[2]) : 10;
     const int warmup = argc > 3 ? atoi(argv[3]) : 2;
     const char* prec = argc > 4 ? argv[4] : "f32";
+    const int gpus = argc > 5 ? atoi(argv[5]) : 0;
+    const int overlap = argc > 6 ? atoi(argv[6]) : 0;
     nb_config cfg;
     nb_config_default(&cfg);
     cfg.n = (int32_t)n;
@@ -35,6 +39,36 @@ int main(int argc, char** argv) {
         for (int k = 0; k < 3; ++k) q[k * n + i] = 2.0 * u01(i, k) - 1.0;
         for (int k = 0; k < 3; ++k) v[k * n + i] = (2.0 * u01(i, 3 + k) - 1.0) * 1e-3;
         m[i] = (0.5 + u01(i, 6)) / ((double)n * cfg.G);
+    }
+    const double pairs = (double)n * (double)(n - 1);
+    if (gpus >= 1) {
+        if (cfg.precision == NB_F64) {
+            fprintf(stderr, "the sharded stepper runs the fp32 modes\n");
+            return 2;
+        }
+        std::vector<int> devs(gpus);
+        for (int g = 0; g < gpus; ++g) devs[g] = g;
+        nb_sharded* sh = nullptr;
+        int rc = nb_sharded_create(&sh, devs.data(), gpus, n, cfg.precision, cfg.G, cfg.eps, cfg.dt,
+                                   overlap ? NB_SHARDED_OVERLAP : 0);
+        if (!rc) rc = nb_sharded_set_state(sh, &q[0], &q[n], &q[2 * n], &v[0], &v[n], &v[2 * n], m.data());
+        if (!rc && warmup > 0) rc = nb_sharded_step(sh, warmup);
+        double ms = 0;
+        if (!rc) rc = nb_sharded_step_timed(sh, steps, &ms);
+        if (rc) {
+            fprintf(stderr, "sharded run failed: %s (%s)\n", nb_strerror(rc), nb_sharded_last_error(sh));
+            if (sh) nb_sharded_destroy(sh);
+            return 2;
+        }
+        int tpl = 0, js = 0, wg = 0;
+        int64_t per = 0;
+        nb_sharded_info(sh, nullptr, &per, &tpl, &js, &wg);
+        printf("{\"n\": %ld, \"precision\": \"%s\", \"gpus\": %d, \"overlap\": %d, \"steps\": %d, \"ms_per_step\": %.4f, "
+               "\"pairs_per_s\": %.6e, \"tflops_20flop\": %.2f, \"targets_per_gpu\": %lld, \"plan\": [%d, %d, %d]}\n",
+               n, prec, gpus, overlap, steps, ms, pairs / (ms * 1e-3), pairs / (ms * 1e-3) * 20 / 1e12, (long long)per, tpl, js,
+               wg);
+        nb_sharded_destroy(sh);
+        return 0;
     }
     nb_context* ctx = nullptr;
     int rc = nb_create(&ctx, &cfg);
@@ -50,7 +84,6 @@ int main(int argc, char** argv) {
         fprintf(stderr, "step failed: %s (%s)\n", nb_strerror(rc), nb_last_error(ctx));
         return 2;
     }
-    const double pairs = (double)n * (double)(n - 1);
     printf("{\"n\": %ld, \"precision\": \"%s\", \"steps\": %d, \"ms_per_step\": %.4f, \"pairs_per_s\": %.6e, "
            "\"tflops_20flop\": %.2f}\n", n, prec, steps, ms, pairs / (ms * 1e-3), pairs / (ms * 1e-3) * 20 / 1e12);
     nb_destroy(ctx);

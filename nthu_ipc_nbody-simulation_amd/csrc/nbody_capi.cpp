@@ -10,11 +10,13 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <new>
 #include <thread>
 #include <vector>
@@ -44,6 +46,7 @@ struct nb_context {
     double* snap_q = nullptr;        // [NB_MAX_WATCH? n_watch][3][n]
     double* snap_v = nullptr;
     int snap_slots = 0;
+    int snap_arrival[NB_MAX_WATCH];  // per snapshot slot: arrival step of the last FIRST_HIT scenario, -2 = holds nothing
     int split = 1;
     double* gm_large = nullptr;       // K1-f64 (n > F64_LARGE_MIN): G*m_eff scratch [n]
     double* partial_large = nullptr;  // ... and partial sums [slices][3][n]
@@ -66,8 +69,17 @@ struct nb_context {
 
 namespace {
 
+// text of the last failure of a call that has no context (raw launches, state files, nb_solve, nb_sharded_create):
+// per host thread, read with nb_last_error(NULL)
+thread_local char g_err[512] = {0};
+
+int set_error(int code, const char* text) {
+    snprintf(g_err, sizeof g_err, "%s", text);
+    return code;
+}
+
 int fail_hip(nb_context* c, hipError_t e, const char* what) {
-    if (c) snprintf(c->err, sizeof c->err, "%s: %s", what, hipGetErrorString(e));
+    snprintf(c ? c->err : g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
     return NB_ERR_HIP;
 }
 
@@ -226,7 +238,7 @@ const char* nb_strerror(int code) {
     return "unknown error";
 }
 
-const char* nb_last_error(const nb_context* ctx) { return ctx ? ctx->err : "null context"; }
+const char* nb_last_error(const nb_context* ctx) { return ctx ? ctx->err : g_err; }
 
 int nb_create(nb_context** out, const nb_config* cfg) {
     if (!out || !cfg || cfg->n <= 0) return NB_ERR_INVALID;
@@ -239,6 +251,7 @@ int nb_create(nb_context** out, const nb_config* cfg) {
     if (!c) return NB_ERR_NOMEM;
     c->cfg = *cfg;
     c->n = cfg->n;
+    for (int k = 0; k < NB_MAX_WATCH; ++k) c->snap_arrival[k] = -2;
     *out = c;  // returned even on failure so the caller can read nb_last_error, then nb_destroy
     NB_HIP(c, hipSetDevice(cfg->device));
     hipDeviceProp_t prop;
@@ -291,7 +304,7 @@ int nb_destroy(nb_context* ctx) {
     return NB_OK;
 }
 
-int nb_set_state(nb_context* c, const double* qx, const double* qy, const double* qz, const double* vx,
+static int nb_set_state_impl(nb_context* c, const double* qx, const double* qy, const double* qz, const double* vx,
                  const double* vy, const double* vz, const double* m, const uint8_t* is_device) {
     if (!c || !qx || !qy || !qz || !vx || !vy || !vz || !m) return NB_ERR_INVALID;
     if (int rc = bind(c)) return rc;
@@ -342,7 +355,7 @@ int nb_set_state(nb_context* c, const double* qx, const double* qy, const double
     return NB_OK;
 }
 
-int nb_get_state(nb_context* c, double* qx, double* qy, double* qz, double* vx, double* vy, double* vz) {
+static int nb_get_state_impl(nb_context* c, double* qx, double* qy, double* qz, double* vx, double* vy, double* vz) {
     if (!c || !qx || !qy || !qz || !vx || !vy || !vz) return NB_ERR_INVALID;
     if (!c->have_state) return NB_ERR_STATE;
     if (int rc = bind(c)) return rc;
@@ -415,7 +428,7 @@ int nb_step_timed(nb_context* c, int first_step, int count, float* ms_per_step) 
     return NB_OK;
 }
 
-int nb_accel(nb_context* c, int step, double* ax, double* ay, double* az) {
+static int nb_accel_impl(nb_context* c, int step, double* ax, double* ay, double* az) {
     if (!c || !ax || !ay || !az) return NB_ERR_INVALID;
     if (!c->have_state) return NB_ERR_STATE;
     if (int rc = bind(c)) return rc;
@@ -455,21 +468,28 @@ int nb_accel(nb_context* c, int step, double* ax, double* ay, double* az) {
     return NB_OK;
 }
 
-int nb_run_scenario(nb_context* c, const nb_scenario* s, nb_scenario_result* res) {
-    if (!c || !s || !res) return NB_ERR_INVALID;
+// ---------------------------------------------------------------- scenario drivers
+}  // extern "C"
+
+namespace {
+
+int check_scenario(const nb_context* c, const nb_scenario* s) {
     if (c->cfg.precision != NB_F64) return NB_ERR_INVALID;
     if (!c->have_state) return NB_ERR_STATE;
     if (s->kind < NB_SCN_MIN_DIST || s->kind > NB_SCN_MISSILE) return NB_ERR_INVALID;
     if (s->n_watch < 0 || s->n_watch > NB_MAX_WATCH) return NB_ERR_INVALID;
+    // one device is destroyed per Problem-3 run (hw5.cu:289-309): the kernels keep a single dead body
+    if (s->kind == NB_SCN_MISSILE && s->n_watch > 1) return NB_ERR_INVALID;
     if (s->planet < 0 || s->planet >= c->n || s->asteroid < 0 || s->asteroid >= c->n) return NB_ERR_INVALID;
     if (s->last_step < s->first_step) return NB_ERR_INVALID;
     for (int k = 0; k < s->n_watch; ++k)
         if (s->watch[k] < 0 || s->watch[k] >= c->n) return NB_ERR_INVALID;
     if (s->engine < 0 || s->engine > 2) return NB_ERR_INVALID;
     if (s->engine == 2 && c->n > SMALL_N_MAX) return NB_ERR_INVALID;
-    if (int rc = bind(c)) return rc;
+    return NB_OK;
+}
 
-    const size_t n = (size_t)c->n;
+F64Scenario device_scenario(const nb_context* c, const nb_scenario* s) {
     F64Scenario sc{};
     sc.kind = s->kind;
     sc.planet = s->planet;
@@ -477,64 +497,124 @@ int nb_run_scenario(nb_context* c, const nb_scenario* s, nb_scenario_result* res
     sc.n_watch = (s->kind == NB_SCN_MIN_DIST) ? 0 : s->n_watch;
     for (int k = 0; k < sc.n_watch; ++k) sc.watch[k] = s->watch[k];
     sc.destroy_on_arrival = (s->kind == NB_SCN_MISSILE);
-    sc.R2 = s->planet_radius * s->planet_radius;            // nbody.cc:134
-    sc.missile_dstep = s->missile_speed * c->cfg.dt;        // hw5.cu:274
+    sc.R2 = s->planet_radius * s->planet_radius;      // nbody.cc:134
+    sc.missile_dstep = s->missile_speed * c->cfg.dt;  // hw5.cu:274
+    return sc;
+}
 
-    const bool want_snap = (s->kind == NB_SCN_FIRST_HIT) && sc.n_watch > 0;
-    if (want_snap && c->snap_slots < sc.n_watch) {
-        free_dev(c->snap_q);
-        free_dev(c->snap_v);
-        NB_HIP(c, hipMalloc(&c->snap_q, (size_t)sc.n_watch * 3 * n * sizeof(double)));
-        NB_HIP(c, hipMalloc(&c->snap_v, (size_t)sc.n_watch * 3 * n * sizeof(double)));
-        c->snap_slots = sc.n_watch;
+bool wants_snapshots(const nb_scenario* s) {
+    return s->kind == NB_SCN_FIRST_HIT && s->n_watch > 0 && !(s->flags & NB_SCN_NO_SNAPSHOT);
+}
+
+int ensure_snapshots(nb_context* c, int n_watch) {
+    if (c->snap_slots >= n_watch) return NB_OK;
+    const size_t n = (size_t)c->n;
+    free_dev(c->snap_q);
+    free_dev(c->snap_v);
+    c->snap_slots = 0;
+    NB_HIP(c, hipMalloc(&c->snap_q, (size_t)n_watch * 3 * n * sizeof(double)));
+    NB_HIP(c, hipMalloc(&c->snap_v, (size_t)n_watch * 3 * n * sizeof(double)));
+    c->snap_slots = n_watch;
+    return NB_OK;
+}
+
+// K3 reads |sin(step*dt/6000)| by step index from a host-computed (glibc) table and prefetches two steps ahead
+int ensure_fst_table(nb_context* c, int last_step) {
+    const int need = last_step + 3;
+    if (c->fst_len < need) {
+        free_dev(c->fst_dev);
+        c->fst_len = 0;
+        std::vector<double> tab((size_t)need);
+        for (int k = 0; k < need; ++k) tab[(size_t)k] = fst_of(k, c->cfg.dt);
+        NB_HIP(c, hipMalloc(&c->fst_dev, (size_t)need * sizeof(double)));
+        NB_HIP(c, hipMemcpy(c->fst_dev, tab.data(), (size_t)need * sizeof(double), hipMemcpyHostToDevice));
+        c->fst_len = need;
     }
+    return NB_OK;
+}
 
+// K3 reports the index of the last state it computed through a device word + its pinned host copy
+int ensure_done_word(nb_context* c) {
+    if (!c->done_dev) {
+        NB_HIP(c, hipMalloc(&c->done_dev, sizeof(int)));
+        NB_HIP(c, hipHostMalloc(&c->done_host, sizeof(int)));
+    }
+    return NB_OK;
+}
+
+// `err` = the context that reports a HIP failure (the batch leader when several contexts share a stream)
+int reset_monitor(nb_context* err, nb_context* c, hipStream_t stream) {
     F64Monitor* mh = c->mon_host;
     mh->min_d2 = std::numeric_limits<double>::infinity();
     mh->hit_step = -2;
     for (int k = 0; k < MAX_WATCH; ++k) mh->arrival_step[k] = -2;
-    NB_HIP(c, hipMemcpyAsync(c->mon, mh, sizeof(F64Monitor), hipMemcpyHostToDevice, c->stream));
+    for (int k = 0; k < NB_MAX_WATCH; ++k) c->snap_arrival[k] = -2;
+    NB_HIP(err, hipMemcpyAsync(c->mon, mh, sizeof(F64Monitor), hipMemcpyHostToDevice, stream));
+    return NB_OK;
+}
+
+void fill_result(nb_context* c, const nb_scenario* s, const F64Scenario& sc, int steps_done, nb_scenario_result* res) {
+    const F64Monitor* mh = c->mon_host;
+    memset(res, 0, sizeof *res);
+    res->min_dist2 = mh->min_d2;
+    res->hit_step = mh->hit_step;
+    res->steps_done = steps_done;
+    for (int k = 0; k < NB_MAX_WATCH; ++k) {
+        res->arrival_step[k] = (k < sc.n_watch) ? mh->arrival_step[k] : -2;
+        res->missile_cost[k] = (res->arrival_step[k] != -2)
+                                   ? 1e5 + 1e3 * ((res->arrival_step[k] + 1) * c->cfg.dt)  // hw5.cu:305 ; nbody.cc:19
+                                   : 0.0;
+        if (wants_snapshots(s)) c->snap_arrival[k] = res->arrival_step[k];  // which snapshot slots hold a state
+    }
+}
+
+F64SmallArgs small_args(nb_context* c, const F64Scenario& sc, bool want_snap, const double* fst_table, int at, int to,
+                        int last_step) {
+    F64SmallArgs k{};
+    k.q = c->q[c->cur];
+    k.v = c->v;
+    k.m = c->m;
+    k.coef = c->coef;
+    k.fst = fst_table;
+    k.snap_q = want_snap ? c->snap_q : nullptr;
+    k.snap_v = want_snap ? c->snap_v : nullptr;
+    k.mon = c->mon;
+    k.steps_done = c->done_dev;
+    k.n = c->n;
+    k.first_step = at;
+    k.last_step = to;
+    k.final_monitor = (to == last_step);
+    k.G = c->cfg.G;
+    k.eps2 = c->cfg.eps * c->cfg.eps;
+    k.dt = c->cfg.dt;
+    k.scn = sc;
+    return k;
+}
+
+constexpr int SMALL_CHUNK = 50000;  // K3: steps per launch, so that the host can stop relaunching after a hit
+
+int run_scenario_impl(nb_context* c, const nb_scenario* s, nb_scenario_result* res) {
+    if (int rc = check_scenario(c, s)) return rc;
+    if (int rc = bind(c)) return rc;
+    const F64Scenario sc = device_scenario(c, s);
+    const bool want_snap = wants_snapshots(s);
+    if (want_snap)
+        if (int rc = ensure_snapshots(c, sc.n_watch)) return rc;
+    if (int rc = reset_monitor(c, c, c->stream)) return rc;
     NB_HIP(c, hipStreamSynchronize(c->stream));
+    F64Monitor* mh = c->mon_host;
 
     const bool small_engine = (s->engine == 2) || (s->engine == 0 && c->n <= SMALL_N_MAX);
     if (small_engine) {
         // K3: the whole step loop inside one single-workgroup kernel, in chunks so the host can stop after a hit
-        const int need = s->last_step + 3;  // the kernel prefetches |sin| two steps ahead
-        if (c->fst_len < need) {
-            free_dev(c->fst_dev);
-            std::vector<double> tab((size_t)need);
-            for (int k = 0; k < need; ++k) tab[(size_t)k] = fst_of(k, c->cfg.dt);
-            NB_HIP(c, hipMalloc(&c->fst_dev, (size_t)need * sizeof(double)));
-            NB_HIP(c, hipMemcpy(c->fst_dev, tab.data(), (size_t)need * sizeof(double), hipMemcpyHostToDevice));
-            c->fst_len = need;
-        }
-        if (!c->done_dev) {
-            NB_HIP(c, hipMalloc(&c->done_dev, sizeof(int)));
-            NB_HIP(c, hipHostMalloc(&c->done_host, sizeof(int)));
-        }
-        const int chunk = 50000;
+        if (int rc = ensure_fst_table(c, s->last_step)) return rc;
+        if (int rc = ensure_done_word(c)) return rc;
         int at = s->first_step;
         bool first = true;
         while (first || at < s->last_step) {
             first = false;
-            F64SmallArgs k{};
-            k.q = c->q[c->cur];
-            k.v = c->v;
-            k.m = c->m;
-            k.coef = c->coef;
-            k.fst = c->fst_dev;
-            k.snap_q = want_snap ? c->snap_q : nullptr;
-            k.snap_v = want_snap ? c->snap_v : nullptr;
-            k.mon = c->mon;
-            k.steps_done = c->done_dev;
-            k.n = c->n;
-            k.first_step = at;
-            k.last_step = std::min(s->last_step, at + chunk);
-            k.final_monitor = (k.last_step == s->last_step);
-            k.G = c->cfg.G;
-            k.eps2 = c->cfg.eps * c->cfg.eps;
-            k.dt = c->cfg.dt;
-            k.scn = sc;
+            const F64SmallArgs k = small_args(c, sc, want_snap, c->fst_dev, at, std::min(s->last_step, at + SMALL_CHUNK),
+                                              s->last_step);
             NB_HIP(c, (hipError_t)launch_f64_small(k, c->stream));
             NB_HIP(c, hipMemcpyAsync(mh, c->mon, sizeof(F64Monitor), hipMemcpyDeviceToHost, c->stream));
             NB_HIP(c, hipMemcpyAsync(c->done_host, c->done_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -542,14 +622,7 @@ int nb_run_scenario(nb_context* c, const nb_scenario* s, nb_scenario_result* res
             at = *c->done_host;
             if (mh->hit_step != -2 || at < k.last_step) break;
         }
-        memset(res, 0, sizeof *res);
-        res->min_dist2 = mh->min_d2;
-        res->hit_step = mh->hit_step;
-        res->steps_done = at;
-        for (int k = 0; k < NB_MAX_WATCH; ++k) {
-            res->arrival_step[k] = (k < sc.n_watch) ? mh->arrival_step[k] : -2;
-            res->missile_cost[k] = (res->arrival_step[k] != -2) ? 1e5 + 1e3 * ((res->arrival_step[k] + 1) * c->cfg.dt) : 0.0;
-        }
+        fill_result(c, s, sc, at, res);
         return NB_OK;
     }
 
@@ -583,38 +656,25 @@ int nb_run_scenario(nb_context* c, const nb_scenario* s, nb_scenario_result* res
     }
     NB_HIP(c, hipMemcpyAsync(mh, c->mon, sizeof(F64Monitor), hipMemcpyDeviceToHost, c->stream));
     NB_HIP(c, hipStreamSynchronize(c->stream));
-
-    memset(res, 0, sizeof *res);
-    res->min_dist2 = mh->min_d2;
-    res->hit_step = mh->hit_step;
-    res->steps_done = stopped ? step : s->last_step;
-    for (int k = 0; k < NB_MAX_WATCH; ++k) {
-        res->arrival_step[k] = (k < sc.n_watch) ? mh->arrival_step[k] : -2;
-        res->missile_cost[k] = (res->arrival_step[k] != -2)
-                                   ? 1e5 + 1e3 * ((res->arrival_step[k] + 1) * c->cfg.dt)  // hw5.cu:305 ; nbody.cc:19
-                                   : 0.0;
-    }
+    fill_result(c, s, sc, stopped ? step : s->last_step, res);
     return NB_OK;
 }
 
-// Several scenarios of equally sized systems in lock step: ONE launch per step serves all of them (blockIdx.y), each
-// with its own state, step index, |sin| and monitor.  What hw5.cu does with one host thread + launch stream per
-// device (hw5.cu:587-588), without the streams contending for the command processor.
-int nb_run_scenarios_batched(nb_context** ctxs, const nb_scenario* scns, nb_scenario_result* results, int count) {
+// Several scenarios of equally sized systems on one GPU, all driven by ONE stream (that of ctxs[0]):
+//  * small systems (K3): one launch whose workgroup k runs scenario k to its end, relaunched per SMALL_CHUNK steps
+//    for the slots still running;
+//  * otherwise (K2): lock step, ONE launch per step serves all of them (blockIdx.y), each with its own state, step
+//    index, |sin| and monitor — what hw5.cu does with one host thread + launch stream per scenario
+//    (hw5.cu:564-567,587-588), without the streams contending for the command processor.
+int run_batched_impl(nb_context** ctxs, const nb_scenario* scns, nb_scenario_result* results, int count) {
     if (!ctxs || !scns || !results || count <= 0 || count > MAX_BATCH) return NB_ERR_INVALID;
     nb_context* c0 = ctxs[0];
+    if (!c0) return NB_ERR_INVALID;
     for (int b = 0; b < count; ++b) {
         nb_context* c = ctxs[b];
-        const nb_scenario* s = &scns[b];
-        if (!c || c->cfg.precision != NB_F64 || c->n != c0->n || c->cfg.device != c0->cfg.device) return NB_ERR_INVALID;
-        if (!c->have_state) return NB_ERR_STATE;
-        if (s->kind < NB_SCN_MIN_DIST || s->kind > NB_SCN_MISSILE || s->n_watch < 0 || s->n_watch > NB_MAX_WATCH)
-            return NB_ERR_INVALID;
-        if (s->planet < 0 || s->planet >= c->n || s->asteroid < 0 || s->asteroid >= c->n || s->last_step < s->first_step)
-            return NB_ERR_INVALID;
-        if (s->kind == NB_SCN_FIRST_HIT && s->n_watch > 0) return NB_ERR_INVALID;  // snapshots: use nb_run_scenario
-        for (int k = 0; k < s->n_watch; ++k)
-            if (s->watch[k] < 0 || s->watch[k] >= c->n) return NB_ERR_INVALID;
+        if (!c || c->n != c0->n || c->cfg.device != c0->cfg.device) return NB_ERR_INVALID;
+        if (c->cfg.dt != c0->cfg.dt || scns[b].engine != scns[0].engine) return NB_ERR_INVALID;
+        if (int rc = check_scenario(c, &scns[b])) return rc;
         for (int b2 = 0; b2 < b; ++b2)
             if (ctxs[b2] == c) return NB_ERR_INVALID;
     }
@@ -622,28 +682,58 @@ int nb_run_scenarios_batched(nb_context** ctxs, const nb_scenario* scns, nb_scen
     hipStream_t stream = c0->stream;
 
     F64Scenario sc[MAX_BATCH];
+    bool snap[MAX_BATCH];
     int done_at[MAX_BATCH];  // -1 while running; else the index of the last state computed
     for (int b = 0; b < count; ++b) {
         nb_context* c = ctxs[b];
-        const nb_scenario* s = &scns[b];
-        sc[b] = F64Scenario{};
-        sc[b].kind = s->kind;
-        sc[b].planet = s->planet;
-        sc[b].asteroid = s->asteroid;
-        sc[b].n_watch = (s->kind == NB_SCN_MIN_DIST) ? 0 : s->n_watch;
-        for (int k = 0; k < sc[b].n_watch; ++k) sc[b].watch[k] = s->watch[k];
-        sc[b].destroy_on_arrival = (s->kind == NB_SCN_MISSILE);
-        sc[b].R2 = s->planet_radius * s->planet_radius;
-        sc[b].missile_dstep = s->missile_speed * c->cfg.dt;
+        sc[b] = device_scenario(c, &scns[b]);
+        snap[b] = wants_snapshots(&scns[b]);
+        if (snap[b])
+            if (int rc = ensure_snapshots(c, sc[b].n_watch)) { snprintf(c0->err, sizeof c0->err, "%s", c->err); return rc; }
         done_at[b] = -1;
-        F64Monitor* mh = c->mon_host;
-        mh->min_d2 = std::numeric_limits<double>::infinity();
-        mh->hit_step = -2;
-        for (int k = 0; k < MAX_WATCH; ++k) mh->arrival_step[k] = -2;
         NB_HIP(c0, hipStreamSynchronize(c->stream));  // earlier work of this context (uploads) is complete
-        NB_HIP(c0, hipMemcpyAsync(c->mon, mh, sizeof(F64Monitor), hipMemcpyHostToDevice, stream));
+        if (int rc = reset_monitor(c0, c, stream)) return rc;
     }
     NB_HIP(c0, hipStreamSynchronize(stream));
+
+    const bool small_engine = (scns[0].engine == 2) || (scns[0].engine == 0 && c0->n <= SMALL_N_MAX);
+    if (small_engine) {
+        int max_last = 0, at[MAX_BATCH];
+        for (int b = 0; b < count; ++b) {
+            max_last = std::max(max_last, scns[b].last_step);
+            at[b] = scns[b].first_step;
+            if (int rc = ensure_done_word(ctxs[b])) { snprintf(c0->err, sizeof c0->err, "%s", ctxs[b]->err); return rc; }
+        }
+        if (int rc = ensure_fst_table(c0, max_last)) return rc;  // same dt everywhere: one table serves the batch
+        int running = count;
+        while (running > 0) {
+            F64SmallBatchArgs args{};
+            args.count = count;
+            int to[MAX_BATCH];
+            for (int b = 0; b < count; ++b) {
+                if (done_at[b] >= 0) continue;  // finished slot: item[b].n stays 0
+                to[b] = std::min(scns[b].last_step, at[b] + SMALL_CHUNK);
+                args.item[b] = small_args(ctxs[b], sc[b], snap[b], c0->fst_dev, at[b], to[b], scns[b].last_step);
+            }
+            NB_HIP(c0, (hipError_t)launch_f64_small_batched(args, c0->n, stream));
+            for (int b = 0; b < count; ++b) {
+                if (done_at[b] >= 0) continue;
+                NB_HIP(c0, hipMemcpyAsync(ctxs[b]->mon_host, ctxs[b]->mon, sizeof(F64Monitor), hipMemcpyDeviceToHost, stream));
+                NB_HIP(c0, hipMemcpyAsync(ctxs[b]->done_host, ctxs[b]->done_dev, sizeof(int), hipMemcpyDeviceToHost, stream));
+            }
+            NB_HIP(c0, hipStreamSynchronize(stream));
+            for (int b = 0; b < count; ++b) {
+                if (done_at[b] >= 0) continue;
+                at[b] = *ctxs[b]->done_host;
+                if (ctxs[b]->mon_host->hit_step != -2 || at[b] < to[b] || at[b] >= scns[b].last_step) {
+                    done_at[b] = at[b];
+                    --running;
+                }
+            }
+        }
+        for (int b = 0; b < count; ++b) fill_result(ctxs[b], &scns[b], sc[b], done_at[b], &results[b]);
+        return NB_OK;
+    }
 
     const int sync_every = scns[0].sync_every > 0 ? scns[0].sync_every : 2000;
     int running = count;
@@ -656,6 +746,8 @@ int nb_run_scenarios_batched(nb_context** ctxs, const nb_scenario* scns, nb_scen
             const int step = scns[b].first_step + t;
             F64Args a = base_args(c, step);
             a.scn = sc[b];
+            a.snap_q = snap[b] ? c->snap_q : nullptr;
+            a.snap_v = snap[b] ? c->snap_v : nullptr;
             if (step > scns[b].last_step) {  // the state last_step exists: only its monitor is left
                 a.do_update = 0;
                 done_at[b] = scns[b].last_step;
@@ -681,24 +773,38 @@ int nb_run_scenarios_batched(nb_context** ctxs, const nb_scenario* scns, nb_scen
     for (int b = 0; b < count; ++b)
         NB_HIP(c0, hipMemcpyAsync(ctxs[b]->mon_host, ctxs[b]->mon, sizeof(F64Monitor), hipMemcpyDeviceToHost, stream));
     NB_HIP(c0, hipStreamSynchronize(stream));
-    for (int b = 0; b < count; ++b) {
-        nb_context* c = ctxs[b];
-        nb_scenario_result* res = &results[b];
-        memset(res, 0, sizeof *res);
-        res->min_dist2 = c->mon_host->min_d2;
-        res->hit_step = c->mon_host->hit_step;
-        res->steps_done = done_at[b];
-        for (int k = 0; k < NB_MAX_WATCH; ++k) {
-            res->arrival_step[k] = (k < sc[b].n_watch) ? c->mon_host->arrival_step[k] : -2;
-            res->missile_cost[k] = (res->arrival_step[k] != -2) ? 1e5 + 1e3 * ((res->arrival_step[k] + 1) * c->cfg.dt) : 0.0;
-        }
-    }
+    for (int b = 0; b < count; ++b) fill_result(ctxs[b], &scns[b], sc[b], done_at[b], &results[b]);
     return NB_OK;
 }
 
-int nb_restore_snapshot(nb_context* dst, nb_context* src, int slot) {
+}  // namespace
+
+extern "C" {
+
+int nb_run_scenario(nb_context* c, const nb_scenario* s, nb_scenario_result* res) {
+    if (!c || !s || !res) return NB_ERR_INVALID;
+    try {
+        return run_scenario_impl(c, s, res);
+    } catch (...) {  // std::bad_alloc from the host-side tables: nothing crosses the C boundary
+        return NB_ERR_NOMEM;
+    }
+}
+
+int nb_run_scenarios_batched(nb_context** ctxs, const nb_scenario* scns, nb_scenario_result* results, int count) {
+    try {
+        return run_batched_impl(ctxs, scns, results, count);
+    } catch (...) {
+        return NB_ERR_NOMEM;
+    }
+}
+
+static int nb_restore_snapshot_impl(nb_context* dst, nb_context* src, int slot) {
     if (!dst || !src || slot < 0 || slot >= src->snap_slots) return NB_ERR_INVALID;
     if (dst->n != src->n || dst->cfg.precision != NB_F64 || src->cfg.precision != NB_F64) return NB_ERR_INVALID;
+    if (src->snap_arrival[slot] == -2) {  // that device's missile never arrived: the slot is uninitialised memory
+        snprintf(dst->err, sizeof dst->err, "snapshot slot %d holds no state (no missile arrival recorded)", slot);
+        return NB_ERR_STATE;
+    }
     const size_t n = (size_t)src->n;
     std::vector<double> q(3 * n), v(3 * n);
     if (int rc = bind(src)) return rc;
@@ -708,81 +814,326 @@ int nb_restore_snapshot(nb_context* dst, nb_context* src, int slot) {
                         src->m_host.data(), src->dev_host.data());
 }
 
+int nb_set_state(nb_context* c, const double* qx, const double* qy, const double* qz, const double* vx,
+                 const double* vy, const double* vz, const double* m, const uint8_t* is_device) {
+    try {
+        return nb_set_state_impl(c, qx, qy, qz, vx, vy, vz, m, is_device);
+    } catch (...) {  // std::bad_alloc from the host staging vectors
+        return NB_ERR_NOMEM;
+    }
+}
+
+int nb_get_state(nb_context* c, double* qx, double* qy, double* qz, double* vx, double* vy, double* vz) {
+    try {
+        return nb_get_state_impl(c, qx, qy, qz, vx, vy, vz);
+    } catch (...) {  // std::bad_alloc from the host staging vectors
+        return NB_ERR_NOMEM;
+    }
+}
+
+int nb_accel(nb_context* c, int step, double* ax, double* ay, double* az) {
+    try {
+        return nb_accel_impl(c, step, ax, ay, az);
+    } catch (...) {  // std::bad_alloc from the host staging vectors
+        return NB_ERR_NOMEM;
+    }
+}
+
+int nb_restore_snapshot(nb_context* dst, nb_context* src, int slot) {
+    try {
+        return nb_restore_snapshot_impl(dst, src, slot);
+    } catch (...) {  // std::bad_alloc from the host staging vectors
+        return NB_ERR_NOMEM;
+    }
+}
+
 // ---------------------------------------------------------------- binary state files
+}  // extern "C"
+
 namespace {
-struct StateHeader {
+// version 1 (round 1): magic "NBODYST1", int64 n, int32 precision, int32 step, double G, eps, dt            (48 bytes)
+// version 2:           magic "NBODYST2", uint32 byte-order mark, int32 precision, int64 n, int32 step,
+//                      int32 planet, int32 asteroid, int32 reserved, double G, eps, dt                      (64 bytes)
+struct StateHeaderV1 {
     char magic[8];
     int64_t n;
     int32_t precision;
     int32_t step;
     double G, eps, dt;
 };
-const char kMagic[8] = {'N', 'B', 'O', 'D', 'Y', 'S', 'T', '1'};
+struct StateHeaderV2 {
+    char magic[8];
+    uint32_t bom;
+    int32_t precision;
+    int64_t n;
+    int32_t step;
+    int32_t planet, asteroid, reserved;
+    double G, eps, dt;
+};
+static_assert(sizeof(StateHeaderV1) == 48 && sizeof(StateHeaderV2) == 64, "on-disk layout");
+const char kMagic1[8] = {'N', 'B', 'O', 'D', 'Y', 'S', 'T', '1'};
+const char kMagic2[8] = {'N', 'B', 'O', 'D', 'Y', 'S', 'T', '2'};
+constexpr uint32_t kBom = 0x01020304u;
+
+struct FileCloser {
+    void operator()(FILE* f) const {
+        if (f) fclose(f);
+    }
+};
+using FilePtr = std::unique_ptr<FILE, FileCloser>;
+
+// header of either version; the stream is left at the first body array
+int read_header(FILE* f, nb_state_header* h) {
+    char magic[8];
+    if (fread(magic, 8, 1, f) != 1) return NB_ERR_IO;
+    memset(h, 0, sizeof *h);
+    if (memcmp(magic, kMagic1, 8) == 0) {
+        StateHeaderV1 v;
+        if (fread(&v.n, sizeof v - 8, 1, f) != 1) return NB_ERR_IO;
+        h->n = v.n; h->precision = v.precision; h->step = v.step;
+        h->planet = h->asteroid = -1;
+        h->G = v.G; h->eps = v.eps; h->dt = v.dt;
+    } else if (memcmp(magic, kMagic2, 8) == 0) {
+        StateHeaderV2 v;
+        if (fread(&v.bom, sizeof v - 8, 1, f) != 1) return NB_ERR_IO;
+        if (v.bom != kBom) return set_error(NB_ERR_IO, "state file written with another byte order");
+        h->n = v.n; h->precision = v.precision; h->step = v.step;
+        h->planet = v.planet; h->asteroid = v.asteroid;
+        h->G = v.G; h->eps = v.eps; h->dt = v.dt;
+    } else {
+        return set_error(NB_ERR_IO, "not an NBODYST1/NBODYST2 state file");
+    }
+    if (h->n <= 0 || h->precision < NB_F64 || h->precision > NB_F32_ACC64) return set_error(NB_ERR_IO, "corrupt state header");
+    return NB_OK;
+}
+
+int write_state(const char* path, const nb_state_header* h, const double* const q[6], const double* m,
+                const uint8_t* is_device) {
+    if (h->n <= 0) return NB_ERR_INVALID;
+    const size_t n = (size_t)h->n;
+    StateHeaderV2 v{};
+    memcpy(v.magic, kMagic2, 8);
+    v.bom = kBom;
+    v.precision = h->precision;
+    v.n = h->n;
+    v.step = h->step;
+    v.planet = h->planet;
+    v.asteroid = h->asteroid;
+    v.G = h->G; v.eps = h->eps; v.dt = h->dt;
+    FILE* f = fopen(path, "wb");
+    if (!f) return set_error(NB_ERR_IO, "cannot open state file for writing");
+    bool ok = fwrite(&v, sizeof v, 1, f) == 1;
+    for (int k = 0; k < 6 && ok; ++k) ok = fwrite(q[k], sizeof(double), n, f) == n;
+    ok = ok && fwrite(m, sizeof(double), n, f) == n;
+    if (ok && is_device) ok = fwrite(is_device, 1, n, f) == n;
+    else if (ok) {
+        std::vector<uint8_t> z(n, 0);
+        ok = fwrite(z.data(), 1, n, f) == n;
+    }
+    ok = (fclose(f) == 0) && ok;
+    return ok ? NB_OK : set_error(NB_ERR_IO, "short write to state file");
+}
+
+int read_state_impl(const char* path, nb_state_header* hdr, int64_t capacity, double* qx, double* qy, double* qz,
+                    double* vx, double* vy, double* vz, double* m, uint8_t* is_device) {
+    if (!path || !hdr) return NB_ERR_INVALID;
+    FilePtr f(fopen(path, "rb"));
+    if (!f) return set_error(NB_ERR_IO, "cannot open state file");
+    if (int rc = read_header(f.get(), hdr)) return rc;
+    if (!qx && !qy && !qz && !vx && !vy && !vz && !m && !is_device) return NB_OK;  // header only
+    if (!qx || !qy || !qz || !vx || !vy || !vz || !m) return NB_ERR_INVALID;
+    if (capacity < hdr->n) return set_error(NB_ERR_INVALID, "arrays too small for the bodies in the state file");
+    const size_t n = (size_t)hdr->n;
+    double* arr[7] = {qx, qy, qz, vx, vy, vz, m};
+    for (double* a : arr)
+        if (fread(a, sizeof(double), n, f.get()) != n) return set_error(NB_ERR_IO, "truncated state file");
+    if (is_device) {
+        if (fread(is_device, 1, n, f.get()) != n) return set_error(NB_ERR_IO, "truncated state file");
+    }
+    return NB_OK;
+}
+
 }  // namespace
 
+extern "C" {
+
 int nb_state_file_info(const char* path, int64_t* n, int* precision, int* step) {
-    if (!path) return NB_ERR_INVALID;
-    FILE* f = fopen(path, "rb");
-    if (!f) return NB_ERR_IO;
-    StateHeader h;
-    const bool ok = fread(&h, sizeof h, 1, f) == 1 && memcmp(h.magic, kMagic, 8) == 0 && h.n > 0;
-    fclose(f);
-    if (!ok) return NB_ERR_IO;
+    nb_state_header h;
+    if (int rc = read_state_impl(path, &h, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr)) return rc;
     if (n) *n = h.n;
     if (precision) *precision = h.precision;
     if (step) *step = h.step;
     return NB_OK;
 }
 
+int nb_read_state_file(const char* path, nb_state_header* hdr, int64_t capacity, double* qx, double* qy, double* qz,
+                       double* vx, double* vy, double* vz, double* m, uint8_t* is_device) {
+    return read_state_impl(path, hdr, capacity, qx, qy, qz, vx, vy, vz, m, is_device);
+}
+
+int nb_write_state_file(const char* path, const nb_state_header* hdr, const double* qx, const double* qy,
+                        const double* qz, const double* vx, const double* vy, const double* vz, const double* m,
+                        const uint8_t* is_device) {
+    if (!path || !hdr || !qx || !qy || !qz || !vx || !vy || !vz || !m) return NB_ERR_INVALID;
+    if (hdr->precision < NB_F64 || hdr->precision > NB_F32_ACC64) return NB_ERR_INVALID;
+    const double* q[6] = {qx, qy, qz, vx, vy, vz};
+    try {
+        return write_state(path, hdr, q, m, is_device);
+    } catch (...) {
+        return NB_ERR_NOMEM;
+    }
+}
+
 int nb_save_state(nb_context* c, const char* path, int step) {
     if (!c || !path) return NB_ERR_INVALID;
     if (!c->have_state) return NB_ERR_STATE;
-    const size_t n = (size_t)c->n;
-    std::vector<double> buf(6 * n);
-    if (int rc = nb_get_state(c, &buf[0], &buf[n], &buf[2 * n], &buf[3 * n], &buf[4 * n], &buf[5 * n])) return rc;
-    StateHeader h;
-    memcpy(h.magic, kMagic, 8);
-    h.n = c->n;
-    h.precision = c->cfg.precision;
-    h.step = step;
-    h.G = c->cfg.G;
-    h.eps = c->cfg.eps;
-    h.dt = c->cfg.dt;
-    FILE* f = fopen(path, "wb");
-    if (!f) return NB_ERR_IO;
-    bool ok = fwrite(&h, sizeof h, 1, f) == 1 && fwrite(buf.data(), sizeof(double), 6 * n, f) == 6 * n &&
-              fwrite(c->m_host.data(), sizeof(double), n, f) == n && fwrite(c->dev_host.data(), 1, n, f) == n;
-    ok = (fclose(f) == 0) && ok;
-    return ok ? NB_OK : NB_ERR_IO;
+    try {
+        const size_t n = (size_t)c->n;
+        std::vector<double> buf(6 * n);
+        if (int rc = nb_get_state(c, &buf[0], &buf[n], &buf[2 * n], &buf[3 * n], &buf[4 * n], &buf[5 * n])) return rc;
+        nb_state_header h{};
+        h.n = c->n;
+        h.precision = c->cfg.precision;
+        h.step = step;
+        h.planet = h.asteroid = -1;  // a context does not know the scenario's bodies (nb_write_state_file records them)
+        h.G = c->cfg.G;
+        h.eps = c->cfg.eps;
+        h.dt = c->cfg.dt;
+        const double* q[6] = {&buf[0], &buf[n], &buf[2 * n], &buf[3 * n], &buf[4 * n], &buf[5 * n]};
+        int rc = write_state(path, &h, q, c->m_host.data(), c->dev_host.data());
+        if (rc) snprintf(c->err, sizeof c->err, "%s", nb_last_error(nullptr));
+        return rc;
+    } catch (...) {
+        return NB_ERR_NOMEM;
+    }
 }
 
 int nb_load_state(nb_context* c, const char* path, int* step) {
     if (!c || !path) return NB_ERR_INVALID;
-    FILE* f = fopen(path, "rb");
-    if (!f) return NB_ERR_IO;
-    StateHeader h;
-    if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, kMagic, 8) != 0) {
-        fclose(f);
-        return NB_ERR_IO;
+    try {
+        nb_state_header h;
+        if (int rc = read_state_impl(path, &h, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr)) {
+            snprintf(c->err, sizeof c->err, "%s", nb_last_error(nullptr));
+            return rc;
+        }
+        // a checkpoint resumes the run it was taken from: same system size, arithmetic and integration parameters.
+        // (nb_read_state_file + nb_set_state is the explicit route for loading a state under other parameters.)
+        if (h.n != c->n || h.precision != c->cfg.precision || h.G != c->cfg.G || h.eps != c->cfg.eps || h.dt != c->cfg.dt) {
+            snprintf(c->err, sizeof c->err,
+                     "state file (n=%lld precision=%d G=%g eps=%g dt=%g) does not match the context (n=%d precision=%d "
+                     "G=%g eps=%g dt=%g)", (long long)h.n, h.precision, h.G, h.eps, h.dt, c->n, c->cfg.precision, c->cfg.G,
+                     c->cfg.eps, c->cfg.dt);
+            return NB_ERR_INVALID;
+        }
+        const size_t n = (size_t)c->n;
+        std::vector<double> buf(7 * n);
+        std::vector<uint8_t> dev(n);
+        if (int rc = read_state_impl(path, &h, (int64_t)n, &buf[0], &buf[n], &buf[2 * n], &buf[3 * n], &buf[4 * n], &buf[5 * n],
+                                     &buf[6 * n], dev.data())) {
+            snprintf(c->err, sizeof c->err, "%s", nb_last_error(nullptr));
+            return rc;
+        }
+        if (step) *step = h.step;
+        return nb_set_state(c, &buf[0], &buf[n], &buf[2 * n], &buf[3 * n], &buf[4 * n], &buf[5 * n], &buf[6 * n], dev.data());
+    } catch (...) {
+        return NB_ERR_NOMEM;
     }
-    if (h.n != c->n) {
-        fclose(f);
-        return NB_ERR_INVALID;
-    }
-    const size_t n = (size_t)c->n;
-    std::vector<double> buf(7 * n);
-    std::vector<uint8_t> dev(n);
-    const bool ok = fread(buf.data(), sizeof(double), 7 * n, f) == 7 * n && fread(dev.data(), 1, n, f) == n;
-    fclose(f);
-    if (!ok) return NB_ERR_IO;
-    if (step) *step = h.step;
-    return nb_set_state(c, &buf[0], &buf[n], &buf[2 * n], &buf[3 * n], &buf[4 * n], &buf[5 * n], &buf[6 * n], dev.data());
 }
 
 // ---------------------------------------------------------------- whole program
-int nb_solve(int n, int planet, int asteroid, const double* qx, const double* qy, const double* qz,
-             const double* vx, const double* vy, const double* vz, const double* m, const uint8_t* is_device,
-             const int* devices, int n_devices, nb_answer* out) {
+}  // extern "C"
+
+namespace {
+
+struct CtxDeleter {
+    void operator()(nb_context* c) const {
+        if (c) nb_destroy(c);
+    }
+};
+using CtxPtr = std::unique_ptr<nb_context, CtxDeleter>;
+
+struct ThreadJoiner {  // no exception may leave joinable threads behind (std::terminate)
+    std::vector<std::thread>& ts;
+    ~ThreadJoiner() {
+        for (auto& t : ts)
+            if (t.joinable()) t.join();
+    }
+};
+
+struct SolveSlot {  // one scenario of the program: P1, P2 or the Problem-3 run of one device
+    nb_scenario scn{};
+    nb_scenario_result res{};
+    int device_k = -1;  // MISSILE: index into the device list
+    bool zero_devices = false;  // P1: devices massless (nbody.cc:109-113)
+    int rc = NB_OK;
+    bool ran = false;
+    char err[256] = {0};
+};
+
+struct SolveInput {
+    int n, planet, asteroid;
+    const double *qx, *qy, *qz, *vx, *vy, *vz, *m;
+    const uint8_t* is_device;
+    const std::vector<double>* m_no_devices;
+};
+
+// all scenarios of `slots` on one GPU: contexts + one batched launch stream, at most `cap` scenarios at a time
+void run_group(const SolveInput& in, int gpu, const std::vector<SolveSlot*>& slots, int cap) {
+    try {
+        for (size_t at = 0; at < slots.size(); at += (size_t)cap) {
+            const int cnt = (int)std::min(slots.size() - at, (size_t)cap);
+            std::vector<CtxPtr> owned;
+            nb_context* ctxs[MAX_BATCH];
+            nb_scenario scns[MAX_BATCH];
+            nb_scenario_result ress[MAX_BATCH];
+            int rc = NB_OK;
+            for (int k = 0; k < cnt && !rc; ++k) {
+                SolveSlot* s = slots[at + k];
+                nb_config cfg;
+                nb_config_default(&cfg);
+                cfg.n = in.n;
+                cfg.device = gpu;
+                nb_context* c = nullptr;
+                rc = nb_create(&c, &cfg);
+                owned.emplace_back(c);
+                if (!rc)
+                    rc = nb_set_state(c, in.qx, in.qy, in.qz, in.vx, in.vy, in.vz,
+                                      s->zero_devices ? in.m_no_devices->data() : in.m, in.is_device);
+                ctxs[k] = c;
+                scns[k] = s->scn;
+            }
+            const nb_context* failed = (rc && !owned.empty()) ? owned.back().get() : nullptr;  // set-up failure
+            if (!rc) {
+                rc = nb_run_scenarios_batched(ctxs, scns, ress, cnt);
+                if (rc) failed = ctxs[0];  // the batch reports through its leader
+            }
+            for (int k = 0; k < cnt; ++k) {
+                if (failed) snprintf(slots[at + k]->err, sizeof slots[at + k]->err, "%s", nb_last_error(failed));
+                slots[at + k]->rc = rc;
+                slots[at + k]->res = ress[k];
+                slots[at + k]->ran = true;
+            }
+            if (rc) return;
+        }
+    } catch (...) {
+        for (SolveSlot* s : slots)
+            if (!s->ran) s->rc = NB_ERR_NOMEM;
+    }
+}
+
+// groups[g] runs on gpus[g]: inline for one GPU, one host thread per GPU otherwise (hw5.cu:564-567,587-588)
+void run_groups(const SolveInput& in, const std::vector<int>& gpus, const std::vector<std::vector<SolveSlot*>>& groups,
+                int cap) {
+    std::vector<std::thread> ts;
+    ThreadJoiner join{ts};
+    for (size_t g = 1; g < groups.size(); ++g)
+        if (!groups[g].empty()) ts.emplace_back([&, g] { run_group(in, gpus[g], groups[g], cap); });
+    if (!groups.empty() && !groups[0].empty()) run_group(in, gpus[0], groups[0], cap);
+}
+
+int solve_impl(int n, int planet, int asteroid, const double* qx, const double* qy, const double* qz, const double* vx,
+               const double* vy, const double* vz, const double* m, const uint8_t* is_device, const int* devices,
+               int n_devices, nb_answer* out) {
     if (n <= 0 || !qx || !qy || !qz || !vx || !vy || !vz || !m || !out) return NB_ERR_INVALID;
     if (planet < 0 || planet >= n || asteroid < 0 || asteroid >= n) return NB_ERR_INVALID;
     int ndev_gpu = 0;
@@ -792,22 +1143,31 @@ int nb_solve(int n, int planet, int asteroid, const double* qx, const double* qy
     else gpus.push_back(0);
     for (int g : gpus)
         if (g < 0 || g >= ndev_gpu) return NB_ERR_NO_DEVICE;
+    const size_t G = gpus.size();
 
     std::vector<int> dev_idx;
+    std::vector<double> m_no_devices(m, m + n);
     for (int i = 0; i < n; ++i)
-        if (is_device && is_device[i]) dev_idx.push_back(i);
-    if ((int)dev_idx.size() > NB_MAX_WATCH) return NB_ERR_INVALID;
+        if (is_device && is_device[i]) {
+            dev_idx.push_back(i);
+            m_no_devices[(size_t)i] = 0.0;
+        }
+    const size_t D = dev_idx.size();
+    if (D > NB_MAX_WATCH) return NB_ERR_INVALID;
+    const SolveInput in{n, planet, asteroid, qx, qy, qz, vx, vy, vz, m, is_device, &m_no_devices};
+    const bool trace = getenv("NB_SOLVE_TRACE") != nullptr;  // stderr timeline of the driver's phases
+    const auto t_start = std::chrono::steady_clock::now();
+    auto stamp = [&](const char* what) {
+        if (trace)
+            fprintf(stderr, "[nb_solve] %8.1f ms  %s\n",
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(), what);
+    };
+    stamp("HIP runtime up, input checked");
+
+    int cap = MAX_BATCH;  // scenarios per launch stream; NB_SOLVE_MAX_BATCH (2..8) lowers it (tests of the queueing path)
+    if (const char* e = getenv("NB_SOLVE_MAX_BATCH")) cap = std::min(MAX_BATCH, std::max(2, atoi(e)));
 
     const int n_steps = 200000;  // nbody.cc:10
-    auto make_ctx = [&](int gpu, nb_context** c) -> int {
-        nb_config cfg;
-        nb_config_default(&cfg);
-        cfg.n = n;
-        cfg.device = gpu;
-        int rc = nb_create(c, &cfg);
-        if (rc) return rc;
-        return nb_set_state(*c, qx, qy, qz, vx, vy, vz, m, is_device);
-    };
     auto base_scn = [&](int kind) {
         nb_scenario s{};
         s.kind = kind;
@@ -815,123 +1175,100 @@ int nb_solve(int n, int planet, int asteroid, const double* qx, const double* qy
         s.last_step = n_steps;
         s.planet = planet;
         s.asteroid = asteroid;
-        s.sync_every = 2000;
+        s.sync_every = 2000;    // hw5.cu:72
         s.planet_radius = 1e7;  // nbody.cc:17
         s.missile_speed = 1e6;  // nbody.cc:18
         return s;
     };
 
-    // Problem 1 (devices massless, nbody.cc:109-122) and Problem 2 (nbody.cc:124-138) are independent: run them
-    // concurrently, each on its own context/stream (and GPU when several are given) like hw5.cu:564-567.
-    nb_context *c1 = nullptr, *c2 = nullptr;
-    int rc1 = NB_OK, rc2 = NB_OK;
-    nb_scenario_result r1{}, r2{};
-    std::thread t1([&] {
-        rc1 = make_ctx(gpus[0], &c1);
-        for (size_t k = 0; k < dev_idx.size() && !rc1; ++k) rc1 = nb_set_mass(c1, dev_idx[k], 0.0);
-        if (!rc1) {
-            nb_scenario s = base_scn(NB_SCN_MIN_DIST);
-            rc1 = nb_run_scenario(c1, &s, &r1);
-        }
-    });
-    // Small systems (the persistent single-workgroup engine: one CU per scenario) also start every Problem-3 run NOW,
-    // from step 0, next to P1 and P2: until its missile arrives a device's run IS the P2 trajectory (the literal
-    // definition of hw5.cu:289-309 applied to every step), so nothing depends on P2's snapshots and the critical path
-    // of the whole program is one 200 000-step scenario.  Larger systems would only compete for CUs: they wait for
-    // P2 and resume from its arrival snapshots below (hw5.cu:265-287,482-489).
-    const size_t D = dev_idx.size();
-    // ... as long as every scenario gets a hardware queue of its own (HIP multiplexes streams onto 4 by default; with
-    // more, the long persistent launches queue behind each other — measured on b80/b90, 4 devices: slower than waiting)
-    int hw_queues = 4;  // ROCclr's default number of hardware queues per device; GPU_MAX_HW_QUEUES overrides it
-    if (const char* e = getenv("GPU_MAX_HW_QUEUES")) hw_queues = std::max(1, atoi(e));
-    const bool speculative_p3 = n <= SMALL_N_MAX && D > 0 && D + 2 <= (size_t)hw_queues * gpus.size();
-    std::vector<nb_context*> cs(D, nullptr);
-    std::vector<int> rcs(D, NB_OK);
-    std::vector<nb_scenario_result> rs(D);
-    std::vector<std::thread> ts;
-    if (speculative_p3)
-        for (size_t k = 0; k < D; ++k)
-            ts.emplace_back([&, k] {
-                rcs[k] = make_ctx(gpus[k % gpus.size()], &cs[k]);
-                if (rcs[k]) return;
-                nb_scenario s = base_scn(NB_SCN_MISSILE);
-                s.n_watch = 1;
-                s.watch[0] = dev_idx[k];
-                rcs[k] = nb_run_scenario(cs[k], &s, &rs[k]);
-            });
-    {
-        rc2 = make_ctx(gpus[gpus.size() > 1 ? 1 : 0], &c2);
-        if (!rc2) {
-            nb_scenario s = base_scn(NB_SCN_FIRST_HIT);
-            s.n_watch = (int)D;
-            for (size_t k = 0; k < D; ++k) s.watch[k] = dev_idx[k];
-            rc2 = nb_run_scenario(c2, &s, &r2);
-        }
+    // Every scenario of the program starts at step 0 and they all advance together — P1 (devices massless,
+    // nbody.cc:109-122), P2 (nbody.cc:124-138) and one Problem-3 run per gravity device (hw5.cu:289-309 applied from the
+    // first step: until its missile arrives a device's run IS the P2 trajectory, so nothing waits for P2's snapshots,
+    // hw5.cu:265-287,482-489).  On one GPU that is ONE launch stream: a single persistent launch with a workgroup per
+    // scenario for n <= 128, one batched launch per step otherwise; the critical path of the whole program is one
+    // 200 000-step scenario.  Several GPUs each take a share of the scenarios (the reference's task parallelism).
+    std::vector<SolveSlot> slots(2 + D);
+    slots[0].scn = base_scn(NB_SCN_MIN_DIST);
+    slots[0].zero_devices = true;
+    slots[1].scn = base_scn(NB_SCN_FIRST_HIT);
+    slots[1].scn.n_watch = (int)D;  // arrival steps order the devices that do not fit the first wave (hw5.cu:574-585)
+    for (size_t k = 0; k < D; ++k) slots[1].scn.watch[k] = dev_idx[k];
+    slots[1].scn.flags = NB_SCN_NO_SNAPSHOT;
+    for (size_t k = 0; k < D; ++k) {
+        SolveSlot& s = slots[2 + k];
+        s.scn = base_scn(NB_SCN_MISSILE);
+        s.scn.n_watch = 1;
+        s.scn.watch[0] = dev_idx[k];
+        s.device_k = (int)k;
     }
-
-    // Problem 3 (hw5.cu:568-602): every device whose missile arrives before the hit is tried from its snapshot,
-    // all of them concurrently; answer = feasible device with the smallest cost (strict <, hw5.cu:512).
-    out->hit_time_step = r2.hit_step;
+    const size_t first_wave = std::min(slots.size(), G * (size_t)cap);
+    {
+        std::vector<std::vector<SolveSlot*>> groups(G);
+        for (size_t i = 0; i < first_wave; ++i) groups[i % G].push_back(&slots[i]);
+        run_groups(in, gpus, groups, cap);
+    }
+    stamp("first wave of scenarios done");
+    if (slots[0].rc) return set_error(slots[0].rc, slots[0].err);
+    if (slots[1].rc) return set_error(slots[1].rc, slots[1].err);
+    out->min_dist = std::sqrt(slots[0].res.min_dist2);  // nbody.cc:121 takes min of sqrt; sqrt is monotone
+    out->hit_time_step = slots[1].res.hit_step;
     out->gravity_device_id = -1;
     out->missile_cost = 0;
+    if (slots[1].res.hit_step == -2) return NB_OK;  // no collision: nothing to prevent (hw5.cu:547-548,568)
+
+    // Problem 3 (hw5.cu:568-602): answer = feasible device of least cost (strict <, hw5.cu:512); cost is monotone in
+    // the arrival step, so a device can only improve on a feasible one by arriving earlier
+    int best_arrival = std::numeric_limits<int>::max();
     int rc3 = NB_OK;
-    if (!rc2 && r2.hit_step != -2 && !speculative_p3) {
-        std::vector<size_t> todo;
-        for (size_t k = 0; k < D; ++k) {
-            if (r2.arrival_step[k] == -2) continue;
-            nb_config cfg;
-            nb_config_default(&cfg);
-            cfg.n = n;
-            cfg.device = gpus.size() > 1 ? gpus[k % gpus.size()] : gpus[0];
-            rcs[k] = nb_create(&cs[k], &cfg);
-            if (!rcs[k]) rcs[k] = nb_restore_snapshot(cs[k], c2, (int)k);
-            if (!rcs[k]) todo.push_back(k);
+    auto account = [&](const SolveSlot& s) {
+        if (s.rc) { rc3 = set_error(s.rc, s.err); return; }
+        if (!s.ran) return;
+        // feasible: the missile arrived (before the P2 hit, hence before any hit of this run) and no hit followed
+        if (s.res.hit_step == -2 && s.res.arrival_step[0] != -2 && s.res.arrival_step[0] < best_arrival) {
+            best_arrival = s.res.arrival_step[0];
+            out->gravity_device_id = dev_idx[(size_t)s.device_k];
+            out->missile_cost = s.res.missile_cost[0];
         }
-        auto missile_scn = [&](size_t k) {
-            nb_scenario s = base_scn(NB_SCN_MISSILE);
-            s.first_step = r2.arrival_step[k];
-            s.n_watch = 1;
-            s.watch[0] = dev_idx[k];
-            return s;
-        };
-        if (gpus.size() == 1 && n > SMALL_N_MAX && todo.size() >= 2 && todo.size() <= (size_t)MAX_BATCH) {
-            // one GPU, per-step launches: all devices in ONE launch per step instead of one launch stream each
-            std::vector<nb_context*> bc;
-            std::vector<nb_scenario> bs;
-            for (size_t k : todo) { bc.push_back(cs[k]); bs.push_back(missile_scn(k)); }
-            std::vector<nb_scenario_result> br(todo.size());
-            int rcb = nb_run_scenarios_batched(bc.data(), bs.data(), br.data(), (int)todo.size());
-            for (size_t j = 0; j < todo.size(); ++j) { rcs[todo[j]] = rcb; rs[todo[j]] = br[j]; }
-        } else {
-            for (size_t k : todo)
-                ts.emplace_back([&, k] {
-                    nb_scenario s = missile_scn(k);
-                    rcs[k] = nb_run_scenario(cs[k], &s, &rs[k]);
-                });
+    };
+    for (size_t i = 2; i < first_wave; ++i) account(slots[i]);
+
+    // devices beyond the first wave: cheapest first — ascending arrival step on the P2 trajectory (hw5.cu:574-585) —
+    // and stop as soon as no remaining device can beat a feasible one (PROBLEM3_BREAK, hw5.cu:490-493)
+    std::vector<size_t> rest;
+    for (size_t i = first_wave; i < slots.size(); ++i)
+        if (slots[1].res.arrival_step[slots[i].device_k] != -2) rest.push_back(i);  // never arrives before the hit: fails
+    std::sort(rest.begin(), rest.end(), [&](size_t a, size_t b) {
+        return slots[1].res.arrival_step[slots[a].device_k] < slots[1].res.arrival_step[slots[b].device_k];
+    });
+    size_t at = 0;
+    while (at < rest.size() && !rc3) {
+        std::vector<std::vector<SolveSlot*>> groups(G);
+        size_t taken = 0;
+        for (; at < rest.size() && taken < G * (size_t)cap; ++at) {
+            if (slots[1].res.arrival_step[slots[rest[at]].device_k] >= best_arrival) { at = rest.size(); break; }
+            groups[taken % G].push_back(&slots[rest[at]]);
+            ++taken;
         }
+        if (!taken) break;
+        run_groups(in, gpus, groups, cap);
+        for (auto& g : groups)
+            for (SolveSlot* s : g) account(*s);
     }
-    for (auto& t : ts) t.join();
-    if (!rc2 && r2.hit_step != -2) {
-        double best = std::numeric_limits<double>::infinity();
-        for (size_t k = 0; k < D; ++k) {
-            if (rcs[k]) rc3 = rcs[k];
-            // feasible: the missile arrived (before the P2 hit, hence before any hit of this run) and no hit followed
-            if (cs[k] && !rcs[k] && rs[k].hit_step == -2 && rs[k].arrival_step[0] != -2 && rs[k].missile_cost[0] < best) {
-                best = rs[k].missile_cost[0];
-                out->gravity_device_id = dev_idx[k];
-                out->missile_cost = best;
-            }
-        }
-    }
-    for (size_t k = 0; k < D; ++k)
-        if (cs[k]) nb_destroy(cs[k]);
-    t1.join();
-    out->min_dist = std::sqrt(r1.min_dist2);  // nbody.cc:121 takes min of sqrt; sqrt is monotone
-    if (c1) nb_destroy(c1);
-    if (c2) nb_destroy(c2);
-    if (rc1) return rc1;
-    if (rc2) return rc2;
     return rc3;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nb_solve(int n, int planet, int asteroid, const double* qx, const double* qy, const double* qz,
+             const double* vx, const double* vy, const double* vz, const double* m, const uint8_t* is_device,
+             const int* devices, int n_devices, nb_answer* out) {
+    try {
+        return solve_impl(n, planet, asteroid, qx, qy, qz, vx, vy, vz, m, is_device, devices, n_devices, out);
+    } catch (...) {  // bad_alloc / system_error from the host-side containers and threads
+        return NB_ERR_NOMEM;
+    }
 }
 
 // ---------------------------------------------------------------- raw launches on caller-owned HBM
@@ -946,13 +1283,22 @@ static int check_launch(const nb_launch_f32* a, bool accel_only) {
     if (a->j_split > 1 && !a->workspace) return NB_ERR_INVALID;
     if (a->source_path < 0 || a->source_path > 2) return NB_ERR_INVALID;
     if (a->wg_size != 0 && a->wg_size != 256 && a->wg_size != 512 && a->wg_size != 1024) return NB_ERR_INVALID;
+    if (a->phase < NB_PHASE_WHOLE || a->phase > NB_PHASE_MIDDLE) return NB_ERR_INVALID;
+    if (a->src_begin || a->src_end) {  // a sub-range of the sources: whole 256-body tiles, except at the very end
+        if (a->src_begin < 0 || a->src_begin > a->src_end || a->src_end > a->n_src) return NB_ERR_INVALID;
+        if (a->src_begin % TILE || (a->src_end % TILE && a->src_end != a->n_src)) return NB_ERR_INVALID;
+    }
+    if (a->phase != NB_PHASE_WHOLE && (!a->workspace || a->workspace_bytes < nb_workspace_bytes_f32(a->n_tgt, a->acc64)))
+        return set_error(NB_ERR_INVALID, "a step cut into phases keeps its running sums in the workspace");
     return NB_OK;
 }
 
 static F32Plan resolve_plan(const nb_launch_f32* a) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    F32Plan p = plan_f32(a->n_tgt, a->n_src, cus, a->targets_per_lane, a->j_split, a->workspace != nullptr,
+    // slices are planned for the sources this launch covers (a phase of a step covers a sub-range)
+    const long n_cover = (a->src_begin || a->src_end) ? std::max<long>(1, a->src_end - a->src_begin) : a->n_src;
+    F32Plan p = plan_f32(a->n_tgt, n_cover, cus, a->targets_per_lane, a->j_split, a->workspace != nullptr,
                          a->source_path, a->wg_size);
     // the caller's workspace must hold SLICES_PER_LAUNCH partial records + running sum + compensation per target
     const size_t rec = a->acc64 ? sizeof(double4) : sizeof(float4);
@@ -972,6 +1318,9 @@ static F32Args to_args(const nb_launch_f32* a) {
     k.n_src = a->n_src;
     k.tgt_off = a->tgt_off;
     k.n_tgt = a->n_tgt;
+    k.src_begin = a->src_begin;
+    k.src_end = a->src_end;
+    k.phase = a->phase;
     k.eps2 = a->eps2;
     k.dt = a->dt;
     return k;
@@ -980,13 +1329,13 @@ static F32Args to_args(const nb_launch_f32* a) {
 int nb_launch_step_f32(const nb_launch_f32* a, void* hip_stream) {
     if (int rc = check_launch(a, false)) return rc;
     hipError_t e = (hipError_t)launch_f32(to_args(a), resolve_plan(a), a->acc64 != 0, false, (hipStream_t)hip_stream);
-    return e == hipSuccess ? NB_OK : NB_ERR_HIP;
+    return e == hipSuccess ? NB_OK : fail_hip(nullptr, e, "nb_launch_step_f32");
 }
 
 int nb_launch_accel_f32(const nb_launch_f32* a, void* hip_stream) {
     if (int rc = check_launch(a, true)) return rc;
     hipError_t e = (hipError_t)launch_f32(to_args(a), resolve_plan(a), a->acc64 != 0, true, (hipStream_t)hip_stream);
-    return e == hipSuccess ? NB_OK : NB_ERR_HIP;
+    return e == hipSuccess ? NB_OK : fail_hip(nullptr, e, "nb_launch_accel_f32");
 }
 
 const char* nb_kernel_name_f32(const nb_launch_f32* a, int accel_only) {

@@ -1,6 +1,7 @@
 #include "nbody_io.h"
 
 #include <cstdio>
+#include <cstring>
 #include <fstream>
 
 namespace nbio {
@@ -20,6 +21,15 @@ bool read_input(const char* filename, Input& in) {
         in.is_device[i] = in.type[i] == "device";
     }
     return true;
+}
+
+bool is_state_file(const char* filename) {
+    FILE* f = fopen(filename, "rb");
+    if (!f) return false;
+    char magic[8] = {0};
+    const bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, "NBODYST", 7) == 0;
+    fclose(f);
+    return ok;
 }
 
 bool write_output(const char* filename, double min_dist, int hit_time_step, int gravity_device_id,

@@ -18,6 +18,11 @@ struct Input {
 // be opened or is truncated.
 bool read_input(const char* filename, Input& in);
 
+// binary form of the same input: an NBODYST1/2 state file (include/nbody_amd.h).  is_state_file looks at the magic only;
+// read_state_input needs planet/asteroid recorded in the header (version 2) and links against libnbody_amd.
+bool is_state_file(const char* filename);
+bool read_state_input(const char* filename, Input& in);
+
 // three lines, scientific with 16 digits after the point (digits10 + 1): nbody.cc:43-48 == hw5.cu:135-140
 bool write_output(const char* filename, double min_dist, int hit_time_step, int gravity_device_id,
                   double missile_cost);

@@ -22,10 +22,18 @@ struct F32Args {
     void* partial;      // source-slice workspace, records float4 (double4 if acc64):
                         //   [SLICES_PER_LAUNCH][n_tgt] partial sums of one launch + [2][n_tgt] running sum / compensation
     long n_src, tgt_off, n_tgt;
+    long src_begin, src_end;  // sources of THIS launch sequence: [src_begin, src_end) (src_begin a multiple of 256);
+                              // 0,0 = all n_src.  A step may be cut into several such phases (own shard first, the
+                              // gathered remote shards later): the running sum in the workspace carries across them
+    int phase;                // F32_PHASE_* below
     long tiles_per_slice;  // SPLIT launches: 256-source tiles per source slice ...
     int slice0;            // ... and the index of the slice blockIdx.y == 0 works on
     float eps2, dt;
 };
+constexpr int F32_PHASE_WHOLE = 0;   // all of the step: start the sums, run the epilogue
+constexpr int F32_PHASE_FIRST = 1;   // start the sums, keep them in the workspace
+constexpr int F32_PHASE_LAST = 2;    // continue the sums, then the epilogue (store accelerations / kick-drift)
+constexpr int F32_PHASE_MIDDLE = 3;  // continue the sums, keep them
 constexpr int SLICES_PER_LAUNCH = 16;  // blockIdx.y extent of one split launch = partial-sum slots in the workspace
 constexpr int MAX_JSPLIT = 1024;       // source slices per step (processed SLICES_PER_LAUNCH at a time)
 struct F32Plan {
@@ -123,5 +131,10 @@ struct F64SmallArgs {
     F64Scenario scn;
 };
 int launch_f64_small(const F64SmallArgs& a, hipStream_t stream);
+struct F64SmallBatchArgs {  // one workgroup per scenario (blockIdx.x); item[k].n == 0 marks a finished slot
+    F64SmallArgs item[MAX_BATCH];
+    int count;
+};
+int launch_f64_small_batched(const F64SmallBatchArgs& b, int n, hipStream_t stream);
 
 }  // namespace nbk

@@ -165,18 +165,19 @@ __global__ __launch_bounds__(WGS, (WGS == 1024 ? 4 : WGS == 512 ? 2 : (P >= 4 ? 
         }
     };
 
-    // this workgroup's slice of the sources, in whole tiles (the last slice takes the ragged end)
-    const long ntiles_all = (a.n_src + TILE - 1) / TILE;
-    long k0 = 0, k1 = ntiles_all;
+    // this workgroup's slice of the launch's source range [src_begin, src_end), in whole tiles (the last slice takes the
+    // ragged end)
+    const long ntiles_all = (a.src_end + TILE - 1) / TILE;
+    long k0 = a.src_begin / TILE, k1 = ntiles_all;
     if (SPLIT) {
-        k0 = ((long)a.slice0 + blockIdx.y) * a.tiles_per_slice;
+        k0 += ((long)a.slice0 + blockIdx.y) * a.tiles_per_slice;
         k1 = k0 + a.tiles_per_slice < ntiles_all ? k0 + a.tiles_per_slice : ntiles_all;
         if (k0 > k1) k0 = k1;
     }
 
     if constexpr (SGPR) {
         const long j0 = k0 * TILE;
-        const long j1 = k1 * TILE < a.n_src ? k1 * TILE : a.n_src;
+        const long j1 = k1 * TILE < a.src_end ? k1 * TILE : a.src_end;
         constexpr int U = SGPR_BATCH;
         const long jb = j0 + (j1 - j0) / U * U;  // end of the whole batches
         if (jb > j0) {
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(WGS, (WGS == 1024 ? 4 : WGS == 512 ? 2 : (P >= 4 ? 
         auto load_src = [&](long k) -> float4 {
             long j = k * TILE + t;
             // bodies past the end are massless points at the origin: with eps2 > 0 they add exactly +0
-            return j < a.n_src ? a.src[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+            return j < a.src_end ? a.src[j] : make_float4(0.f, 0.f, 0.f, 0.f);
         };
         if (k0 < k1) {
             tile[0][t] = load_src(k0);
@@ -287,15 +288,22 @@ static int launch_one(const F32Args& a0, int js, hipStream_t stream) {
     const long per_block = (long)WGS * 2 * P;
     const long blocks = (a0.n_tgt + per_block - 1) / per_block;
     if (blocks <= 0 || blocks > 0x7fffffffL) return (int)hipErrorInvalidValue;
-    if (js <= 1) {
+    F32Args a = a0;
+    if (a.src_begin == 0 && a.src_end == 0) a.src_end = a.n_src;
+    if (a.src_begin % TILE || a.src_begin < 0 || a.src_end > a.n_src || a.src_begin > a.src_end) return (int)hipErrorInvalidValue;
+    if (js <= 1 && a.phase == F32_PHASE_WHOLE) {
         hipLaunchKernelGGL((nbody_force_f32<P, ACC64, ACCEL_ONLY, false, SGPR, WGS>), dim3((unsigned)blocks), dim3(WGS), 0,
-                           stream, a0);
+                           stream, a);
         return (int)hipGetLastError();
     }
-    if (!a0.partial) return (int)hipErrorInvalidValue;
-    F32Args a = a0;
-    const long ntiles = (a.n_src + TILE - 1) / TILE;
+    // source slices and/or a step cut into phases: partial sums go through the workspace
+    if (!a.partial) return (int)hipErrorInvalidValue;
+    if (js < 1) js = 1;
+    const bool starts = a.phase == F32_PHASE_WHOLE || a.phase == F32_PHASE_FIRST;
+    const bool ends = a.phase == F32_PHASE_WHOLE || a.phase == F32_PHASE_LAST;
+    const long ntiles = (a.src_end - a.src_begin + TILE - 1) / TILE;
     a.tiles_per_slice = (ntiles + js - 1) / js;
+    if (a.tiles_per_slice < 1) a.tiles_per_slice = 1;  // an empty range still runs its reducer (phase bookkeeping)
     const long rblocks = (a.n_tgt + WG - 1) / WG;
     for (int s0 = 0; s0 < js; s0 += SLICES_PER_LAUNCH) {  // 16 slices per launch; the running sum carries across
         const int gy = js - s0 < SLICES_PER_LAUNCH ? js - s0 : SLICES_PER_LAUNCH;
@@ -304,7 +312,7 @@ static int launch_one(const F32Args& a0, int js, hipStream_t stream) {
                            dim3(WGS), 0, stream, a);
         if (hipError_t e = hipGetLastError()) return (int)e;
         hipLaunchKernelGGL((nbody_reduce_update_f32<ACC64, ACCEL_ONLY>), dim3((unsigned)rblocks), dim3(WG), 0, stream, a, gy,
-                           (int)(s0 == 0), (int)(s0 + gy >= js));
+                           (int)(starts && s0 == 0), (int)(ends && s0 + gy >= js));
         if (hipError_t e = hipGetLastError()) return (int)e;
     }
     return (int)hipSuccess;

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(WG) void nbody_step_f64_batched(F64BatchArgs b) {
 // no grid barrier, every wave reaches the loop exit.  Same arithmetic as K2 (same G*m_eff rounding, same pair term,
 // same non-contracted kick/drift); only the summation split S differs.
 template <int S>
-__global__ __launch_bounds__(SMALL_N_MAX * S) void nbody_scenario_small_f64(F64SmallArgs a) {
+__device__ __forceinline__ void scenario_small_body(const F64SmallArgs& a) {
     __shared__ double sq[2][3][SMALL_N_MAX];
     __shared__ double sg[2][SMALL_N_MAX];
     const int t = threadIdx.x;
@@ -388,6 +388,22 @@ __global__ __launch_bounds__(SMALL_N_MAX * S) void nbody_scenario_small_f64(F64S
 }
 
 template <int S>
+__global__ __launch_bounds__(SMALL_N_MAX * S) void nbody_scenario_small_f64(F64SmallArgs a) {
+    scenario_small_body<S>(a);
+}
+
+// Up to MAX_BATCH scenarios of equally sized small systems in ONE launch: workgroup k runs scenario k from its own
+// state, with its own monitor, completely independently of the others (own LDS, no inter-workgroup traffic) — the whole
+// reference program (P1, P2 and one Problem-3 run per device, hw5.cu:564-567,587-588) is then a single kernel launch on
+// 2 + D compute units, with no host thread, stream or hardware queue per scenario.
+template <int S>
+__global__ __launch_bounds__(SMALL_N_MAX * S) void nbody_scenario_small_f64_batched(F64SmallBatchArgs b) {
+    const F64SmallArgs& a = b.item[blockIdx.x];
+    if (a.n <= 0) return;  // finished slot (workgroup-uniform)
+    scenario_small_body<S>(a);
+}
+
+template <int S>
 static int launch_small_s(const F64SmallArgs& a, int threads, hipStream_t stream) {
     hipLaunchKernelGGL((nbody_scenario_small_f64<S>), dim3(1), dim3(threads), 0, stream, a);
     return (int)hipGetLastError();
@@ -401,6 +417,14 @@ int launch_f64_small(const F64SmallArgs& a, hipStream_t stream) {
     constexpr int S = 8;
     int threads = ((a.n * S + 63) / 64) * 64;
     return launch_small_s<S>(a, threads, stream);
+}
+
+int launch_f64_small_batched(const F64SmallBatchArgs& b, int n, hipStream_t stream) {
+    if (n <= 0 || n > SMALL_N_MAX || b.count <= 0 || b.count > MAX_BATCH) return (int)hipErrorInvalidValue;
+    constexpr int S = 8;
+    const int threads = ((n * S + 63) / 64) * 64;
+    hipLaunchKernelGGL((nbody_scenario_small_f64_batched<S>), dim3(b.count), dim3(threads), 0, stream, b);
+    return (int)hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -1,0 +1,423 @@
+// nbody_sharded.cpp — index-sharded multi-GPU stepping behind the C ABI (nb_sharded_*): ONE process drives P GPUs of a
+// node, one HIP stream per GPU, one in-place RCCL all-gather of float4 positions per GPU per step over xGMI.
+//
+// The reference never shards bodies: each of its 2 GPUs holds the whole system and runs a different scenario
+// (hw5.cu:564-567,587-588).  This is the data-parallel scheme the north star adds:
+//   rank r of P owns targets [r*N/P, (r+1)*N/P): their velocities (and fp64 masters) live only on GPU r;
+//   every GPU holds ALL positions twice (ping-pong float4[N] {x,y,z,G*m}) because every target needs every source;
+//   per step and GPU: force + fused kick-drift (samples/nbody.cc:56-88) of the own targets from array `cur`, written into
+//   the own slot of array `nxt`, then ncclAllGather(sendbuff = nxt + r*N/P, recvbuff = nxt) — the in-place form.
+// With overlap a step is cut into phases: the own shard's sources first — they are final as soon as the
+// previous step's kernel has written them — while the all-gather of the other shards is still in flight on a second
+// stream; the remote sources follow once it has landed.  The running sums wait in the workspace between the phases.
+//
+// RCCL is loaded with dlopen when the first sharded system is created, so bin/hw5 and single-GPU users of libnbody_amd
+// never pay for (or depend on) librccl.  nbody_amd.distributed is the second host of the same scheme: one process per
+// GPU with torch.distributed.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/nbody_amd.h"
+#include "nbody_kernels.h"
+
+using namespace nbk;
+
+namespace {
+
+struct RcclApi {
+    void* handle = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+// loaded once per process; never unloaded (communicators may outlive any one sharded system)
+const RcclApi* rccl(char* err, size_t errlen) {
+    static RcclApi api;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+            api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (api.handle) break;
+        }
+        if (api.handle) {
+            api.CommInitAll = (decltype(api.CommInitAll))dlsym(api.handle, "ncclCommInitAll");
+            api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.handle, "ncclCommDestroy");
+            api.AllGather = (decltype(api.AllGather))dlsym(api.handle, "ncclAllGather");
+            api.GroupStart = (decltype(api.GroupStart))dlsym(api.handle, "ncclGroupStart");
+            api.GroupEnd = (decltype(api.GroupEnd))dlsym(api.handle, "ncclGroupEnd");
+            api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.handle, "ncclGetErrorString");
+        }
+    }
+    if (!api.handle || !api.CommInitAll || !api.CommDestroy || !api.AllGather || !api.GroupStart || !api.GroupEnd ||
+        !api.GetErrorString) {
+        snprintf(err, errlen, "cannot load RCCL (librccl.so.1): %s", api.handle ? "missing symbol" : dlerror());
+        return nullptr;
+    }
+    return &api;
+}
+
+struct Rank {
+    int device = 0, n_cus = 256;
+    int64_t lo = 0;
+    hipStream_t stream = nullptr, comm_stream = nullptr;
+    hipEvent_t stepped = nullptr, gathered = nullptr;
+    float4* pos[2] = {nullptr, nullptr};
+    float4* vel = nullptr;
+    double4* pos64 = nullptr;
+    double4* vel64 = nullptr;
+    void* ws = nullptr;
+    ncclComm_t comm = nullptr;
+};
+
+}  // namespace
+
+struct nb_sharded {
+    int P = 0;
+    int64_t n = 0, per = 0;
+    int precision = NB_F32;
+    int flags = 0;
+    double G = 0, eps = 0, dt = 0;
+    std::vector<Rank> rank;
+    int cur = 0;
+    bool have_state = false;
+    bool gather_pending = false;  // overlap: the all-gather of pos[cur] is still in flight on the comm streams
+    const RcclApi* api = nullptr;
+    char err[512] = {0};
+};
+
+namespace {
+
+thread_local char g_err[512] = {0};
+
+int fail(nb_sharded* s, int code, const char* what, const char* detail) {
+    snprintf(s ? s->err : g_err, sizeof g_err, "%s: %s", what, detail);
+    return code;
+}
+
+#define SH_HIP(s, call)                                                                \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess) return fail(s, NB_ERR_HIP, #call, hipGetErrorString(e_)); \
+    } while (0)
+#define SH_NCCL(s, call)                                                                      \
+    do {                                                                                      \
+        ncclResult_t r_ = (call);                                                             \
+        if (r_ != ncclSuccess) return fail(s, NB_ERR_HIP, #call, (s)->api->GetErrorString(r_)); \
+    } while (0)
+
+bool acc64(const nb_sharded* s) { return s->precision == NB_F32_ACC64; }
+bool overlapped(const nb_sharded* s) { return (s->flags & NB_SHARDED_OVERLAP) && s->P > 1; }
+
+int64_t workspace_bytes(const nb_sharded* s) { return nb_workspace_bytes_f32(s->per, acc64(s)); }
+
+// one phase of rank r's step: sources [src_begin, src_end) of the gathered array `cur`
+int launch_phase(nb_sharded* s, Rank& k, int64_t src_begin, int64_t src_end, int phase) {
+    F32Args a{};
+    a.src = k.pos[s->cur];
+    a.out = k.pos[s->cur ^ 1];
+    a.vel = k.vel;
+    a.pos64 = k.pos64;
+    a.vel64 = k.vel64;
+    a.partial = k.ws;
+    a.n_src = s->n;
+    a.tgt_off = k.lo;
+    a.n_tgt = s->per;
+    a.src_begin = src_begin;
+    a.src_end = src_end;
+    a.phase = phase;
+    a.eps2 = (float)(s->eps * s->eps);
+    a.dt = (float)s->dt;
+    const long cover = (src_begin || src_end) ? (long)(src_end - src_begin) : (long)s->n;
+    const F32Plan plan = plan_f32(s->per, cover > 0 ? cover : 1, k.n_cus, 0, 0, k.ws != nullptr);
+    SH_HIP(s, (hipError_t)launch_f32(a, plan, acc64(s), false, k.stream));
+    return NB_OK;
+}
+
+int step_once(nb_sharded* s) {
+    const bool ov = overlapped(s);
+    for (Rank& k : s->rank) {
+        SH_HIP(s, hipSetDevice(k.device));
+        if (!ov) {
+            if (int rc = launch_phase(s, k, 0, 0, F32_PHASE_WHOLE)) return rc;
+            continue;
+        }
+        // own shard first: final since this GPU's previous launch (or the initial upload); no exchange needed
+        const int64_t lo = k.lo, hi = k.lo + s->per;
+        if (int rc = launch_phase(s, k, lo, hi, F32_PHASE_FIRST)) return rc;
+        if (s->gather_pending) SH_HIP(s, hipStreamWaitEvent(k.stream, k.gathered, 0));  // the other shards have landed
+        if (lo > 0)
+            if (int rc = launch_phase(s, k, 0, lo, hi < s->n ? F32_PHASE_MIDDLE : F32_PHASE_LAST)) return rc;
+        if (hi < s->n)
+            if (int rc = launch_phase(s, k, hi, s->n, F32_PHASE_LAST)) return rc;
+    }
+    // exchange: every GPU contributes its own slot of the array its kernels have just written
+    const int nxt = s->cur ^ 1;
+    if (ov)
+        for (Rank& k : s->rank) {
+            SH_HIP(s, hipSetDevice(k.device));
+            SH_HIP(s, hipEventRecord(k.stepped, k.stream));
+            SH_HIP(s, hipStreamWaitEvent(k.comm_stream, k.stepped, 0));
+        }
+    SH_NCCL(s, s->api->GroupStart());
+    for (Rank& k : s->rank) {
+        float* buf = (float*)k.pos[nxt];
+        ncclResult_t r = s->api->AllGather(buf + 4 * k.lo, buf, (size_t)(4 * s->per), ncclFloat, k.comm,
+                                           ov ? k.comm_stream : k.stream);
+        if (r != ncclSuccess) {
+            (void)s->api->GroupEnd();
+            return fail(s, NB_ERR_HIP, "ncclAllGather", s->api->GetErrorString(r));
+        }
+    }
+    SH_NCCL(s, s->api->GroupEnd());
+    if (ov)
+        for (Rank& k : s->rank) {
+            SH_HIP(s, hipSetDevice(k.device));
+            SH_HIP(s, hipEventRecord(k.gathered, k.comm_stream));
+        }
+    s->gather_pending = ov;
+    s->cur = nxt;
+    return NB_OK;
+}
+
+int sync_all(nb_sharded* s) {
+    for (Rank& k : s->rank) {
+        SH_HIP(s, hipSetDevice(k.device));
+        SH_HIP(s, hipStreamSynchronize(k.stream));
+        if (k.comm_stream) SH_HIP(s, hipStreamSynchronize(k.comm_stream));
+    }
+    s->gather_pending = false;
+    return NB_OK;
+}
+
+void release(nb_sharded* s) {
+    for (Rank& k : s->rank) {
+        (void)hipSetDevice(k.device);
+        if (k.stream) (void)hipStreamSynchronize(k.stream);
+        if (k.comm_stream) (void)hipStreamSynchronize(k.comm_stream);
+        if (k.comm && s->api) (void)s->api->CommDestroy(k.comm);
+        for (void* p : {(void*)k.pos[0], (void*)k.pos[1], (void*)k.vel, (void*)k.pos64, (void*)k.vel64, k.ws})
+            if (p) (void)hipFree(p);
+        if (k.stepped) (void)hipEventDestroy(k.stepped);
+        if (k.gathered) (void)hipEventDestroy(k.gathered);
+        if (k.stream) (void)hipStreamDestroy(k.stream);
+        if (k.comm_stream) (void)hipStreamDestroy(k.comm_stream);
+    }
+}
+
+int create_impl(nb_sharded** out, const int* devices, int n_devices, int64_t n, int precision, double G, double eps,
+                double dt, int flags) {
+    if (!out) return NB_ERR_INVALID;
+    *out = nullptr;
+    if (!devices || n_devices <= 0 || n_devices > 64 || n <= 0) return fail(nullptr, NB_ERR_INVALID, "nb_sharded_create", "bad argument");
+    if (precision != NB_F32 && precision != NB_F32_ACC64) return fail(nullptr, NB_ERR_INVALID, "nb_sharded_create", "precision must be NB_F32 or NB_F32_ACC64");
+    if (!(eps > 0)) return fail(nullptr, NB_ERR_INVALID, "nb_sharded_create", "fp32 kernels need eps > 0");
+    if (n % n_devices) return fail(nullptr, NB_ERR_INVALID, "nb_sharded_create", "n must be divisible by the number of devices");
+    // overlap cuts the sources at shard boundaries: they must fall on whole 256-body tiles
+    if ((flags & NB_SHARDED_OVERLAP) && n_devices > 1 && (n / n_devices) % TILE)
+        return fail(nullptr, NB_ERR_INVALID, "nb_sharded_create", "overlap needs n / devices to be a multiple of 256");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return NB_ERR_NO_DEVICE;
+    for (int i = 0; i < n_devices; ++i) {
+        if (devices[i] < 0 || devices[i] >= ndev) return NB_ERR_NO_DEVICE;
+        for (int j = 0; j < i; ++j)
+            if (devices[j] == devices[i]) return fail(nullptr, NB_ERR_INVALID, "nb_sharded_create", "a device is listed twice (RCCL: one rank per GPU)");
+    }
+    nb_sharded* s = new (std::nothrow) nb_sharded();
+    if (!s) return NB_ERR_NOMEM;
+    *out = s;  // returned even on failure so the caller can read nb_sharded_last_error, then nb_sharded_destroy
+    s->P = n_devices;
+    s->n = n;
+    s->per = n / n_devices;
+    s->precision = precision;
+    s->flags = flags;
+    s->G = G;
+    s->eps = eps;
+    s->dt = dt;
+    s->api = rccl(s->err, sizeof s->err);
+    if (!s->api) return NB_ERR_HIP;
+    s->rank.resize((size_t)n_devices);
+    const size_t N = (size_t)n, per = (size_t)s->per;
+    for (int r = 0; r < n_devices; ++r) {
+        Rank& k = s->rank[(size_t)r];
+        k.device = devices[r];
+        k.lo = (int64_t)r * s->per;
+        SH_HIP(s, hipSetDevice(k.device));
+        SH_HIP(s, hipDeviceGetAttribute(&k.n_cus, hipDeviceAttributeMultiprocessorCount, k.device));
+        SH_HIP(s, hipStreamCreateWithFlags(&k.stream, hipStreamNonBlocking));
+        if (overlapped(s)) {
+            SH_HIP(s, hipStreamCreateWithFlags(&k.comm_stream, hipStreamNonBlocking));
+            SH_HIP(s, hipEventCreateWithFlags(&k.stepped, hipEventDisableTiming));
+            SH_HIP(s, hipEventCreateWithFlags(&k.gathered, hipEventDisableTiming));
+        }
+        SH_HIP(s, hipMalloc(&k.pos[0], N * sizeof(float4)));
+        SH_HIP(s, hipMalloc(&k.pos[1], N * sizeof(float4)));
+        SH_HIP(s, hipMalloc(&k.vel, per * sizeof(float4)));
+        if (acc64(s)) {
+            SH_HIP(s, hipMalloc(&k.pos64, per * sizeof(double4)));
+            SH_HIP(s, hipMalloc(&k.vel64, per * sizeof(double4)));
+        }
+        // the workspace lets the step slice the sources (and carry sums between phases): allocate it whenever the plan
+        // would slice, and always for overlap
+        if (overlapped(s) || plan_f32(s->per, s->n, k.n_cus, 0, 0, true).j_split > 1)
+            SH_HIP(s, hipMalloc(&k.ws, (size_t)workspace_bytes(s)));
+    }
+    std::vector<ncclComm_t> comms((size_t)n_devices);
+    SH_NCCL(s, s->api->CommInitAll(comms.data(), n_devices, devices));
+    for (int r = 0; r < n_devices; ++r) s->rank[(size_t)r].comm = comms[(size_t)r];
+    return NB_OK;
+}
+
+int set_state_impl(nb_sharded* s, const double* qx, const double* qy, const double* qz, const double* vx,
+                   const double* vy, const double* vz, const double* m) {
+    const size_t N = (size_t)s->n, per = (size_t)s->per;
+    std::vector<float4> p(N), v(per);
+    for (size_t i = 0; i < N; ++i)  // G*m folded in fp64, rounded once (as nb_set_state does)
+        p[i] = make_float4((float)qx[i], (float)qy[i], (float)qz[i], (float)(s->G * m[i]));
+    std::vector<double4> p64, v64;
+    if (acc64(s)) { p64.resize(per); v64.resize(per); }
+    for (Rank& k : s->rank) {
+        SH_HIP(s, hipSetDevice(k.device));
+        const size_t lo = (size_t)k.lo;
+        for (size_t i = 0; i < per; ++i) v[i] = make_float4((float)vx[lo + i], (float)vy[lo + i], (float)vz[lo + i], 0.f);
+        // both ping-pong arrays get every body once: the slots other GPUs own are refreshed by the all-gather, and the
+        // G*m column never changes
+        SH_HIP(s, hipMemcpy(k.pos[0], p.data(), N * sizeof(float4), hipMemcpyHostToDevice));
+        SH_HIP(s, hipMemcpy(k.pos[1], p.data(), N * sizeof(float4), hipMemcpyHostToDevice));
+        SH_HIP(s, hipMemcpy(k.vel, v.data(), per * sizeof(float4), hipMemcpyHostToDevice));
+        if (acc64(s)) {
+            for (size_t i = 0; i < per; ++i) {
+                p64[i] = make_double4(qx[lo + i], qy[lo + i], qz[lo + i], s->G * m[lo + i]);
+                v64[i] = make_double4(vx[lo + i], vy[lo + i], vz[lo + i], 0.0);
+            }
+            SH_HIP(s, hipMemcpy(k.pos64, p64.data(), per * sizeof(double4), hipMemcpyHostToDevice));
+            SH_HIP(s, hipMemcpy(k.vel64, v64.data(), per * sizeof(double4), hipMemcpyHostToDevice));
+        }
+    }
+    s->cur = 0;
+    s->gather_pending = false;
+    s->have_state = true;
+    return NB_OK;
+}
+
+int get_state_impl(nb_sharded* s, double* qx, double* qy, double* qz, double* vx, double* vy, double* vz) {
+    if (int rc = sync_all(s)) return rc;
+    const size_t N = (size_t)s->n, per = (size_t)s->per;
+    if (acc64(s)) {
+        std::vector<double4> p(per), v(per);
+        for (Rank& k : s->rank) {
+            SH_HIP(s, hipSetDevice(k.device));
+            SH_HIP(s, hipMemcpy(p.data(), k.pos64, per * sizeof(double4), hipMemcpyDeviceToHost));
+            SH_HIP(s, hipMemcpy(v.data(), k.vel64, per * sizeof(double4), hipMemcpyDeviceToHost));
+            const size_t lo = (size_t)k.lo;
+            for (size_t i = 0; i < per; ++i) {
+                qx[lo + i] = p[i].x; qy[lo + i] = p[i].y; qz[lo + i] = p[i].z;
+                vx[lo + i] = v[i].x; vy[lo + i] = v[i].y; vz[lo + i] = v[i].z;
+            }
+        }
+        return NB_OK;
+    }
+    // every GPU holds all positions after the all-gather: read them from the last one (the most remote from rank 0's
+    // own writes, so a broken exchange shows up in the result), velocities from their owners
+    std::vector<float4> p(N), v(per);
+    Rank& last = s->rank.back();
+    SH_HIP(s, hipSetDevice(last.device));
+    SH_HIP(s, hipMemcpy(p.data(), last.pos[s->cur], N * sizeof(float4), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < N; ++i) { qx[i] = p[i].x; qy[i] = p[i].y; qz[i] = p[i].z; }
+    for (Rank& k : s->rank) {
+        SH_HIP(s, hipSetDevice(k.device));
+        SH_HIP(s, hipMemcpy(v.data(), k.vel, per * sizeof(float4), hipMemcpyDeviceToHost));
+        const size_t lo = (size_t)k.lo;
+        for (size_t i = 0; i < per; ++i) { vx[lo + i] = v[i].x; vy[lo + i] = v[i].y; vz[lo + i] = v[i].z; }
+    }
+    return NB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nb_sharded_create(nb_sharded** out, const int* devices, int n_devices, int64_t n, int precision, double G,
+                      double eps, double dt, int flags) {
+    try {
+        return create_impl(out, devices, n_devices, n, precision, G, eps, dt, flags);
+    } catch (...) {
+        return NB_ERR_NOMEM;
+    }
+}
+
+int nb_sharded_destroy(nb_sharded* s) {
+    if (!s) return NB_ERR_INVALID;
+    release(s);
+    delete s;
+    return NB_OK;
+}
+
+const char* nb_sharded_last_error(const nb_sharded* s) { return s ? s->err : g_err; }
+
+int nb_sharded_set_state(nb_sharded* s, const double* qx, const double* qy, const double* qz, const double* vx,
+                         const double* vy, const double* vz, const double* m) {
+    if (!s || !qx || !qy || !qz || !vx || !vy || !vz || !m) return NB_ERR_INVALID;
+    if (s->rank.empty() || !s->rank.back().comm) return NB_ERR_STATE;  // creation failed half way
+    try {
+        return set_state_impl(s, qx, qy, qz, vx, vy, vz, m);
+    } catch (...) {
+        return NB_ERR_NOMEM;
+    }
+}
+
+int nb_sharded_get_state(nb_sharded* s, double* qx, double* qy, double* qz, double* vx, double* vy, double* vz) {
+    if (!s || !qx || !qy || !qz || !vx || !vy || !vz) return NB_ERR_INVALID;
+    if (!s->have_state) return NB_ERR_STATE;
+    try {
+        return get_state_impl(s, qx, qy, qz, vx, vy, vz);
+    } catch (...) {
+        return NB_ERR_NOMEM;
+    }
+}
+
+int nb_sharded_step(nb_sharded* s, int count) {
+    if (!s || count < 0) return NB_ERR_INVALID;
+    if (!s->have_state) return NB_ERR_STATE;
+    for (int i = 0; i < count; ++i)
+        if (int rc = step_once(s)) return rc;
+    return sync_all(s);
+}
+
+int nb_sharded_step_timed(nb_sharded* s, int count, double* ms_per_step) {
+    if (!s || count <= 0 || !ms_per_step) return NB_ERR_INVALID;
+    if (!s->have_state) return NB_ERR_STATE;
+    if (int rc = sync_all(s)) return rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < count; ++i)
+        if (int rc = step_once(s)) return rc;
+    if (int rc = sync_all(s)) return rc;
+    *ms_per_step = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / count;
+    return NB_OK;
+}
+
+int nb_sharded_info(const nb_sharded* s, int* n_devices, int64_t* targets_per_device, int* targets_per_lane, int* j_split,
+                    int* wg_size) {
+    if (!s || s->rank.empty()) return NB_ERR_INVALID;
+    const Rank& k = s->rank[0];
+    const F32Plan p = plan_f32(s->per, s->n, k.n_cus, 0, 0, k.ws != nullptr);
+    if (n_devices) *n_devices = s->P;
+    if (targets_per_device) *targets_per_device = s->per;
+    if (targets_per_lane) *targets_per_lane = p.targets_per_lane;
+    if (j_split) *j_split = p.j_split;
+    if (wg_size) *wg_size = p.wg_size;
+    return NB_OK;
+}
+
+}  // extern "C"

@@ -10,8 +10,11 @@ hw5.cu:564-567,587-588); this is the new data-parallel scheme the north star ask
   (3) swap.  Masses never change, so G*m travels inside the float4 and is never re-sent separately.
 
 xGMI is point-to-point (7 links/GPU): the all-gather moves each 16*N/P-byte shard once per peer link —
-2 MiB per rank at N=2^20/P=8, 8 MiB at N=2^22 — tens of microseconds against tens of milliseconds of compute,
-so no overlap machinery is needed.
+2 MiB per rank at N=2^20/P=8, 8 MiB at N=2^22 — tens of microseconds against tens of milliseconds of compute.
+`overlap=True` hides even that: a step is cut into phases over disjoint source ranges — the own shard
+first (final as soon as this rank's previous launch has written it) while the asynchronous all-gather of the other
+shards is still in flight, the remote shards after it — with the running sums kept in the kernel's workspace between
+the phases.  Off by default: bench.py reports both on the multi-GPU node (`overlap_ab`).
 
 torch is used for device memory, the stream and the collective only; the arithmetic is the HIP kernel behind
 `capi.launch_f32`.  `compute` is injectable so the sharding/exchange logic can be exercised on CPU with gloo
@@ -36,7 +39,7 @@ def hip_compute(acc64=False, targets_per_lane=0, j_split=0, source_path=0, wg_si
     (partial sums when a shard's targets alone cannot fill the chip) is a torch tensor allocated once."""
     ws = {}
 
-    def compute(src, out, vel, off, n_tgt, eps2, dt, pos64=None, vel64=None):
+    def compute(src, out, vel, off, n_tgt, eps2, dt, pos64=None, vel64=None, src_range=None, phase=capi.NB_PHASE_WHOLE):
         if not src.is_cuda:
             raise RuntimeError("nbody_amd has no CPU compute path: tensors must live on a HIP device")
         key = (src.device, src.shape[0], n_tgt)
@@ -52,7 +55,8 @@ def hip_compute(acc64=False, targets_per_lane=0, j_split=0, source_path=0, wg_si
                         acc64=acc64, targets_per_lane=targets_per_lane, j_split=j_split, source_path=source_path,
                         wg_size=wg_size,
                         workspace_ptr=w.data_ptr() if w is not None else 0,
-                        workspace_bytes=w.numel() if w is not None else 0)
+                        workspace_bytes=w.numel() if w is not None else 0, phase=phase,
+                        src_begin=src_range[0] if src_range else 0, src_end=src_range[1] if src_range else 0)
 
     return compute
 
@@ -60,9 +64,11 @@ def hip_compute(acc64=False, targets_per_lane=0, j_split=0, source_path=0, wg_si
 class ShardedSystem:
     """N bodies sharded by index over the ranks of the default process group (or unsharded when world == 1)."""
 
-    def __init__(self, n, pos_shard, vel_shard, eps, dt, device, compute=None, acc64=False, group=None, trace=False):
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+    def __init__(self, n, pos_shard, vel_shard, eps, dt, device, compute=None, acc64=False, group=None, trace=False,
+                 exchange="in_place", overlap=False):
+        self.dist_on = dist.is_initialized()  # a one-rank group still runs the collective (tests the in-place call)
+        self.world = dist.get_world_size(group) if self.dist_on else 1
+        self.rank = dist.get_rank(group) if self.dist_on else 0
         self.group = group
         self.n = n
         self.lo, self.hi = shard_range(n, self.rank, self.world)
@@ -70,6 +76,15 @@ class ShardedSystem:
         assert tuple(pos_shard.shape) == (self.n_tgt, 4) and tuple(vel_shard.shape) == (self.n_tgt, 4)
         self.eps2, self.dt = float(eps) * float(eps), float(dt)
         self.acc64 = acc64
+        if exchange not in ("in_place", "staged"):
+            raise ValueError(f"exchange={exchange!r}: expected 'in_place' or 'staged'")
+        self.exchange = exchange
+        # two-phase step: sources are cut at shard boundaries, which must be whole 256-body tiles of the kernel
+        self.overlap = bool(overlap) and self.world > 1
+        if self.overlap and self.n_tgt % 256:
+            raise ValueError(f"overlap needs n/world = {self.n_tgt} to be a multiple of 256")
+        self._pending = None  # the asynchronous all-gather of pos[cur], if one is in flight
+        self.kernel_events = None  # a list: step() appends (start, end) torch.cuda.Event pairs around its launches
         self.trace = trace and torch.cuda.is_available()  # roctx ranges (torch.cuda.nvtx -> roctx on ROCm) for rocprofv3
         self.compute = compute or hip_compute(acc64)
         self.pos = [torch.zeros((n, 4), dtype=torch.float32, device=device) for _ in range(2)]
@@ -79,45 +94,79 @@ class ShardedSystem:
             self.pos64 = pos_shard.to(device=device, dtype=torch.float64).contiguous()
             self.vel64 = vel_shard.to(device=device, dtype=torch.float64).contiguous()
         self.cur = 0
-        self._inplace_ok = True
         self.pos[0][self.lo:self.hi] = pos_shard.to(device=device, dtype=torch.float32)
         self._exchange(self.pos[0])
         self.pos[1].copy_(self.pos[0])  # G*m column of the other buffer for slots this rank never writes
 
-    def _exchange(self, buf):
-        """In-place all-gather: every rank contributes its own slot of `buf`."""
-        if self.world == 1:
-            return
+    @property
+    def exchange_mode(self):
+        """How positions travel between ranks: "none" (one rank), "in_place" (RCCL/NCCL: send buffer = this rank's slot
+        of the receive buffer), "staged" (RCCL with the shard cloned first; only when asked for with exchange="staged"),
+        "list" (gloo rehearsal / CPU tests)."""
+        if not self.dist_on:
+            return "none"
+        if dist.get_backend(self.group) == "nccl":
+            return self.exchange
+        return "list"
+
+    def _exchange(self, buf, async_op=False):
+        """In-place all-gather: every rank contributes its own slot of `buf`.  Errors of the
+        collective propagate: a failed RCCL call must never be retried on the same communicator, and every rank
+        must issue the same collective sequence.  async_op -> the Work handle (wait() orders the current stream after
+        the collective without blocking the host, for RCCL)."""
+        if not self.dist_on:
+            return None
         if dist.get_backend(self.group) == "nccl":
             # RCCL: in place, send buffer = this rank's slot of the receive buffer (ncclAllGather's in-place form)
-            if self._inplace_ok:
-                try:
-                    dist.all_gather_into_tensor(buf, buf[self.lo:self.hi], group=self.group)
-                    return
-                except (RuntimeError, ValueError):  # a torch build that refuses aliased buffers: stage the shard once
-                    self._inplace_ok = False
-            dist.all_gather_into_tensor(buf, buf[self.lo:self.hi].clone(), group=self.group)
-        else:
-            # gloo (CPU tests / single-GPU rehearsal): same exchange through the list form
-            per = self.n_tgt
-            dist.all_gather([buf[r * per:(r + 1) * per] for r in range(self.world)],
-                            buf[self.lo:self.hi].clone(), group=self.group)
+            shard = buf[self.lo:self.hi]
+            return dist.all_gather_into_tensor(buf, shard.clone() if self.exchange == "staged" else shard,
+                                               group=self.group, async_op=async_op)
+        # gloo (CPU tests / single-GPU rehearsal): same exchange through the list form
+        per = self.n_tgt
+        return dist.all_gather([buf[r * per:(r + 1) * per] for r in range(self.world)],
+                               buf[self.lo:self.hi].clone(), group=self.group, async_op=async_op)
+
+    def _wait_gather(self):
+        if self._pending is not None:
+            self._pending.wait()
+            self._pending = None
 
     def step(self):
         src, out = self.pos[self.cur], self.pos[self.cur ^ 1]
+        args = (src, out, self.vel, self.lo, self.n_tgt, self.eps2, self.dt, self.pos64, self.vel64)
         if self.trace:
             torch.cuda.nvtx.range_push("nbody.force_kick_drift")
-        self.compute(src, out, self.vel, self.lo, self.n_tgt, self.eps2, self.dt, self.pos64, self.vel64)
+        if self.kernel_events is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        if self.overlap:
+            lo, hi, n = self.lo, self.hi, self.n
+            # own shard: written by this rank's previous launch, so its all-gather need not have finished
+            self.compute(*args, src_range=(lo, hi), phase=capi.NB_PHASE_FIRST)
+            self._wait_gather()  # the other shards of `src` have landed
+            if lo > 0:
+                self.compute(*args, src_range=(0, lo), phase=capi.NB_PHASE_MIDDLE if hi < n else capi.NB_PHASE_LAST)
+            if hi < n:
+                self.compute(*args, src_range=(hi, n), phase=capi.NB_PHASE_LAST)
+        else:
+            self.compute(*args)
+        if self.kernel_events is not None:
+            e1.record()
+            self.kernel_events.append((e0, e1))
         if self.trace:
             torch.cuda.nvtx.range_pop()
             torch.cuda.nvtx.range_push("nbody.allgather_positions")
-        self._exchange(out)
+        if self.overlap:
+            self._pending = self._exchange(out, async_op=True)
+        else:
+            self._exchange(out)
         if self.trace:
             torch.cuda.nvtx.range_pop()
         self.cur ^= 1
 
     @property
     def positions(self):
+        self._wait_gather()
         return self.pos[self.cur]
 
     def pairs_per_step(self):

@@ -20,16 +20,17 @@ def test_header_and_binding_agree(nb):
     L = nb.capi.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.nb_abi_version() == 1
+    assert L.nb_abi_version() == 2
 
 
 def test_struct_layouts_match_header(nb):
     import ctypes as C
     c = nb.capi
     assert C.sizeof(c.NbConfig) == 40
-    assert C.sizeof(c.NbScenario) == 6 * 4 + 16 * 4 + 4 + 4 + 16  # ints, watch[], sync_every, engine, 2 doubles
+    assert C.sizeof(c.NbScenario) == 6 * 4 + 16 * 4 + 4 * 4 + 16  # ints, watch[], sync_every/engine/flags/reserved, 2 doubles
+    assert C.sizeof(c.NbStateHeader) == 8 + 4 * 4 + 3 * 8
     assert C.sizeof(c.NbAnswer) == 24
-    assert C.sizeof(c.NbLaunchF32) == 7 * 8 + 4 * 8 + 8 * 4
+    assert C.sizeof(c.NbLaunchF32) == 7 * 8 + 4 * 8 + 8 * 4 + 2 * 8
 
 
 def test_no_cpu_fallback(nb):
@@ -71,6 +72,47 @@ def test_state_file_header_errors(nb, tmp_path):
     good = tmp_path / "hdr.nbst"
     good.write_bytes(b"NBODYST1" + struct.pack("<qiiddd", 7, 0, 123, 6.674e-11, 1e-3, 60.0))
     assert nb.capi.state_file_info(str(good)) == (7, 0, 123)
+    # context-free failures leave their text in the calling thread's nb_last_error(NULL)
+    with pytest.raises(nb.capi.NBodyError, match="not an NBODYST"):
+        nb.capi.read_state_file(str(bad))
+    swapped = tmp_path / "swapped.nbst"
+    swapped.write_bytes(b"NBODYST2" + struct.pack(">IiqiiiIddd", 0x01020304, 0, 7, 0, 1, 2, 0, 6.674e-11, 1e-3, 60.0))
+    with pytest.raises(nb.capi.NBodyError, match="byte order"):
+        nb.capi.read_state_file(str(swapped))
+
+
+def test_state_file_round_trip_without_gpu(nb, oracle, tmp_path):
+    """nb_write_state_file / nb_read_state_file are host-only: the binary form of testcases/b30.in carries exactly the
+    text form's content (n, planet, asteroid, q, v, m, the `device` predicate); version-1 files are still readable;
+    bin/nbconv writes the same bytes."""
+    import subprocess
+
+    import numpy as np
+    from conftest import case_path
+    c = nb.capi
+    s = oracle.read_input(case_path("b30", "in"))
+    path = str(tmp_path / "b30.nbst")
+    c.write_state_file(path, s.q, s.v, s.m, s.is_device, planet=s.planet, asteroid=s.asteroid)
+    assert os.path.getsize(path) == 64 + s.n * (7 * 8 + 1)
+    h, q, v, m, dev = c.read_state_file(path)
+    assert (h["n"], h["planet"], h["asteroid"], h["precision"], h["step"]) == (s.n, s.planet, s.asteroid, c.NB_F64, 0)
+    assert (h["G"], h["eps"], h["dt"]) == (6.674e-11, 1e-3, 60.0)
+    assert np.array_equal(q, s.q) and np.array_equal(v, s.v) and np.array_equal(m, s.m) and np.array_equal(dev, s.is_device)
+    conv = str(tmp_path / "conv.nbst")
+    subprocess.run([os.path.join(ROOT, "bin", "nbconv"), case_path("b30", "in"), conv], check=True)
+    assert open(conv, "rb").read() == open(path, "rb").read()
+    # version 1 (round-1 checkpoints): 48-byte header, no planet/asteroid
+    import struct
+    body = open(path, "rb").read()[64:]
+    v1 = tmp_path / "v1.nbst"
+    v1.write_bytes(b"NBODYST1" + struct.pack("<qiiddd", s.n, 0, 9, 6.674e-11, 1e-3, 60.0) + body)
+    h1, q1, _, m1, _ = c.read_state_file(str(v1))
+    assert (h1["n"], h1["step"], h1["planet"], h1["asteroid"]) == (s.n, 9, -1, -1)
+    assert np.array_equal(q1, s.q) and np.array_equal(m1, s.m)
+    trunc = tmp_path / "trunc.nbst"
+    trunc.write_bytes(open(path, "rb").read()[:-5])
+    with pytest.raises(c.NBodyError, match="truncated"):
+        c.read_state_file(str(trunc))
 
 
 def test_header_is_plain_c_and_links_from_c(nb, tmp_path):
@@ -83,8 +125,10 @@ def test_header_is_plain_c_and_links_from_c(nb, tmp_path):
 #include "nbody_amd.h"
 int main(void) {
     nb_config cfg;
-    nb_scenario scn; nb_scenario_result res; nb_answer ans; nb_launch_f32 l;
+    nb_scenario scn; nb_scenario_result res; nb_answer ans; nb_launch_f32 l; nb_state_header h;
     (void)scn; (void)res; (void)ans; (void)l;
+    if (nb_read_state_file("/nonexistent/x.nbst", &h, 0, 0, 0, 0, 0, 0, 0, 0, 0) != NB_ERR_IO) return 5;
+    if (nb_last_error(0)[0] == 0) return 6;
     if (nb_abi_version() != NB_ABI_VERSION) return 1;
     if (nb_config_default(&cfg) != NB_OK || cfg.dt != 60.0 || cfg.G != 6.674e-11 || cfg.eps != 1e-3) return 2;
     if (nb_config_default(0) != NB_ERR_INVALID) return 3;

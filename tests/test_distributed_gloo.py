@@ -21,10 +21,22 @@ N, STEPS = 512, 3
 
 
 def _oracle_compute(O, G, eps):
-    def compute(src, out, vel, off, n_tgt, eps2, dt, pos64=None, vel64=None):
+    carry = {}
+
+    def compute(src, out, vel, off, n_tgt, eps2, dt, pos64=None, vel64=None, src_range=None, phase=0):
         p = src.numpy().astype(np.float64)
         q = np.ascontiguousarray(p[:, :3].T)
-        a = O.accel_rows(q, np.ascontiguousarray(p[:, 3] / G), G, eps, off, off + n_tgt, omp=False)
+        gm = np.ascontiguousarray(p[:, 3] / G)
+        if src_range is not None:  # a phase of a step: only these sources pull (the others are made massless)
+            mask = np.zeros_like(gm)
+            mask[src_range[0]:src_range[1]] = 1.0
+            gm = gm * mask
+        a = O.accel_rows(q, gm, G, eps, off, off + n_tgt, omp=False)
+        if phase in (2, 3):   # NB_PHASE_LAST / NB_PHASE_MIDDLE continue the running sum
+            a = carry["a"] + a
+        if phase in (1, 3):   # NB_PHASE_FIRST / NB_PHASE_MIDDLE keep it for the next phase
+            carry["a"] = a
+            return
         v = vel.numpy()
         v[:, :3] = (v[:, :3].astype(np.float64) + a.T * dt).astype(np.float32)
         newp = p[off:off + n_tgt, :3] + v[:, :3].astype(np.float64) * dt
@@ -34,7 +46,7 @@ def _oracle_compute(O, G, eps):
     return compute
 
 
-def _run(rank, world, port, result_path):
+def _run(rank, world, port, result_path, overlap=False):
     sys.path.insert(0, ROOT)
     import nbody_amd  # noqa: F401
     from nbody_amd import synthetic
@@ -45,8 +57,8 @@ def _run(rank, world, port, result_path):
     lo, hi = shard_range(N, rank, world)
     pos, vel = synthetic.body4_f32(N, lo, hi)
     sysm = ShardedSystem(N, torch.from_numpy(pos), torch.from_numpy(vel), synthetic.EPS, 1e-2, torch.device("cpu"),
-                         compute=_oracle_compute(O, synthetic.G, synthetic.EPS))
-    assert (sysm.lo, sysm.hi) == (lo, hi)
+                         compute=_oracle_compute(O, synthetic.G, synthetic.EPS), overlap=overlap)
+    assert (sysm.lo, sysm.hi) == (lo, hi) and sysm.overlap == (overlap and world > 1)
     for _ in range(STEPS):
         sysm.step()
     # every rank must hold the same full position array after the exchange
@@ -84,6 +96,31 @@ def test_two_ranks_equal_one_rank(oracle, tmp_path):
     from nbody_amd import synthetic
     p0, _ = synthetic.body4_f32(N)
     assert not np.array_equal(p0[:, :3], b["pos"][:, :3]) and np.array_equal(p0[:, 3], b["pos"][:, 3])
+
+
+def test_overlapped_two_phase_step_equals_plain_step(oracle, tmp_path):
+    """own-shard sources first, the asynchronous all-gather of the other shards in flight, remote sources
+    after it.  Same trajectory as the plain step (the phases only reorder a sum that the stand-in computes in fp64)."""
+    one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
+    _run(0, 1, 0, one)
+    mp.spawn(_run, args=(2, _free_port(), two, True), nprocs=2, join=True)
+    a, b = np.load(one), np.load(two)
+    assert np.abs(a["pos"] - b["pos"]).max() <= 1.2e-7 and np.abs(a["vel"] - b["vel"]).max() <= 1e-9
+    assert np.array_equal(a["pos"][:, 3], b["pos"][:, 3])
+
+
+def test_overlap_needs_tile_aligned_shards(nb):
+    from nbody_amd.distributed import ShardedSystem
+
+    class TwoRanks(ShardedSystem):  # shard bookkeeping only: no process group is started
+        pass
+    import unittest.mock as um
+    with um.patch("torch.distributed.is_initialized", return_value=True), \
+            um.patch("torch.distributed.get_world_size", return_value=2), \
+            um.patch("torch.distributed.get_rank", return_value=0):
+        with pytest.raises(ValueError, match="multiple of 256"):
+            TwoRanks(600, torch.zeros((300, 4)), torch.zeros((300, 4)), 1e-3, 1e-2, torch.device("cpu"),
+                     compute=lambda *a, **k: None, overlap=True)
 
 
 def test_shard_range_and_cpu_refusal(nb):

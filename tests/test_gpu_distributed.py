@@ -17,44 +17,127 @@ pytestmark = pytest.mark.gpu
 N, STEPS = 16384, 4
 
 
-def _run(rank, world, port, path):
+def _run(rank, world, port, path, acc64=False, backend="gloo", overlap=False):
     sys.path.insert(0, ROOT)
     import nbody_amd  # noqa: F401
     from nbody_amd import synthetic
     from nbody_amd.distributed import ShardedSystem, shard_range
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
-    if world > 1:
+    if backend == "nccl":  # world 1 only: RCCL refuses two ranks on one device
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
+                                device_id=dev)
+    elif world > 1:
         dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     lo, hi = shard_range(N, rank, world)
     pos, vel = synthetic.body4_f32(N, lo, hi)
-    sysm = ShardedSystem(N, torch.from_numpy(pos), torch.from_numpy(vel), synthetic.EPS, 1e-2, dev)
+    if acc64:  # fp64 masters start from the fp64 bodies (what bench.py --precision f32acc64 does)
+        q, v, m = synthetic.bodies(N, lo, hi)
+        pos = np.concatenate([q.T, (synthetic.G * m)[:, None]], axis=1)
+        vel = np.concatenate([v.T, np.zeros((hi - lo, 1))], axis=1)
+    sysm = ShardedSystem(N, torch.from_numpy(pos), torch.from_numpy(vel), synthetic.EPS, 1e-2, dev, acc64=acc64,
+                         overlap=overlap)
+    if backend == "nccl":
+        assert sysm.exchange_mode == "in_place"
+        before = sysm.positions.clone()
+        dist.all_gather_into_tensor(sysm.positions, sysm.positions[sysm.lo:sysm.hi])  # the aliased call by itself
+        torch.cuda.synchronize()
+        assert torch.equal(before, sysm.positions)
     for _ in range(STEPS):
         sysm.step()
     torch.cuda.synchronize()
+    if acc64:  # the fp64 masters are the state of this mode: gather them instead of the fp32 copies
+        p64 = [torch.zeros_like(sysm.pos64) for _ in range(world)] if world > 1 else [sysm.pos64]
+        if world > 1:
+            dist.all_gather(p64, sysm.pos64)
+        pos64 = torch.cat(p64).cpu().numpy()
+    myv = sysm.vel64 if acc64 else sysm.vel
     if world > 1:
-        vels = [torch.zeros_like(sysm.vel) for _ in range(world)]
-        dist.all_gather(vels, sysm.vel)
+        vels = [torch.zeros_like(myv) for _ in range(world)]
+        dist.all_gather(vels, myv)
         allv = torch.cat(vels)
     else:
-        allv = sysm.vel
+        allv = myv
     if rank == 0:
-        np.savez(path, pos=sysm.positions.cpu().numpy(), vel=allv.cpu().numpy())
-    if world > 1:
+        extra = dict(pos64=pos64) if acc64 else {}
+        np.savez(path, pos=sysm.positions.cpu().numpy(), vel=allv.cpu().numpy(), **extra)
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_ranks_on_one_gpu_match_single(nb, tmp_path, world):
+def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_on_one_gpu_match_single(nb, tmp_path, world):
+    port = _free_port()
     one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
     mp.spawn(_run, args=(1, 0, one), nprocs=1, join=True)
     mp.spawn(_run, args=(world, port, two), nprocs=world, join=True)
     a, b = np.load(one), np.load(two)
     # the sharded launch may pick another register blocking / source split: equal to fp32 rounding, not bitwise
     assert np.abs(a["pos"] - b["pos"]).max() < 5e-7 and np.abs(a["vel"] - b["vel"]).max() < 1e-5
+    p0, _ = nb.synthetic.body4_f32(N)
+    assert np.abs(b["pos"][:, :3] - p0[:, :3]).max() > 1e-6 and np.array_equal(b["pos"][:, 3], p0[:, 3])
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_on_one_gpu_match_single_acc64(nb, oracle, tmp_path, world):
+    """NB_F32_ACC64 sharded (BASELINE configs[4]'s arithmetic; bench.py --precision f32acc64 --gpus P): tgt_off != 0
+    launches with fp64 masters must move bodies like the unsharded run, and both like the fp64 oracle."""
+    one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
+    mp.spawn(_run, args=(1, 0, one, True), nprocs=1, join=True)
+    mp.spawn(_run, args=(world, _free_port(), two, True), nprocs=world, join=True)
+    a, b = np.load(one), np.load(two)
+    # fp64 masters: the pair arithmetic is fp32 in both, only the register blocking / slice order may differ
+    assert np.abs(a["pos64"] - b["pos64"])[:, :3].max() < 1e-9 and np.abs(a["vel"] - b["vel"]).max() < 1e-7
+    assert np.array_equal(a["pos64"][:, 3], b["pos64"][:, 3])
+    # the oracle, stepped the way this mode is defined: pair arithmetic on the fp32 copy of the positions, fp64 masters
+    # integrated with the fp64 sums (samples/nbody.cc:76-88 for the update)
+    syn = nb.synthetic
+    q, v, m = syn.bodies(N)
+    gm = (syn.G * m).astype(np.float32).astype(np.float64) / syn.G
+    for _ in range(STEPS):
+        acc = oracle.accel_rows(q.astype(np.float32).astype(np.float64), gm, syn.G, syn.EPS)
+        v = v + acc * 1e-2
+        q = q + v * 1e-2
+    # Trajectory-level bound, not a per-launch one (that is tests/test_gpu_f32_parity.py::test_config4_*): a master that
+    # sits within 1e-10 of an fp32 rounding boundary may round the other way on the GPU, which moves that body's copy by
+    # 6e-8 and its closest neighbour's force by up to G*m/eps^3 * 6e-8 ~ 1e-3, i.e. 1e-7 per step in q at dt = 1e-2.
+    # The bodies move by ~1e-3 over the 4 steps.
+    dq = np.abs(b["pos64"][:, :3].T - q).max()
+    dv = np.abs(b["vel"][:, :3].T - v).max()
+    assert dq < 2e-6 and dv < 2e-4, (dq, dv)
+    assert np.abs(b["pos64"][:, :3].T - syn.bodies(N)[0]).max() > 1e-4  # they did move
+
+
+def test_nccl_world1_in_place_all_gather(nb, tmp_path):
+    """The one RCCL aliasing check reachable on a one-GPU box: a world-size-1 `nccl` group runs the real
+    all_gather_into_tensor(buf, buf[lo:hi]) (send buffer = own slot of the receive buffer) every step; the trajectory
+    must equal the run without a process group bit for bit (same shard, same plan)."""
+    one, two = str(tmp_path / "one.npz"), str(tmp_path / "nccl.npz")
+    mp.spawn(_run, args=(1, 0, one), nprocs=1, join=True)
+    mp.spawn(_run, args=(1, _free_port(), two, False, "nccl"), nprocs=1, join=True)
+    a, b = np.load(one), np.load(two)
+    assert np.array_equal(a["pos"], b["pos"]) and np.array_equal(a["vel"], b["vel"])
+
+
+@pytest.mark.parametrize("world,acc64", [(2, False), (4, False), (4, True)])
+def test_overlapped_step_on_one_gpu_matches_single(nb, tmp_path, world, acc64):
+    """SURVEY §8(f)-3 with the real kernel: every rank cuts its step into phases (own shard / the shards before it / the
+    shards after it: NB_PHASE_FIRST, MIDDLE, LAST with the running sums in the workspace) around the asynchronous
+    exchange.  Same trajectory as the unsharded run, to the rounding of a reordered sum."""
+    one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
+    mp.spawn(_run, args=(1, 0, one, acc64), nprocs=1, join=True)
+    mp.spawn(_run, args=(world, _free_port(), two, acc64, "gloo", True), nprocs=world, join=True)
+    a, b = np.load(one), np.load(two)
+    if acc64:
+        assert np.abs(a["pos64"] - b["pos64"])[:, :3].max() < 1e-9 and np.abs(a["vel"] - b["vel"]).max() < 1e-7
+    else:
+        assert np.abs(a["pos"] - b["pos"]).max() < 5e-7 and np.abs(a["vel"] - b["vel"]).max() < 1e-5
     p0, _ = nb.synthetic.body4_f32(N)
     assert np.abs(b["pos"][:, :3] - p0[:, :3]).max() > 1e-6 and np.array_equal(b["pos"][:, 3], p0[:, 3])

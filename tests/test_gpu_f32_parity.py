@@ -175,3 +175,182 @@ def test_fp32_rejects_eps_zero_and_devices(nb):
         q = np.zeros((3, 16)); q[0] = np.arange(16)
         with pytest.raises(nb.capi.NBodyError):
             ctx.set_state(q, q, np.ones(16), np.ones(16, dtype=np.uint8))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE configs[3] / configs[4]: the PER-RANK launch shapes of the 8-GPU runs, on one GPU, against the oracle.
+# A rank of P = 8 holds all n_src sources and owns n_tgt = n_src / 8 targets starting at tgt_off = rank * n_tgt.
+
+def _oracle_rows(oracle, syn, pos, rows):
+    """fp64 reference accelerations + sum of magnitudes for single target rows, from the fp32 records the GPU sees."""
+    q32 = np.ascontiguousarray(pos[:, :3].T.astype(np.float64))
+    gm = pos[:, 3].astype(np.float64) / syn.G
+    ref = np.empty((3, len(rows)))
+    s = np.empty(len(rows))
+    for c, i in enumerate(rows):
+        r, ab = oracle.accel_rows(q32, gm, syn.G, syn.EPS, int(i), int(i) + 1, want_abs=True)
+        ref[:, c], s[c] = r[:, 0], ab[0]
+    return ref, s
+
+
+def _check_step_rows(pos, vel0, out, vel1, rows, off, ref, s, dt, tol):
+    """rows of one fused force+kick+drift launch against  v' = v + a*dt ; q' = q + v'*dt  (samples/nbody.cc:76-88)."""
+    dt32 = np.float64(np.float32(dt))
+    for c, i in enumerate(rows):
+        a_gpu = (vel1[i - off, :3].astype(np.float64) - vel0[i - off, :3].astype(np.float64)) / dt32
+        # v' is stored in fp32: a is recovered to ulp(v')/dt
+        slack = 2.0 ** -23 * np.abs(vel1[i - off, :3]).max() / dt32
+        assert np.abs(a_gpu - ref[:, c]).max() <= tol * s[c] + slack, (i, a_gpu, ref[:, c])
+        q_exp = (vel1[i - off, :3].astype(np.float64) * dt32 + pos[i, :3].astype(np.float64)).astype(np.float32)
+        assert np.abs(out[i, :3] - q_exp).max() <= np.spacing(np.abs(q_exp).max()), (i, out[i], q_exp)
+        assert out[i, 3] == pos[i, 3]
+
+
+@pytest.mark.parametrize("rank", [0, 3, 7])
+def test_config3_rank_shape_f32(nb, oracle, rank):
+    """configs[3]: N = 2^22, fp32, P = 8  ->  n_src = 2^22, n_tgt = 2^19, tgt_off = rank * 2^19.  Accelerations of 8
+    strided rows of the shard, and (rank 3) one fused step, with the plan the sharded host gets by default."""
+    import torch
+    syn = nb.synthetic
+    n, per = 1 << 22, 1 << 19
+    off = rank * per
+    pos, _ = syn.body4_f32(n)
+    src = torch.from_numpy(pos).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    ws = torch.empty(nb.capi.workspace_bytes_f32(per), dtype=torch.uint8, device="cuda")
+    acc = torch.zeros((per, 4), dtype=torch.float32, device="cuda")
+    nb.capi.launch_f32(src.data_ptr(), 0, n, off, per, syn.EPS ** 2, syn.DT, stream, acc_ptr=acc.data_ptr(),
+                       workspace_ptr=ws.data_ptr(), workspace_bytes=ws.numel(), accel_only=True)
+    torch.cuda.synchronize()
+    tpl, js, wg = nb.capi.plan_f32(n, per, workspace_bytes=ws.numel())
+    assert (tpl, wg) == (8, 512) and js >= 16  # the sliced 512 x R8 plan of the bench, more slices for the shard
+    rows = off + np.arange(8) * (per // 8) + 11
+    rows[-1] = off + per - 1  # the shard's last body
+    ref, s = _oracle_rows(oracle, syn, pos, rows)
+    a = acc.cpu().numpy()[rows - off, :3].T.astype(np.float64)
+    assert (np.abs(a - ref).max(axis=0) / s).max() < TOL_F32
+    if rank == 3:
+        dt = 1e-2
+        _, vel_np = syn.body4_f32(n, off, off + per)
+        vel = torch.from_numpy(vel_np).cuda()
+        out = torch.zeros_like(src)
+        nb.capi.launch_f32(src.data_ptr(), out.data_ptr(), n, off, per, syn.EPS ** 2, dt, stream,
+                           vel_ptr=vel.data_ptr(), workspace_ptr=ws.data_ptr(), workspace_bytes=ws.numel())
+        torch.cuda.synchronize()
+        o = out.cpu().numpy()
+        _check_step_rows(pos, vel_np, o, vel.cpu().numpy(), rows, off, ref, s, dt, TOL_F32)
+        assert not o[:off].any() and not o[off + per:].any()  # only the rank's own slot is written
+
+
+def test_config4_rank_shape_acc64(nb, oracle):
+    """configs[4]: N = 2^24, fp32 pair math / fp64 accumulate, P = 8  ->  n_src = 2^24, n_tgt = 2^21,
+    tgt_off = 5 * 2^21: accelerations of 8 rows and one fused step (fp64 masters) against the oracle."""
+    import torch
+    syn = nb.synthetic
+    n, per, rank = 1 << 24, 1 << 21, 5
+    off = rank * per
+    pos, _ = syn.body4_f32(n)
+    src = torch.from_numpy(pos).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    ws = torch.empty(nb.capi.workspace_bytes_f32(per, True), dtype=torch.uint8, device="cuda")
+    acc = torch.zeros((per, 4), dtype=torch.float64, device="cuda")
+    nb.capi.launch_f32(src.data_ptr(), 0, n, off, per, syn.EPS ** 2, syn.DT, stream, acc_ptr=acc.data_ptr(),
+                       acc64=True, workspace_ptr=ws.data_ptr(), workspace_bytes=ws.numel(), accel_only=True)
+    torch.cuda.synchronize()
+    rows = off + np.arange(8) * (per // 8) + 7
+    rows[-1] = off + per - 1
+    ref, s = _oracle_rows(oracle, syn, pos, rows)
+    a = acc.cpu().numpy()[rows - off, :3].T
+    assert (np.abs(a - ref).max(axis=0) / s).max() < TOL_ACC64
+    # one fused step of the shard: fp64 masters integrate, the fp32 copy goes to the rank's slot of `out`
+    dt = 1e-2
+    q, v, m = syn.bodies(n, off, off + per)
+    p64 = torch.from_numpy(np.concatenate([q.T, (syn.G * m)[:, None]], axis=1)).cuda()
+    v64 = torch.from_numpy(np.concatenate([v.T, np.zeros((per, 1))], axis=1)).cuda()
+    out = torch.zeros_like(src)
+    nb.capi.launch_f32(src.data_ptr(), out.data_ptr(), n, off, per, syn.EPS ** 2, dt, stream, acc64=True,
+                       pos64_ptr=p64.data_ptr(), vel64_ptr=v64.data_ptr(), workspace_ptr=ws.data_ptr(),
+                       workspace_bytes=ws.numel())
+    torch.cuda.synchronize()
+    r = rows - off
+    dt32 = np.float64(np.float32(dt))
+    v_new = v64.cpu().numpy()[r, :3]
+    p_new = p64.cpu().numpy()[r, :3]
+    v_exp = v.T[r] + ref.T * dt32
+    assert np.all(np.abs(v_new - v_exp) <= TOL_ACC64 * s[:, None] * dt32 + 1e-15)
+    assert np.all(np.abs(p_new - (q.T[r] + v_new * dt32)) <= 4e-16)
+    o = out[off:off + per].cpu().numpy()[r]
+    assert np.array_equal(o[:, :3], p_new.astype(np.float32)) and np.array_equal(o[:, 3], pos[rows, 3])
+
+
+def test_bench_plan_step_against_oracle(nb, oracle):
+    """The exact kernel bench.py times — nbody_force_f32<4,false,false,true,true,512> (512-thread workgroups, R = 8,
+    source slices, step mode) + its reducer's kick-drift — stepped once against the oracle: ragged N = 131072 + 77
+    through nb_step's default plan, 40 rows of q,v vs  v + a_oracle*dt , q + v'*dt  (samples/nbody.cc:76-88)."""
+    syn = nb.synthetic
+    n, dt = 131072 + 77, 1e-2
+    ws = nb.capi.workspace_bytes_f32(n)
+    assert nb.capi.kernel_name_f32(n, n, workspace_bytes=ws) == "nbody_force_f32<4, false, false, true, true, 512>"
+    assert nb.capi.kernel_name_f32(1 << 20, 1 << 20, workspace_bytes=nb.capi.workspace_bytes_f32(1 << 20)) == \
+        "nbody_force_f32<4, false, false, true, true, 512>"
+    q, v, m = syn.bodies(n)
+    pos, vel = syn.body4_f32(n)
+    with nb.capi.Context(n, nb.capi.NB_F32, 0, G=syn.G, eps=syn.EPS, dt=dt) as ctx:
+        ctx.set_state(q, v, m)
+        ctx.step(1, 1)
+        qg, vg = ctx.get_state()
+    rows = np.concatenate([np.arange(36) * (n // 36) + 3, [n - 77, n - 76, n - 2, n - 1]])  # incl. the ragged tail block
+    ref, s = _oracle_rows(oracle, syn, pos, rows)
+    out = np.concatenate([qg.T, pos[:, 3:4].astype(np.float64)], axis=1).astype(np.float32)
+    _check_step_rows(pos, vel, out, vg.T.astype(np.float32), rows, 0, ref, s, dt, TOL_F32)
+
+
+@pytest.mark.parametrize("acc64", [False, True])
+def test_phased_step_equals_whole_step(nb, oracle, acc64):
+    """A step cut into three launches over disjoint source ranges (NB_PHASE_FIRST / MIDDLE / LAST, running sums in the
+    workspace; how the overlapped multi-GPU step consumes its own shard before the gathered ones): same accelerations as
+    the oracle, same update as the one-launch step to the rounding of a reordered sum; misuse is refused."""
+    import torch
+    c, syn = nb.capi, nb.synthetic
+    n, off, cnt, dt = 3 * 4096 + 100, 4096, 4096, 1e-2
+    pos, _ = syn.body4_f32(n)
+    _, vel_np = syn.body4_f32(n, off, off + cnt)
+    src = torch.from_numpy(pos).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    ws = torch.empty(c.workspace_bytes_f32(cnt, acc64), dtype=torch.uint8, device="cuda")
+    q, v, m = syn.bodies(n, off, off + cnt)
+    outs = []
+    for ranges in ([(0, 0, c.NB_PHASE_WHOLE)],
+                   [(off, off + cnt, c.NB_PHASE_FIRST), (0, off, c.NB_PHASE_MIDDLE), (off + cnt, n, c.NB_PHASE_LAST)]):
+        out = torch.zeros_like(src)
+        kw = dict(workspace_ptr=ws.data_ptr(), workspace_bytes=ws.numel(), acc64=acc64)
+        if acc64:
+            p64 = torch.from_numpy(np.concatenate([q.T, (syn.G * m)[:, None]], axis=1)).cuda()
+            v64 = torch.from_numpy(np.concatenate([v.T, np.zeros((cnt, 1))], axis=1)).cuda()
+            kw.update(pos64_ptr=p64.data_ptr(), vel64_ptr=v64.data_ptr())
+        else:
+            vel = torch.from_numpy(vel_np).cuda()
+            kw.update(vel_ptr=vel.data_ptr())
+        for b, e, ph in ranges:
+            c.launch_f32(src.data_ptr(), out.data_ptr(), n, off, cnt, syn.EPS ** 2, dt, stream, phase=ph, src_begin=b,
+                         src_end=e, **kw)
+        torch.cuda.synchronize()
+        outs.append((out.cpu().numpy(), (v64 if acc64 else vel).cpu().numpy()))
+    (o0, v0), (o1, v1) = outs
+    assert np.abs(o0 - o1).max() <= 6e-8 and np.abs(v0 - v1).max() <= (1e-12 if acc64 else 2e-9)
+    assert not o1[:off].any() and not o1[off + cnt:].any()
+    rows = off + np.array([0, 1, 777, 2048, cnt - 1])
+    ref, s = _oracle_rows(oracle, syn, pos, rows)
+    dt32 = np.float64(np.float32(dt))
+    a_gpu = (v1[rows - off, :3].astype(np.float64) - (v.T if acc64 else vel_np[:, :3].astype(np.float64))[rows - off]) / dt32
+    slack = 0 if acc64 else 2.0 ** -23 * np.abs(v1[rows - off, :3]).max() / dt32
+    assert np.all(np.abs(a_gpu.T - ref) <= (TOL_ACC64 if acc64 else TOL_F32) * s + slack)
+    # refused: a phase without a workspace, a range that is not whole tiles, a range past the end
+    base = dict(vel_ptr=1, acc64=False)
+    for bad in (dict(phase=c.NB_PHASE_FIRST), dict(src_begin=100, src_end=512, workspace_ptr=ws.data_ptr(),
+                                                  workspace_bytes=ws.numel()),
+                dict(src_begin=0, src_end=300, workspace_ptr=ws.data_ptr(), workspace_bytes=ws.numel()),
+                dict(src_begin=256, src_end=n + 1, workspace_ptr=ws.data_ptr(), workspace_bytes=ws.numel())):
+        with pytest.raises(c.NBodyError) as e:
+            c.launch_f32(src.data_ptr(), src.data_ptr(), n, off, cnt, syn.EPS ** 2, dt, stream, **base, **bad)
+        assert e.value.code == c.NB_ERR_INVALID

@@ -1,0 +1,156 @@
+"""The whole-program driver nb_solve and the scenario engines behind it: every scenario (P1, P2, one Problem-3 run per
+device) from step 0 in one launch stream per GPU; several GPUs; the cheapest-first queue for scenarios beyond one
+stream (hw5.cu:490-493,574-596); the batched persistent engine; the ABI's refusal paths added with them."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, case_path, read_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _solve_case(nb, oracle, case, **kw):
+    s = oracle.read_input(case_path(case, "in"))
+    got = nb.capi.solve(s.n, s.planet, s.asteroid, s.q, s.v, s.m, s.is_device, **kw)
+    gold = read_golden(case)
+    return ("%.16e\n%d\n%d %.16e\n" % got), gold[4]
+
+
+@pytest.mark.parametrize("case", ["b30", "b90", "b200"])
+def test_solve_spread_over_two_device_slots(nb, oracle, case):
+    """devices=[0,0]: the multi-GPU code path (one host thread and launch stream per listed device, scenarios dealt
+    round-robin: P1 -> first, P2 -> second, ...) on the one GPU of the box.  Answers byte-identical to the goldens."""
+    text, gold = _solve_case(nb, oracle, case, devices=[0, 0])
+    assert text == gold
+
+
+@pytest.mark.parametrize("case,cap", [("b30", 2), ("b80", 3), ("b200", 4)])
+def test_solve_queue_beyond_one_stream(nb, oracle, case, cap, monkeypatch):
+    """NB_SOLVE_MAX_BATCH < 2 + D: the devices that do not fit the first wave are queued in ascending arrival step
+    (hw5.cu:574-585) and skipped once they cannot beat a feasible one (hw5.cu:490-493); the answer does not change.
+    b80: device 76 (arrival 151213) is the answer; 77-79 arrive later."""
+    monkeypatch.setenv("NB_SOLVE_MAX_BATCH", str(cap))
+    text, gold = _solve_case(nb, oracle, case)
+    assert text == gold
+
+
+def test_batched_persistent_engine_equals_single_runs(nb, oracle):
+    """K3 batched (one launch, one workgroup per scenario) vs one persistent launch per scenario on b50: P1, P2 with
+    snapshots, and both Problem-3 runs from step 0 — identical results and bitwise identical final states."""
+    c = nb.capi
+    s = oracle.read_input(case_path("b50", "in"))
+    devs = [int(i) for i in np.flatnonzero(s.is_device)]
+    m0 = s.m.copy()
+    m0[devs] = 0.0
+    kws = [dict(kind=c.NB_SCN_MIN_DIST, planet=s.planet, asteroid=s.asteroid, last_step=60000),
+           dict(kind=c.NB_SCN_FIRST_HIT, planet=s.planet, asteroid=s.asteroid, watch=devs),
+           dict(kind=c.NB_SCN_MISSILE, planet=s.planet, asteroid=s.asteroid, watch=[devs[0]]),
+           dict(kind=c.NB_SCN_MISSILE, planet=s.planet, asteroid=s.asteroid, watch=[devs[1]], last_step=120000)]
+    out = {}
+    for mode in ("single", "batched"):
+        ctxs = [c.Context(s.n) for _ in kws]
+        for k, x in enumerate(ctxs):
+            x.set_state(s.q, s.v, m0 if k == 0 else s.m, s.is_device)
+        res = [x.run_scenario(engine=2, **kw) for x, kw in zip(ctxs, kws)] if mode == "single" else \
+            c.run_scenarios_batched(ctxs, [dict(engine=2, **kw) for kw in kws])
+        snap = []
+        for slot in range(len(devs)):  # P2's snapshots must be the same states
+            with c.Context(s.n) as r:
+                r.restore_snapshot_from(ctxs[1], slot)
+                snap.append(r.get_state())
+        out[mode] = (res, [x.get_state() for x in ctxs], snap)
+        for x in ctxs:
+            x.close()
+    (ra, sa, na), (rb, sb, nb_) = out["single"], out["batched"]
+    assert ra == rb, (ra, rb)
+    assert rb[1]["hit_step"] == 103140 and rb[1]["arrival_step"] == [87218, 89015]
+    assert rb[2]["hit_step"] == -2 and rb[2]["arrival_step"] == [87218] and rb[3]["steps_done"] == 120000
+    assert rb[0]["steps_done"] == 60000
+    for (qa, va), (qb, vb) in list(zip(sa, sb))[:1] + list(zip(sa, sb))[2:] + list(zip(na, nb_)):
+        assert np.array_equal(qa, qb) and np.array_equal(va, vb)  # (P2's own final state is unspecified after a hit)
+
+
+def test_missile_scenario_takes_one_device(nb, oracle):
+    """One device is destroyed per Problem-3 run (hw5.cu:289-309): more than one watched device is refused by both
+    entry points instead of silently destroying only one of them."""
+    c = nb.capi
+    s = oracle.read_input(case_path("b80", "in"))
+    devs = [int(i) for i in np.flatnonzero(s.is_device)]
+    with c.Context(s.n) as a, c.Context(s.n) as b:
+        for x in (a, b):
+            x.set_state(s.q, s.v, s.m, s.is_device)
+        with pytest.raises(c.NBodyError) as e:
+            a.run_scenario(c.NB_SCN_MISSILE, s.planet, s.asteroid, watch=devs[:2], last_step=10)
+        assert e.value.code == c.NB_ERR_INVALID
+        with pytest.raises(c.NBodyError) as e:
+            c.run_scenarios_batched([a, b], [dict(kind=c.NB_SCN_MISSILE, planet=s.planet, asteroid=s.asteroid,
+                                                  watch=devs[:2], last_step=10)] * 2)
+        assert e.value.code == c.NB_ERR_INVALID
+        r = a.run_scenario(c.NB_SCN_MISSILE, s.planet, s.asteroid, watch=devs[:1], last_step=10)  # one is fine
+        assert r["steps_done"] == 10
+
+
+def test_restore_snapshot_of_a_device_that_never_arrived(nb, oracle):
+    """A FIRST_HIT run that ends before device k's missile arrives leaves slot k unwritten: restoring it is a call
+    sequence error (NB_ERR_STATE), not an upload of uninitialised memory; NB_SCN_NO_SNAPSHOT keeps no slots at all."""
+    c = nb.capi
+    s = oracle.read_input(case_path("b30", "in"))
+    devs = [int(i) for i in np.flatnonzero(s.is_device)]
+    with c.Context(s.n) as p2, c.Context(s.n) as dst:
+        p2.set_state(s.q, s.v, s.m, s.is_device)
+        r = p2.run_scenario(c.NB_SCN_FIRST_HIT, s.planet, s.asteroid, watch=devs, last_step=1000)
+        assert r["arrival_step"] == [-2, -2] and r["hit_step"] == -2
+        with pytest.raises(c.NBodyError) as e:
+            dst.restore_snapshot_from(p2, 0)
+        assert e.value.code == c.NB_ERR_STATE and "no missile arrival" in str(e.value)
+    with c.Context(s.n) as p2, c.Context(s.n) as dst:
+        p2.set_state(s.q, s.v, s.m, s.is_device)
+        r = p2.run_scenario(c.NB_SCN_FIRST_HIT, s.planet, s.asteroid, watch=devs, flags=c.NB_SCN_NO_SNAPSHOT)
+        assert r["arrival_step"] == [178526, 177846] and r["hit_step"] == 180769
+        with pytest.raises(c.NBodyError):
+            dst.restore_snapshot_from(p2, 1)
+
+
+def test_load_state_refuses_other_parameters(nb, oracle, tmp_path):
+    """A checkpoint resumes the run it came from: another dt, eps, G or precision is NB_ERR_INVALID with the reason in
+    nb_last_error; the explicit route (read_state_file + set_state) still loads it."""
+    c = nb.capi
+    s = oracle.read_input(case_path("b20", "in"))
+    path = str(tmp_path / "b20.nbst")
+    with c.Context(s.n) as ctx:
+        ctx.set_state(s.q, s.v, s.m, s.is_device)
+        ctx.step(1, 3)
+        ctx.save_state(path, step=3)
+        q3, v3 = ctx.get_state()
+    for kw in (dict(dt=30.0), dict(eps=2e-3), dict(G=1e-11)):
+        with c.Context(s.n, **kw) as ctx, pytest.raises(c.NBodyError) as e:
+            ctx.load_state(path)
+        assert e.value.code == c.NB_ERR_INVALID and "does not match" in str(e.value)
+    with c.Context(s.n, c.NB_F32_ACC64) as ctx, pytest.raises(c.NBodyError) as e:
+        ctx.load_state(path)
+    assert e.value.code == c.NB_ERR_INVALID
+    h, q, v, m, dev = c.read_state_file(path)
+    assert h["step"] == 3 and np.array_equal(q, q3) and np.array_equal(v, v3) and np.array_equal(dev, s.is_device)
+    with c.Context(s.n, dt=30.0) as ctx:
+        ctx.set_state(q, v, m, dev)
+        ctx.step(4, 1)
+
+
+@pytest.mark.parametrize("case", ["b30", "b200"])
+def test_cli_binary_input(nb, case, tmp_path):
+    """hw5 <input> accepts the binary (NBODYST2) form of the same data — nbconv's output — and prints
+    the same three lines as for the text file."""
+    st, out = str(tmp_path / f"{case}.nbst"), str(tmp_path / "out")
+    subprocess.run([os.path.join(ROOT, "bin", "nbconv"), case_path(case, "in"), st], check=True)
+    subprocess.run([os.path.join(ROOT, "bin", "hw5"), st, out], check=True, timeout=300)
+    assert open(out).read() == read_golden(case)[4]
+    # a checkpoint without planet/asteroid is not a program input
+    c = nb.capi
+    _, q, v, m, dev = c.read_state_file(st)
+    plain = str(tmp_path / "plain.nbst")
+    c.write_state_file(plain, q, v, m, dev)
+    p = subprocess.run([os.path.join(ROOT, "bin", "hw5"), plain, out], capture_output=True)
+    assert p.returncode == 1 and b"cannot read state file" in p.stderr
