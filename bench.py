@@ -102,7 +102,7 @@ def load_traffic(n_bodies, world, kernel, j_split):
     return e.get("hbm_bytes_per_launch"), e.get("reduce_share_of_span")
 
 
-def sharded_check(torch, dist, world, rank, device, dev_index):
+def sharded_check(torch, dist, world, rank, device, dev_index, backend):
     """world > 1 only, after the timed region: the same sharded stepper (index shards, tgt_off != 0 launches, in-place
     RCCL all-gather, ping-pong) on a small system, against the UNSHARDED run of the same bodies on rank 0's GPU through
     nb_step.  Proves on the real multi-GPU node what tests/test_gpu_distributed.py rehearses on one GPU."""
@@ -117,6 +117,8 @@ def sharded_check(torch, dist, world, rank, device, dev_index):
         s.step()
     torch.cuda.synchronize()
     bits = s.positions.contiguous().view(torch.int32).to(torch.int64).sum().reshape(1)  # checksum of the gathered array
+    if backend != "nccl":
+        bits = bits.cpu()
     hi_, lo_ = bits.clone(), bits.clone()
     dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
     dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
@@ -178,10 +180,12 @@ def main():
     device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
+        patience = datetime.timedelta(seconds=300)  # a wedged collective ends the run instead of hanging it
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", device_id=device, timeout=patience)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, timeout=patience)
 
     n = args.bodies
     acc64 = args.precision == "f32acc64"
@@ -239,38 +243,53 @@ def main():
 
     # --- untimed diagnostics of the multi-GPU path (after the timed region; not part of `value`)
     exchange_ms = check = overlap_ab = None
+    diag_errors = []
     if world > 1:
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-        barrier()
-        ev[0].record()
-        for _ in range(20):
-            sysm._exchange(sysm.positions)  # re-gathers the current positions: a no-op on the data
-        ev[1].record()
-        torch.cuda.synchronize()
-        exchange_ms = ev[0].elapsed_time(ev[1]) / 20
-        if args.backend == "nccl":
-            check = sharded_check(torch, dist, world, rank, device, dev_index)
+        # every rank takes the same path through these: an exception that all ranks raise alike (a refused argument) is
+        # recorded in the JSON instead of losing the measurement above
+        try:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            barrier()
+            ev[0].record()
+            for _ in range(20):
+                sysm._exchange(sysm.positions)  # re-gathers the current positions: a no-op on the data
+            ev[1].record()
+            torch.cuda.synchronize()
+            exchange_ms = ev[0].elapsed_time(ev[1]) / 20
+        except Exception as e:  # noqa: BLE001
+            diag_errors.append(f"exchange_ms: {type(e).__name__}: {e}")
+        try:
+            check = sharded_check(torch, dist, world, rank, device, dev_index, args.backend)
+        except Exception as e:  # noqa: BLE001
+            diag_errors.append(f"sharded_check: {type(e).__name__}: {e}")
         # the same system stepped with the other setting of --overlap, a few steps, wall clock (max over ranks)
-        sysm.kernel_events = None
-        ab = {}
-        for mode in (False, True):
-            if mode and sysm.n_tgt % 256:
-                continue
-            sysm._wait_gather()
-            sysm.overlap = mode
-            sysm.step()
-            barrier()
-            t1 = time.perf_counter()
-            for _ in range(min(5, max(2, args.steps))):
+        try:
+            sysm.kernel_events = None
+            ab = {}
+            k_ab = min(5, max(2, args.steps))
+            for mode in (False, True):
+                if mode and sysm.n_tgt % 256:
+                    continue
+                sysm._wait_gather()
+                sysm.overlap = mode
                 sysm.step()
-            barrier()
-            w = torch.tensor([(time.perf_counter() - t1) / min(5, max(2, args.steps))], dtype=torch.float64,
-                             device=device if args.backend == "nccl" else "cpu")
-            dist.all_reduce(w, op=dist.ReduceOp.MAX)
-            ab["on" if mode else "off"] = float(w.item()) * 1e3
-        sysm._wait_gather()
+                barrier()
+                t1 = time.perf_counter()
+                for _ in range(k_ab):
+                    sysm.step()
+                barrier()
+                w = torch.tensor([(time.perf_counter() - t1) / k_ab], dtype=torch.float64,
+                                 device=device if args.backend == "nccl" else "cpu")
+                dist.all_reduce(w, op=dist.ReduceOp.MAX)
+                ab["on" if mode else "off"] = float(w.item()) * 1e3
+            overlap_ab = ab
+        except Exception as e:  # noqa: BLE001
+            diag_errors.append(f"overlap_ab: {type(e).__name__}: {e}")
+        try:
+            sysm._wait_gather()
+        except Exception:  # noqa: BLE001
+            pass
         sysm.overlap = args.overlap and world > 1
-        overlap_ab = ab
 
     if rank == 0:
         pairs_step = n * (n - 1)
@@ -323,6 +342,8 @@ def main():
             out["exchange_ms"] = exchange_ms  # one all-gather of float4[N] by itself, mean of 20
         if check is not None:
             out["sharded_check"] = check
+        if diag_errors:
+            out["diagnostics_errors"] = diag_errors
         if overlap_ab:
             out["overlap"] = bool(args.overlap)
             out["overlap_ab"] = {"ms_per_step": overlap_ab, "note": "two-phase step (own-shard sources during the "

@@ -77,14 +77,16 @@ typedef struct nb_scenario {
                                       one device is destroyed per run, hw5.cu:289-309; more is NB_ERR_INVALID) */
     int32_t watch[NB_MAX_WATCH];   /* their body indices */
     int32_t sync_every;            /* host polls the hit flag every this many steps (hw5.cu:72: 2000); <=0 -> 2000 */
-    int32_t engine;                /* 0 = auto; 1 = one launch per step (any n); 2 = whole step loop inside one
-                                      persistent single-workgroup launch (n <= 128) */
+    int32_t engine;                /* 0 = auto; 1 = one launch per step (any n; long runs replay a hipGraph of launches);
+                                      2 = whole step loop inside one persistent single-workgroup launch (n <= 128) */
     int32_t flags;                 /* NB_SCN_NO_SNAPSHOT: FIRST_HIT records arrival steps but keeps no (q,v) snapshots */
     int32_t reserved;
     double planet_radius;          /* 1e7   nbody.cc:17 */
     double missile_speed;          /* 1e6   nbody.cc:18 */
 } nb_scenario;
 #define NB_SCN_NO_SNAPSHOT 1
+#define NB_SCN_EAGER 2 /* per-step engine: issue every launch from the host even for long runs (default: runs of >= 4000
+                          steps replay a captured hipGraph of 1000 launches, the host looks at the monitors once per replay) */
 
 typedef struct nb_scenario_result {
     double min_dist2;                     /* MIN_DIST: min squared planet–asteroid distance (sqrt on the host) */

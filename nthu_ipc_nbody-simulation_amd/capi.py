@@ -272,6 +272,7 @@ class Context:
 
 
 NB_SCN_NO_SNAPSHOT = 1
+NB_SCN_EAGER = 2
 
 
 def _scenario_struct(kind, planet, asteroid, first_step=0, last_step=200000, watch=(), sync_every=2000,

@@ -55,6 +55,11 @@ struct nb_context {
     int fst_len = 0;
     int* done_dev = nullptr;
     int* done_host = nullptr;  // pinned
+    F64Ctl* ctl_host = nullptr;  // pinned staging copy of *ctl
+    F64Ctl* ctl = nullptr;     // graph-driven stepping: {base step, active} read by every launch of a replayed graph
+    void* arena = nullptr;       // F64: ONE device allocation behind q, v, m, coef, acc, mon, done_dev, ctl ...
+    void* host_arena = nullptr;  // ... and one pinned allocation behind mon_host, done_host (a context costs two
+                                 // allocations instead of ten: nb_solve creates 2 + D of them per program run)
     std::vector<double> m_host;
     std::vector<uint8_t> dev_host;
 
@@ -105,14 +110,13 @@ void free_dev(T*& p) {
 }
 
 void release(nb_context* c) {
-    free_dev(c->q[0]); free_dev(c->q[1]); free_dev(c->v); free_dev(c->m); free_dev(c->coef); free_dev(c->acc);
-    free_dev(c->mon); free_dev(c->snap_q); free_dev(c->snap_v); free_dev(c->fst_dev); free_dev(c->done_dev);
+    free_dev(c->arena);  // q, v, m, coef, acc, mon, done_dev, ctl
+    free_dev(c->snap_q); free_dev(c->snap_v); free_dev(c->fst_dev);
     free_dev(c->gm_large); free_dev(c->partial_large);
-    if (c->done_host) (void)hipHostFree(c->done_host);
+    if (c->host_arena) (void)hipHostFree(c->host_arena);  // mon_host, done_host
     free_dev(c->pos[0]); free_dev(c->pos[1]); free_dev(c->vel); free_dev(c->pos64); free_dev(c->vel64);
     free_dev(c->acc32);
     free_dev(c->partial);
-    if (c->mon_host) (void)hipHostFree(c->mon_host);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -262,15 +266,25 @@ int nb_create(nb_context** out, const nb_config* cfg) {
     NB_HIP(c, hipEventCreate(&c->ev1));
     const size_t n = (size_t)c->n;
     if (cfg->precision == NB_F64) {
-        NB_HIP(c, hipMalloc(&c->q[0], 3 * n * sizeof(double)));
-        NB_HIP(c, hipMalloc(&c->q[1], 3 * n * sizeof(double)));
-        NB_HIP(c, hipMalloc(&c->v, 3 * n * sizeof(double)));
-        NB_HIP(c, hipMalloc(&c->m, n * sizeof(double)));
-        NB_HIP(c, hipMalloc(&c->coef, n * sizeof(double)));
-        NB_HIP(c, hipMalloc(&c->acc, 3 * n * sizeof(double)));
-        NB_HIP(c, hipMalloc(&c->mon, sizeof(F64Monitor)));
-        NB_HIP(c, hipHostMalloc(&c->mon_host, sizeof(F64Monitor)));
+        // one arena: [q0 3n][q1 3n][v 3n][acc 3n][m n][coef n] doubles, then monitor, done word, graph control word
+        const size_t planes = (14 * n * sizeof(double) + 255) / 256 * 256;
+        NB_HIP(c, hipMalloc(&c->arena, planes + 256 + 256));
+        double* base = (double*)c->arena;
+        c->q[0] = base; c->q[1] = base + 3 * n; c->v = base + 6 * n; c->acc = base + 9 * n;
+        c->m = base + 12 * n; c->coef = base + 13 * n;
+        c->mon = (F64Monitor*)((char*)c->arena + planes);
+        static_assert(sizeof(F64Monitor) <= 224, "monitor + done word share one 256-byte slot");
+        c->done_dev = (int*)((char*)c->arena + planes + 224);
+        c->ctl = (F64Ctl*)((char*)c->arena + planes + 256);
+        NB_HIP(c, hipHostMalloc(&c->host_arena, 256));
+        c->mon_host = (F64Monitor*)c->host_arena;
+        c->done_host = (int*)((char*)c->host_arena + 224);
+        c->ctl_host = (F64Ctl*)((char*)c->host_arena + 232);
         c->split = auto_split_f64(c->n, c->n_cus);
+        if (const char* e = getenv("NB_F64_SPLIT")) {  // experiments: lanes per target of the fp64 step kernel (power of two)
+            const int S = atoi(e);
+            if (S >= 1 && S <= 64 && !(S & (S - 1))) c->split = S;
+        }
         const int large_min = cfg->f64_large_min > 0 ? cfg->f64_large_min : F64_LARGE_MIN;
         if (c->n >= large_min) {  // plain steps of a large fp64 system go through K1-f64
             c->slices_large = plan_f64_large_slices(c->n, c->n_cus);
@@ -533,22 +547,21 @@ int ensure_fst_table(nb_context* c, int last_step) {
     return NB_OK;
 }
 
-// K3 reports the index of the last state it computed through a device word + its pinned host copy
-int ensure_done_word(nb_context* c) {
-    if (!c->done_dev) {
-        NB_HIP(c, hipMalloc(&c->done_dev, sizeof(int)));
-        NB_HIP(c, hipHostMalloc(&c->done_host, sizeof(int)));
-    }
-    return NB_OK;
-}
+// K3 reports the index of the last state it computed through a device word + its pinned host copy (part of the arenas)
+int ensure_done_word(nb_context* c) { return (c->done_dev && c->done_host) ? NB_OK : NB_ERR_STATE; }
 
-// `err` = the context that reports a HIP failure (the batch leader when several contexts share a stream)
-int reset_monitor(nb_context* err, nb_context* c, hipStream_t stream) {
+void reset_monitor_host(nb_context* c) {
     F64Monitor* mh = c->mon_host;
     mh->min_d2 = std::numeric_limits<double>::infinity();
     mh->hit_step = -2;
     for (int k = 0; k < MAX_WATCH; ++k) mh->arrival_step[k] = -2;
     for (int k = 0; k < NB_MAX_WATCH; ++k) c->snap_arrival[k] = -2;
+}
+
+// `err` = the context that reports a HIP failure (the batch leader when several contexts share a stream)
+int reset_monitor(nb_context* err, nb_context* c, hipStream_t stream) {
+    F64Monitor* mh = c->mon_host;
+    reset_monitor_host(c);
     NB_HIP(err, hipMemcpyAsync(c->mon, mh, sizeof(F64Monitor), hipMemcpyHostToDevice, stream));
     return NB_OK;
 }
@@ -592,6 +605,11 @@ F64SmallArgs small_args(nb_context* c, const F64Scenario& sc, bool want_snap, co
 }
 
 constexpr int SMALL_CHUNK = 50000;  // K3: steps per launch, so that the host can stop relaunching after a hit
+constexpr int GRAPH_CHUNK = 1000;      // K2, graph-driven: steps per replay (even: the ping-pong buffers are back in
+                                       // place after a chunk)
+constexpr int GRAPH_MIN_STEPS = 4000;  // shorter ranges are launched eagerly: capture + instantiate would cost more
+
+int run_batched_impl(nb_context** ctxs, const nb_scenario* scns, nb_scenario_result* results, int count);
 
 int run_scenario_impl(nb_context* c, const nb_scenario* s, nb_scenario_result* res) {
     if (int rc = check_scenario(c, s)) return rc;
@@ -626,6 +644,9 @@ int run_scenario_impl(nb_context* c, const nb_scenario* s, nb_scenario_result* r
         return NB_OK;
     }
 
+    if (!(s->flags & NB_SCN_EAGER) && s->last_step - s->first_step >= GRAPH_MIN_STEPS)
+        return run_batched_impl(&c, s, res, 1);  // graph replay of the (batched) step kernel with one slot
+
     const int sync_every = s->sync_every > 0 ? s->sync_every : 2000;  // hw5.cu:72
     const bool can_stop = s->kind != NB_SCN_MIN_DIST;
     bool stopped = false;
@@ -657,6 +678,241 @@ int run_scenario_impl(nb_context* c, const nb_scenario* s, nb_scenario_result* r
     NB_HIP(c, hipMemcpyAsync(mh, c->mon, sizeof(F64Monitor), hipMemcpyDeviceToHost, c->stream));
     NB_HIP(c, hipStreamSynchronize(c->stream));
     fill_result(c, s, sc, stopped ? step : s->last_step, res);
+    return NB_OK;
+}
+
+// ---------------------------------------------------------------- graph-driven stepping (the per-step engine, K2)
+// One eager launch costs the HOST 3.1-3.7 us on this platform (bench/ubench/launch_rate.hip, profiles/r02_launch_rate.txt)
+// — more than a step of a few-hundred-body system takes on the GPU — while a hipGraph of kernel nodes replays at
+// 1.5-2.0 us per node with no host work at all.  A captured launch cannot carry its step index, so the scenario keeps a
+// control word {base step, active} in HBM: the node with offset t computes step base + t, reads |sin| from the
+// host-computed table, runs the monitor-only launch at last_step + 1 and returns at once beyond it (or while the slot is
+// dormant); a one-thread node at the end of the graph advances base by the chunk length.  The host replays the graph,
+// copies the monitors back and looks at them once per chunk (where hw5.cu polls every 2000 steps, hw5.cu:398-402).
+
+struct GraphGroup;
+struct GraphSlot {
+    nb_context* c = nullptr;
+    const nb_scenario* scn = nullptr;
+    F64Scenario sc{};
+    bool snap = false;
+    int base = 0;        // index of the state the slot's buffers hold (host mirror of ctl.base_step)
+    bool active = true;  // false: dormant follower
+    int done_at = -1;    // >= 0: finished; index of the last state computed
+    int inflight = 0;    // replays enqueued with this slot active and not yet collected
+    // follower: a MISSILE run that starts from the snapshot which slot `parent_slot` of `parent` (a FIRST_HIT scenario
+    // with snapshots) takes when the missile of its watched device `parent_watch` arrives (hw5.cu:265-287,482-489)
+    GraphGroup* parent = nullptr;
+    int parent_slot = -1, parent_watch = -1;
+};
+
+struct GraphGroup {  // the scenarios that share one stream and one replayed graph
+    std::vector<GraphSlot> slots;
+    nb_context* lead = nullptr;  // owns the stream and the |sin| table, reports errors
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};  // end of the replays in flight (even / odd)
+    int launched = 0, collected = 0;
+    bool prepared = false;
+    ~GraphGroup() {
+        if (lead) (void)hipSetDevice(lead->cfg.device);
+        if (lead && lead->stream) (void)hipStreamSynchronize(lead->stream);  // error paths: nothing of ours in flight
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (graph) (void)hipGraphDestroy(graph);
+        for (hipEvent_t e : ev)
+            if (e) (void)hipEventDestroy(e);
+    }
+    bool running() const {
+        for (const GraphSlot& s : slots)
+            if (s.done_at < 0) return true;
+        return false;
+    }
+    bool anything_active() const {
+        for (const GraphSlot& s : slots)
+            if (s.done_at < 0 && s.active) return true;
+        return false;
+    }
+};
+
+int upload_ctl(nb_context* err, GraphSlot& s, hipStream_t stream) {
+    *s.c->ctl_host = F64Ctl{s.base, s.active ? 1 : 0};  // pinned; rewritten only with the same values while in flight
+    NB_HIP(err, hipMemcpyAsync(s.c->ctl, s.c->ctl_host, sizeof(F64Ctl), hipMemcpyHostToDevice, stream));
+    return NB_OK;
+}
+
+// monitors, control words, tables, and the captured graph of GRAPH_CHUNK batched launches + the advance node
+int group_prepare(GraphGroup& g) {
+    nb_context* c0 = g.lead;
+    if (int rc = bind(c0)) return rc;
+    hipStream_t stream = c0->stream;
+    int max_last = 0;
+    for (GraphSlot& s : g.slots) {
+        s.sc = device_scenario(s.c, s.scn);
+        s.snap = wants_snapshots(s.scn);
+        if (s.snap)
+            if (int rc = ensure_snapshots(s.c, s.sc.n_watch)) { snprintf(c0->err, sizeof c0->err, "%s", s.c->err); return rc; }
+        max_last = std::max(max_last, s.scn->last_step);
+        NB_HIP(c0, hipStreamSynchronize(s.c->stream));  // earlier work of this context (uploads) is complete
+        if (int rc = reset_monitor(c0, s.c, stream)) return rc;
+        if (int rc = upload_ctl(c0, s, stream)) return rc;
+    }
+    if (int rc = ensure_fst_table(c0, max_last)) return rc;  // indices up to last_step + 1 are read
+    NB_HIP(c0, hipStreamSynchronize(stream));
+
+    const int count = (int)g.slots.size();
+    NB_HIP(c0, hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    hipError_t bad = hipSuccess;
+    for (int t = 0; t < GRAPH_CHUNK && bad == hipSuccess; ++t) {
+        F64BatchArgs args{};
+        args.count = count;
+        for (int b = 0; b < count; ++b) {
+            GraphSlot& s = g.slots[(size_t)b];
+            nb_context* c = s.c;
+            F64Args a{};
+            a.qin = c->q[c->cur ^ (t & 1)];
+            a.qout = c->q[c->cur ^ (t & 1) ^ 1];
+            a.v = c->v;
+            a.m = c->m;
+            a.coef = c->coef;
+            a.snap_q = s.snap ? c->snap_q : nullptr;
+            a.snap_v = s.snap ? c->snap_v : nullptr;
+            a.mon = c->mon;
+            a.n = c->n;
+            a.do_update = 1;  // (full grid; the kernel decides from the control word)
+            a.G = c->cfg.G;
+            a.eps2 = c->cfg.eps * c->cfg.eps;
+            a.dt = c->cfg.dt;
+            a.scn = s.sc;
+            a.ctl = c->ctl;
+            a.fst_table = c0->fst_dev;
+            a.t = t + 1;  // state index base + t  ->  step base + t + 1
+            a.last_step = s.scn->last_step;
+            args.item[b] = a;
+        }
+        bad = (hipError_t)launch_f64_batched(args, c0->n, c0->split, stream);
+    }
+    if (bad == hipSuccess) {
+        F64CtlBatch cb{};
+        cb.count = count;
+        for (int b = 0; b < count; ++b) cb.ctl[b] = g.slots[(size_t)b].c->ctl;
+        bad = (hipError_t)launch_ctl_advance(cb, GRAPH_CHUNK, stream);
+    }
+    hipError_t e = hipStreamEndCapture(stream, &g.graph);
+    if (bad != hipSuccess) return fail_hip(c0, bad, "capturing the step graph");
+    if (e != hipSuccess) return fail_hip(c0, e, "hipStreamEndCapture");
+    NB_HIP(c0, hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+    for (hipEvent_t& e : g.ev) NB_HIP(c0, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    g.prepared = true;
+    return NB_OK;
+}
+
+// one replay = GRAPH_CHUNK steps of every active slot, then the monitors travel to their pinned host copies
+int group_launch(GraphGroup& g) {
+    nb_context* c0 = g.lead;
+    if (int rc = bind(c0)) return rc;
+    if (!g.prepared)
+        if (int rc = group_prepare(g)) return rc;
+    NB_HIP(c0, hipGraphLaunch(g.exec, c0->stream));
+    for (GraphSlot& s : g.slots)
+        if (s.done_at < 0 && s.active) {
+            NB_HIP(c0, hipMemcpyAsync(s.c->mon_host, s.c->mon, sizeof(F64Monitor), hipMemcpyDeviceToHost, c0->stream));
+            ++s.inflight;
+        }
+    NB_HIP(c0, hipEventRecord(g.ev[g.launched & 1], c0->stream));
+    ++g.launched;
+    return NB_OK;
+}
+
+// the oldest replay in flight has finished: host mirrors of the control words, and which slots have ended.  The pinned
+// monitors may already hold what a LATER replay wrote — they only ever move forward (min, first hit, first arrival), and
+// a value that is visible here was written by a replay that is complete (the copy is stream-ordered behind it).
+int group_collect(GraphGroup& g) {
+    nb_context* c0 = g.lead;
+    if (int rc = bind(c0)) return rc;
+    NB_HIP(c0, hipEventSynchronize(g.ev[g.collected & 1]));
+    ++g.collected;
+    for (GraphSlot& s : g.slots) {
+        if (s.inflight <= 0) continue;
+        --s.inflight;
+        if (s.done_at >= 0) continue;  // ended at an earlier replay: the launches of this one returned at once
+        const int before = s.base, last = s.scn->last_step;
+        s.base += GRAPH_CHUNK;  // what nbody_ctl_advance did
+        const int hit = s.c->mon_host->hit_step;
+        if (s.scn->kind != NB_SCN_MIN_DIST && hit != -2) {
+            s.done_at = hit;  // the launch after state `hit` saw it and every later one returned at once
+        } else if (s.base > last) {  // steps before+1 .. last were taken, and the monitor-only launch at last + 1 has run
+            s.done_at = last;
+            s.c->cur ^= (last - before) & 1;  // an odd number of updates leaves the state in the other buffer
+        }
+    }
+    return NB_OK;
+}
+
+// dormant followers whose parent has seen the arrival start from its snapshot; those whose parent ended without one end
+int activate_followers(GraphGroup& g) {
+    nb_context* c0 = g.lead;
+    for (GraphSlot& f : g.slots) {
+        if (f.done_at >= 0 || f.active || !f.parent) continue;
+        GraphSlot& p = f.parent->slots[(size_t)f.parent_slot];
+        const int arr = p.c->mon_host->arrival_step[f.parent_watch];
+        if (arr == -2) {
+            if (p.done_at >= 0) f.done_at = f.scn->first_step;  // never started: arrival_step stays -2
+            continue;
+        }
+        const size_t n = (size_t)f.c->n, B = 3 * n * sizeof(double);
+        const double* sq = p.c->snap_q + (size_t)f.parent_watch * 3 * n;
+        const double* sv = p.c->snap_v + (size_t)f.parent_watch * 3 * n;
+        if (p.c->cfg.device == f.c->cfg.device) {  // the parent's replay that took the snapshot has been synchronised
+            if (int rc = bind(c0)) return rc;
+            NB_HIP(c0, hipMemcpyAsync(f.c->q[f.c->cur], sq, B, hipMemcpyDeviceToDevice, c0->stream));
+            NB_HIP(c0, hipMemcpyAsync(f.c->v, sv, B, hipMemcpyDeviceToDevice, c0->stream));
+        } else {  // another GPU: through the host
+            std::vector<double> hq(3 * n), hv(3 * n);
+            if (int rc = bind(p.c)) return rc;
+            NB_HIP(c0, hipMemcpy(hq.data(), sq, B, hipMemcpyDeviceToHost));
+            NB_HIP(c0, hipMemcpy(hv.data(), sv, B, hipMemcpyDeviceToHost));
+            if (int rc = bind(c0)) return rc;
+            NB_HIP(c0, hipMemcpy(f.c->q[f.c->cur], hq.data(), B, hipMemcpyHostToDevice));
+            NB_HIP(c0, hipMemcpy(f.c->v, hv.data(), B, hipMemcpyHostToDevice));
+        }
+        f.base = arr;
+        f.active = true;
+        if (int rc = bind(c0)) return rc;
+        if (int rc = upload_ctl(c0, f, c0->stream)) return rc;
+    }
+    return NB_OK;
+}
+
+// all groups to completion, one host thread: every running group keeps up to two replays in flight (the second is
+// enqueued while the first executes, so neither the host's enqueue work nor its look at the monitors idles the GPU)
+int run_groups_graph(std::vector<GraphGroup*>& groups) {
+    for (;;) {
+        bool progressed = false;
+        for (GraphGroup* g : groups)
+            if (g->running() && g->anything_active() && g->launched - g->collected < 2) {
+                if (int rc = group_launch(*g)) return rc;
+                progressed = true;
+            }
+        for (GraphGroup* g : groups)
+            if (g->launched > g->collected && (g->launched - g->collected == 2 || !g->running() || !g->anything_active() ||
+                                               !progressed)) {
+                if (int rc = group_collect(*g)) return rc;
+                progressed = true;
+            }
+        bool dormant_left = false, inflight = false;
+        for (GraphGroup* g : groups) {
+            if (int rc = activate_followers(*g)) return rc;
+            for (const GraphSlot& s : g->slots) dormant_left |= (s.done_at < 0);
+            inflight |= g->launched > g->collected;
+        }
+        if (!dormant_left && !inflight) break;
+        if (!progressed && !inflight) {  // only dormant followers whose parents have all ended: cannot wake any more
+            for (GraphGroup* g : groups)
+                for (GraphSlot& s : g->slots)
+                    if (s.done_at < 0) s.done_at = s.scn->first_step;
+            break;
+        }
+    }
     return NB_OK;
 }
 
@@ -732,6 +988,28 @@ int run_batched_impl(nb_context** ctxs, const nb_scenario* scns, nb_scenario_res
             }
         }
         for (int b = 0; b < count; ++b) fill_result(ctxs[b], &scns[b], sc[b], done_at[b], &results[b]);
+        return NB_OK;
+    }
+
+    // long runs: replay a captured graph of launches instead of issuing every launch from the host
+    int longest = 0;
+    bool eager = false;
+    for (int b = 0; b < count; ++b) {
+        longest = std::max(longest, scns[b].last_step - scns[b].first_step);
+        eager |= (scns[b].flags & NB_SCN_EAGER) != 0;
+    }
+    if (!eager && longest >= GRAPH_MIN_STEPS) {
+        GraphGroup g;
+        g.lead = c0;
+        g.slots.resize((size_t)count);
+        for (int b = 0; b < count; ++b) {
+            g.slots[(size_t)b].c = ctxs[b];
+            g.slots[(size_t)b].scn = &scns[b];
+            g.slots[(size_t)b].base = scns[b].first_step;
+        }
+        std::vector<GraphGroup*> one{&g};
+        if (int rc = run_groups_graph(one)) return rc;
+        for (int b = 0; b < count; ++b) fill_result(ctxs[b], &scns[b], g.slots[(size_t)b].sc, g.slots[(size_t)b].done_at, &results[b]);
         return NB_OK;
     }
 
@@ -1075,6 +1353,7 @@ struct SolveInput {
     const double *qx, *qy, *qz, *vx, *vy, *vz, *m;
     const uint8_t* is_device;
     const std::vector<double>* m_no_devices;
+    void (*stamp)(const char*);  // NB_SOLVE_TRACE timeline, or nullptr
 };
 
 // all scenarios of `slots` on one GPU: contexts + one batched launch stream, at most `cap` scenarios at a time
@@ -1103,8 +1382,10 @@ void run_group(const SolveInput& in, int gpu, const std::vector<SolveSlot*>& slo
                 scns[k] = s->scn;
             }
             const nb_context* failed = (rc && !owned.empty()) ? owned.back().get() : nullptr;  // set-up failure
+            if (in.stamp) in.stamp("contexts created, state uploaded");
             if (!rc) {
                 rc = nb_run_scenarios_batched(ctxs, scns, ress, cnt);
+                if (in.stamp) in.stamp("batched scenarios returned");
                 if (rc) failed = ctxs[0];  // the batch reports through its leader
             }
             for (int k = 0; k < cnt; ++k) {
@@ -1154,14 +1435,17 @@ int solve_impl(int n, int planet, int asteroid, const double* qx, const double* 
         }
     const size_t D = dev_idx.size();
     if (D > NB_MAX_WATCH) return NB_ERR_INVALID;
-    const SolveInput in{n, planet, asteroid, qx, qy, qz, vx, vy, vz, m, is_device, &m_no_devices};
     const bool trace = getenv("NB_SOLVE_TRACE") != nullptr;  // stderr timeline of the driver's phases
-    const auto t_start = std::chrono::steady_clock::now();
-    auto stamp = [&](const char* what) {
-        if (trace)
-            fprintf(stderr, "[nb_solve] %8.1f ms  %s\n",
-                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(), what);
+    static std::chrono::steady_clock::time_point t_start;
+    t_start = std::chrono::steady_clock::now();
+    auto stamp_fn = +[](const char* what) {
+        fprintf(stderr, "[nb_solve] %8.1f ms  %s\n",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(), what);
     };
+    auto stamp = [&](const char* what) {
+        if (trace) stamp_fn(what);
+    };
+    const SolveInput in{n, planet, asteroid, qx, qy, qz, vx, vy, vz, m, is_device, &m_no_devices, trace ? stamp_fn : nullptr};
     stamp("HIP runtime up, input checked");
 
     int cap = MAX_BATCH;  // scenarios per launch stream; NB_SOLVE_MAX_BATCH (2..8) lowers it (tests of the queueing path)
@@ -1201,6 +1485,103 @@ int solve_impl(int n, int planet, int asteroid, const double* qx, const double* 
         s.scn.watch[0] = dev_idx[k];
         s.device_k = (int)k;
     }
+    if (n > SMALL_N_MAX) {
+        // Per-step engine: one stream + replayed graph each for P1, for P2, and for the Problem-3 runs (at most two
+        // streams of those per GPU: four hardware queues).  A Problem-3 run is dormant until P2's monitor reports the
+        // missile's arrival at its device; it then starts from the snapshot P2 took at that step (hw5.cu:265-287,
+        // 482-489) at most one replay (GRAPH_CHUNK steps) behind, so the whole program ends one replay after P1 does.
+        // Independent streams keep the scenarios out of phase — one's latency-bound launch prologue overlaps another's
+        // pair loop — which a lock-step batch of large systems cannot (profiles/r02_scenario_batch_timing.txt).
+        std::vector<CtxPtr> owned;
+        auto make = [&](int gpu, bool zero_devices, nb_context** c) -> int {
+            nb_config cfg;
+            nb_config_default(&cfg);
+            cfg.n = n;
+            cfg.device = gpu;
+            int rc = nb_create(c, &cfg);
+            owned.emplace_back(*c);
+            if (rc) return set_error(rc, *c ? nb_last_error(*c) : "nb_create");
+            rc = nb_set_state(*c, qx, qy, qz, vx, vy, vz, zero_devices ? m_no_devices.data() : m, is_device);
+            if (rc) return set_error(rc, nb_last_error(*c));
+            reset_monitor_host(*c);
+            return NB_OK;
+        };
+        slots[1].scn.flags = 0;  // P2 keeps the arrival snapshots its followers start from
+        // Streams: systems of a few hundred bodies leave most of the chip idle and their launch chain does not lengthen
+        // when several scenarios share a launch (measured flat up to 5 at n = 200), so everything on a GPU goes into ONE
+        // graph; from ~256 bodies on a lock-step batch pays for every member (n = 1024: 5.8 / 6.9 / 8.1 / 9.2 us per step
+        // for 1 / 2 / 3 / 4 scenarios) and P1, P2 and the Problem-3 runs get a stream each instead
+        // (profiles/r02_scenario_batch_timing.txt).  NB_SOLVE_STREAMS=merged|split overrides.
+        bool merged = n <= 256;
+        if (const char* e = getenv("NB_SOLVE_STREAMS")) merged = !strcmp(e, "merged");
+        std::vector<GraphGroup> groups(merged ? 3 * G : 2 + 2 * G);
+        std::vector<nb_context*> cs(slots.size(), nullptr);
+        if (int rc = make(gpus[0], true, &cs[0])) return rc;
+        if (int rc = make(gpus[1 % G], false, &cs[1])) return rc;
+        GraphGroup* p2_group = nullptr;
+        int p2_slot = 0;
+        for (size_t i = 0; i < 2; ++i) {
+            GraphGroup& g = merged ? groups[3 * (i % G)] : groups[i];
+            if (!g.lead) g.lead = cs[i];
+            GraphSlot sl;
+            sl.c = cs[i];
+            sl.scn = &slots[i].scn;
+            if (i == 1) { p2_group = &g; p2_slot = (int)g.slots.size(); }
+            g.slots.push_back(sl);
+        }
+        for (size_t k = 0; k < D; ++k) {
+            const size_t gi = (2 + k) % G;  // GPU of this device's run
+            if (int rc = make(gpus[gi], false, &cs[2 + k])) return rc;
+            GraphGroup* g = nullptr;
+            if (merged) {  // the GPU's shared graph while it has room (8 scenarios per launch), then two overflow graphs
+                for (size_t j = 0; j < 3 && !g; ++j)
+                    if (groups[3 * gi + j].slots.size() < (size_t)MAX_BATCH) g = &groups[3 * gi + j];
+            } else {
+                g = &groups[2 + 2 * gi + (k / G) % 2];  // one of the GPU's two follower streams
+                if (g->slots.size() >= (size_t)MAX_BATCH) g = nullptr;
+            }
+            if (!g) return set_error(NB_ERR_INVALID, "too many gravity devices per stream");
+            if (!g->lead) g->lead = cs[2 + k];
+            GraphSlot f;
+            f.c = cs[2 + k];
+            f.scn = &slots[2 + k].scn;
+            f.active = false;
+            f.parent = p2_group;
+            f.parent_slot = p2_slot;
+            f.parent_watch = (int)k;
+            g->slots.push_back(f);
+        }
+        stamp("contexts created, state uploaded");
+        std::vector<GraphGroup*> live;
+        for (GraphGroup& g : groups)
+            if (g.lead) live.push_back(&g);
+        if (int rc = run_groups_graph(live)) return set_error(rc, nb_last_error(live[0]->lead));
+        stamp(merged ? "graph-driven scenarios done (one stream per GPU)" : "graph-driven scenarios done (stream per scenario)");
+        for (GraphGroup* g : live)
+            for (GraphSlot& gs : g->slots) {
+                SolveSlot& sl = slots[(size_t)(std::find(cs.begin(), cs.end(), gs.c) - cs.begin())];
+                fill_result(gs.c, gs.scn, device_scenario(gs.c, gs.scn), gs.done_at, &sl.res);
+                sl.ran = true;
+            }
+        out->min_dist = std::sqrt(slots[0].res.min_dist2);  // nbody.cc:121 takes min of sqrt; sqrt is monotone
+        out->hit_time_step = slots[1].res.hit_step;
+        out->gravity_device_id = -1;
+        out->missile_cost = 0;
+        if (slots[1].res.hit_step == -2) return NB_OK;  // no collision: nothing to prevent (hw5.cu:547-548,568)
+        int best_arrival = std::numeric_limits<int>::max();
+        for (size_t k = 0; k < D; ++k) {
+            const nb_scenario_result& r = slots[2 + k].res;
+            // feasible: the missile arrived (before the P2 hit, else the run never started) and no hit followed
+            // (hw5.cu:512: strict <; cost is monotone in the arrival step)
+            if (r.hit_step == -2 && r.arrival_step[0] != -2 && r.steps_done == n_steps && r.arrival_step[0] < best_arrival) {
+                best_arrival = r.arrival_step[0];
+                out->gravity_device_id = dev_idx[k];
+                out->missile_cost = r.missile_cost[0];
+            }
+        }
+        return NB_OK;
+    }
+
     const size_t first_wave = std::min(slots.size(), G * (size_t)cap);
     {
         std::vector<std::vector<SolveSlot*>> groups(G);

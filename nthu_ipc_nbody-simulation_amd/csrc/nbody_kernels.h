@@ -56,6 +56,11 @@ struct F64Monitor {  // device-resident scenario state, written by workgroup 0 o
     int pad;
 };
 
+struct F64Ctl {  // device-resident control word of a graph-driven scenario: a captured launch cannot carry its step index
+    int base_step;  // the launch with offset t in the graph computes step base_step + t
+    int active;     // 0: the slot is dormant (e.g. a Problem-3 run whose missile has not arrived yet)
+};
+
 struct F64Scenario {  // by-value kernel argument
     int kind;         // nb_scenario_kind, or -1 = no monitor (plain nb_step)
     int planet, asteroid;
@@ -82,6 +87,12 @@ struct F64Args {
     double fst;     // |sin(step*dt/6000)| computed on the host (glibc, as the CPU reference does)
     double G, eps2, dt;
     F64Scenario scn;
+    // graph-driven stepping (ctl != nullptr): step = ctl->base_step + t instead of `step`, |sin| from the host-computed
+    // table `fst_table[step]` instead of `fst`; the update runs while step <= last_step, step == last_step + 1 is the
+    // monitor-only launch for the final state, later launches (and dormant slots) return at once
+    const F64Ctl* ctl;
+    const double* fst_table;
+    int t, last_step;
 };
 int launch_f64(const F64Args& a, int S, hipStream_t stream);  // S = lanes sharing one target (1..64, pow2)
 constexpr int MAX_BATCH = 8;
@@ -90,6 +101,11 @@ struct F64BatchArgs {  // up to MAX_BATCH independent systems of the same n, one
     int count;
 };
 int launch_f64_batched(const F64BatchArgs& b, int n, int S, hipStream_t stream);
+struct F64CtlBatch {
+    F64Ctl* ctl[MAX_BATCH];
+    int count;
+};
+int launch_ctl_advance(const F64CtlBatch& b, int by, hipStream_t stream);  // base_step += by for the active slots
 int auto_split_f64(int n, int n_cus);
 
 // K1-f64: fp64 force + kick-drift for LARGE n (plain nb_step / nb_accel from F64_LARGE_MIN bodies up): sources broadcast

@@ -62,7 +62,9 @@ __device__ __forceinline__ double dist2_bodies(const double* q, int n, int i, in
 
 constexpr int K2_TILE = 1024;  // sources staged per pass: 4 per thread, 32 KB of LDS; n <= 1024 needs ONE pass
 
-template <int S>
+// SELFCHECK: eps == 0 — the self pair must be skipped explicitly (r2 = 0); with eps > 0 it contributes s * 0 = +0 by
+// itself, exactly like skipping it (nbody.cc:59), and the two compares + two selects per pair are saved
+template <int S, bool SELFCHECK>
 __device__ __forceinline__ void step_f64_body(const F64Args& a) {
     __shared__ double sx[K2_TILE], sy[K2_TILE], sz[K2_TILE], sg[K2_TILE];
     __shared__ int sh_skip;
@@ -102,6 +104,18 @@ __device__ __forceinline__ void step_f64_body(const F64Args& a) {
     double vx0 = 0, vy0 = 0, vz0 = 0;
     if (owner) { vx0 = a.v[i]; vy0 = a.v[n + i]; vz0 = a.v[2 * n + i]; }
 
+    // which step is this?  Eager launches carry it; a launch replayed from a graph derives it from the scenario's
+    // device-resident control word (wave-uniform scalar loads, issued behind the vector loads above)
+    int step = a.step, do_update = a.do_update;
+    double fst = a.fst;
+    if (a.ctl) {
+        const F64Ctl ctl = *a.ctl;
+        step = ctl.base_step + a.t;
+        if (!ctl.active || step > a.last_step + 1) return;  // dormant slot / past the end: workgroup-uniform
+        do_update = step <= a.last_step;
+        fst = a.fst_table[step];
+    }
+
     // ---- monitor on the state after step-1 (index step-1), evaluated identically by every workgroup;
     //      only workgroup 0 records it.  A value another workgroup of THIS launch may already have written
     //      (arrival_step == step-1, hit_step == step-1) leads to the same decision as re-deriving it.
@@ -109,7 +123,7 @@ __device__ __forceinline__ void step_f64_body(const F64Args& a) {
         int skip = 0;
         unsigned destroyed = 0, snap = 0;
         if (sc.kind >= 0) {
-            const int idx = a.step - 1;
+            const int idx = step - 1;
             const bool rec = blockIdx.x == 0;
             F64Monitor* mon = a.mon;
             const double d2 = dist2_bodies(a.qin, n, sc.planet, sc.asteroid);
@@ -140,7 +154,7 @@ __device__ __forceinline__ void step_f64_body(const F64Args& a) {
                 }
             }
         }
-        if (!a.do_update) skip = 1;
+        if (!do_update) skip = 1;
         sh_skip = skip;
         sh_destroyed = destroyed;
         sh_snap = snap;
@@ -155,7 +169,7 @@ __device__ __forceinline__ void step_f64_body(const F64Args& a) {
         for (int u = 0; u < PER; ++u) {
             if (u < per_n) {
                 const int jl = u * WG + t;
-                const double mj = __dadd_rn(lm[u], __dmul_rn(__dmul_rn(lc[u], lm[u]), a.fst));
+                const double mj = __dadd_rn(lm[u], __dmul_rn(__dmul_rn(lc[u], lm[u]), fst));
                 sx[jl] = lx[u]; sy[jl] = ly[u]; sz[jl] = lz[u];
                 sg[jl] = (base + jl < n) ? __dmul_rn(a.G, mj) : 0.0;  // G*mj, the reference's first product (nbody.cc:70)
             }
@@ -178,7 +192,8 @@ __device__ __forceinline__ void step_f64_body(const F64Args& a) {
     }
     if (skip) return;  // workgroup-uniform
 
-    // a destroyed device (MISSILE scenario, one watched device) has mass 0 from the step after its arrival (hw5.cu:306)
+    // a destroyed device (MISSILE scenario, one watched device) has mass 0 from the step after its arrival (hw5.cu:306):
+    // its staged G*m is cleared (the staging thread and this one are ordered by the barriers around the write)
     int dead_j = -1;
     for (int k = 0; k < sc.n_watch; ++k)
         if (destroyed & (1u << k)) dead_j = sc.watch[k];
@@ -190,6 +205,10 @@ __device__ __forceinline__ void step_f64_body(const F64Args& a) {
             stage(base);
             __syncthreads();
         }
+        if (dead_j >= base && dead_j < base + K2_TILE) {  // workgroup-uniform
+            if (t == 0) sg[dead_j - base] = 0.0;
+            __syncthreads();
+        }
         const int lim = min(K2_TILE, n - base);
 #pragma unroll 2
         for (int jj = ls; jj < lim; jj += S) {
@@ -199,8 +218,7 @@ __device__ __forceinline__ void step_f64_body(const F64Args& a) {
             double r2 = dx * dx + dy * dy + dz * dz + a.eps2;
             double rinv = rsqrt_fast(r2);
             double s = sg[jj] * rinv * rinv * rinv;  // G*mj/(r2+eps2)^1.5
-            const int j = base + jj;
-            s = (j == i || j == dead_j) ? 0.0 : s;  // j == i skipped (nbody.cc:59), also keeps eps == 0 finite
+            if (SELFCHECK) s = (base + jj == i) ? 0.0 : s;  // j == i skipped (nbody.cc:59): needed for eps == 0 only
             ax += s * dx;
             ay += s * dy;
             az += s * dz;
@@ -232,19 +250,19 @@ __device__ __forceinline__ void step_f64_body(const F64Args& a) {
     }
 }
 
-template <int S>
+template <int S, bool SELFCHECK>
 __global__ __launch_bounds__(WG) void nbody_step_f64(F64Args a) {
-    step_f64_body<S>(a);
+    step_f64_body<S, SELFCHECK>(a);
 }
 
 // One launch advances up to MAX_BATCH independent systems of the same n by one step each (blockIdx.y = system): the
 // scenarios hw5 runs side by side (P3 per device: hw5.cu:587-588) then share ONE launch per step instead of contending
 // for the command processor with one launch stream each.  Every system carries its own step index, |sin| and monitor.
-template <int S>
+template <int S, bool SELFCHECK>
 __global__ __launch_bounds__(WG) void nbody_step_f64_batched(F64BatchArgs b) {
     const F64Args& a = b.item[blockIdx.y];
     if (a.n <= 0) return;  // finished / not started: nothing to do for this slot
-    step_f64_body<S>(a);
+    step_f64_body<S, SELFCHECK>(a);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -256,7 +274,7 @@ __global__ __launch_bounds__(WG) void nbody_step_f64_batched(F64BatchArgs b) {
 // from LDS (identical inputs -> identical, hence workgroup-uniform, decisions): no flags, no inter-workgroup protocol,
 // no grid barrier, every wave reaches the loop exit.  Same arithmetic as K2 (same G*m_eff rounding, same pair term,
 // same non-contracted kick/drift); only the summation split S differs.
-template <int S>
+template <int S, bool SELFCHECK>
 __device__ __forceinline__ void scenario_small_body(const F64SmallArgs& a) {
     __shared__ double sq[2][3][SMALL_N_MAX];
     __shared__ double sg[2][SMALL_N_MAX];
@@ -290,6 +308,7 @@ __device__ __forceinline__ void scenario_small_body(const F64SmallArgs& a) {
         if (k < sc.n_watch && a.m[sc.watch[k]] != 0.0) alive |= 1u << k;
     }
     if (sc.destroy_on_arrival && sc.n_watch > 0 && arr[0] != -2) dead_j = sc.watch[0];
+    if (owner && i == dead_j) sg[0][i] = 0.0;  // a destroyed device pulls nothing: its staged G*m is cleared (hw5.cu:306)
     __syncthreads();
 
     auto d2_of = [&](int buf, int p, int r) {
@@ -336,7 +355,12 @@ __device__ __forceinline__ void scenario_small_body(const F64SmallArgs& a) {
     // as long as one whole iteration of this loop, so a one-deep prefetch would still stall the owners' update
     double fst_next = owner ? a.fst[step + 1] : 0.0;
     for (; step <= a.last_step; ++step) {
+        const int dead_before = dead_j;
         if (monitor(cur, step - 1)) { stopped = true; break; }
+        if (dead_j != dead_before) {  // the missile arrived at this state (workgroup-uniform, once per scenario)
+            if (owner && i == dead_j) sg[cur][i] = 0.0;
+            __syncthreads();
+        }
         const double fst_after = owner ? a.fst[step + 2] : 0.0;
         const double xi = sq[cur][0][ic], yi = sq[cur][1][ic], zi = sq[cur][2][ic];
         double ax = 0, ay = 0, az = 0;
@@ -348,7 +372,7 @@ __device__ __forceinline__ void scenario_small_body(const F64SmallArgs& a) {
             double r2 = dx * dx + dy * dy + dz * dz + a.eps2;
             double rinv = rsqrt_fast(r2);
             double s = sg[cur][jj] * rinv * rinv * rinv;
-            s = (jj == i || jj == dead_j) ? 0.0 : s;  // j == i skipped (nbody.cc:59); destroyed device has m = 0
+            if (SELFCHECK) s = (jj == i) ? 0.0 : s;  // j == i skipped (nbody.cc:59): with eps > 0 the pair is s * 0 = +0
             ax += s * dx;
             ay += s * dy;
             az += s * dz;
@@ -366,7 +390,7 @@ __device__ __forceinline__ void scenario_small_body(const F64SmallArgs& a) {
             sq[cur ^ 1][0][i] = __dadd_rn(xi, __dmul_rn(vx, a.dt));
             sq[cur ^ 1][1][i] = __dadd_rn(yi, __dmul_rn(vy, a.dt));
             sq[cur ^ 1][2][i] = __dadd_rn(zi, __dmul_rn(vz, a.dt));
-            sg[cur ^ 1][i] = __dmul_rn(a.G, __dadd_rn(mi, __dmul_rn(cmi, fst_next)));
+            sg[cur ^ 1][i] = (i == dead_j) ? 0.0 : __dmul_rn(a.G, __dadd_rn(mi, __dmul_rn(cmi, fst_next)));
         }
         __syncthreads();  // the only barrier of the step: buffer cur^1 complete, buffer cur free for step+1's writes
         cur ^= 1;
@@ -387,25 +411,26 @@ __device__ __forceinline__ void scenario_small_body(const F64SmallArgs& a) {
     }
 }
 
-template <int S>
+template <int S, bool SELFCHECK>
 __global__ __launch_bounds__(SMALL_N_MAX * S) void nbody_scenario_small_f64(F64SmallArgs a) {
-    scenario_small_body<S>(a);
+    scenario_small_body<S, SELFCHECK>(a);
 }
 
 // Up to MAX_BATCH scenarios of equally sized small systems in ONE launch: workgroup k runs scenario k from its own
 // state, with its own monitor, completely independently of the others (own LDS, no inter-workgroup traffic) — the whole
 // reference program (P1, P2 and one Problem-3 run per device, hw5.cu:564-567,587-588) is then a single kernel launch on
 // 2 + D compute units, with no host thread, stream or hardware queue per scenario.
-template <int S>
+template <int S, bool SELFCHECK>
 __global__ __launch_bounds__(SMALL_N_MAX * S) void nbody_scenario_small_f64_batched(F64SmallBatchArgs b) {
     const F64SmallArgs& a = b.item[blockIdx.x];
     if (a.n <= 0) return;  // finished slot (workgroup-uniform)
-    scenario_small_body<S>(a);
+    scenario_small_body<S, SELFCHECK>(a);
 }
 
 template <int S>
 static int launch_small_s(const F64SmallArgs& a, int threads, hipStream_t stream) {
-    hipLaunchKernelGGL((nbody_scenario_small_f64<S>), dim3(1), dim3(threads), 0, stream, a);
+    if (a.eps2 > 0.0) hipLaunchKernelGGL((nbody_scenario_small_f64<S, false>), dim3(1), dim3(threads), 0, stream, a);
+    else hipLaunchKernelGGL((nbody_scenario_small_f64<S, true>), dim3(1), dim3(threads), 0, stream, a);
     return (int)hipGetLastError();
 }
 
@@ -423,7 +448,10 @@ int launch_f64_small_batched(const F64SmallBatchArgs& b, int n, hipStream_t stre
     if (n <= 0 || n > SMALL_N_MAX || b.count <= 0 || b.count > MAX_BATCH) return (int)hipErrorInvalidValue;
     constexpr int S = 8;
     const int threads = ((n * S + 63) / 64) * 64;
-    hipLaunchKernelGGL((nbody_scenario_small_f64_batched<S>), dim3(b.count), dim3(threads), 0, stream, b);
+    bool eps_positive = true;
+    for (int k = 0; k < b.count; ++k) eps_positive &= (b.item[k].n <= 0 || b.item[k].eps2 > 0.0);
+    if (eps_positive) hipLaunchKernelGGL((nbody_scenario_small_f64_batched<S, false>), dim3(b.count), dim3(threads), 0, stream, b);
+    else hipLaunchKernelGGL((nbody_scenario_small_f64_batched<S, true>), dim3(b.count), dim3(threads), 0, stream, b);
     return (int)hipGetLastError();
 }
 
@@ -577,14 +605,18 @@ static int launch_s(const F64Args& a, hipStream_t stream) {
     constexpr int TPB = WG / S;
     // a monitor-only launch (do_update == 0) still needs every owner lane when a missile-arrival snapshot may be due
     int blocks = (a.do_update || a.snap_q) ? (a.n + TPB - 1) / TPB : 1;
-    hipLaunchKernelGGL((nbody_step_f64<S>), dim3(blocks), dim3(WG), 0, stream, a);
+    if (a.eps2 > 0.0) hipLaunchKernelGGL((nbody_step_f64<S, false>), dim3(blocks), dim3(WG), 0, stream, a);
+    else hipLaunchKernelGGL((nbody_step_f64<S, true>), dim3(blocks), dim3(WG), 0, stream, a);
     return (int)hipGetLastError();
 }
 
 template <int S>
 static int launch_batched_s(const F64BatchArgs& b, int n, hipStream_t stream) {
     constexpr int TPB = WG / S;
-    hipLaunchKernelGGL((nbody_step_f64_batched<S>), dim3((n + TPB - 1) / TPB, b.count), dim3(WG), 0, stream, b);
+    bool eps_positive = true;
+    for (int k = 0; k < b.count; ++k) eps_positive &= (b.item[k].n <= 0 || b.item[k].eps2 > 0.0);
+    if (eps_positive) hipLaunchKernelGGL((nbody_step_f64_batched<S, false>), dim3((n + TPB - 1) / TPB, b.count), dim3(WG), 0, stream, b);
+    else hipLaunchKernelGGL((nbody_step_f64_batched<S, true>), dim3((n + TPB - 1) / TPB, b.count), dim3(WG), 0, stream, b);
     return (int)hipGetLastError();
 }
 
@@ -600,6 +632,16 @@ int launch_f64_batched(const F64BatchArgs& b, int n, int S, hipStream_t stream) 
         case 64: return launch_batched_s<64>(b, n, stream);
     }
     return (int)hipErrorInvalidValue;
+}
+
+__global__ void nbody_ctl_advance(F64CtlBatch b, int by) {
+    const int k = threadIdx.x;
+    if (k < b.count && b.ctl[k] && b.ctl[k]->active) b.ctl[k]->base_step += by;
+}
+
+int launch_ctl_advance(const F64CtlBatch& b, int by, hipStream_t stream) {
+    hipLaunchKernelGGL(nbody_ctl_advance, dim3(1), dim3(64), 0, stream, b, by);
+    return (int)hipGetLastError();
 }
 
 int launch_f64(const F64Args& a, int S, hipStream_t stream) {

@@ -10,7 +10,7 @@
  *   (1) the reference's 12 golden outputs testcases/b*.out (all three lines), and
  *   (2) the reference's own run_step compiled from /root/reference/samples/nbody.cc
  *       (oracle/_ref/libnbody_ref.so, see oracle/Makefile + oracle/ref_shim.cc): bit-identical
- *       q,v after steps 1, 2 and 1000 (tests/test_oracle_vs_reference.py; fixtures in tests/golden/).
+ *       q,v after steps 1, 2 and 1000 (tests/test_oracle_cpu.py; fixtures in tests/golden/).
  *
  * Each function cites the reference lines it follows (paths relative to /root/reference).
  * Arithmetic is kept operation-for-operation (association order, pow(x,1.5), three divides)

