@@ -174,7 +174,11 @@ int nb_write_state_file(const char* path, const nb_state_header* hdr, const doub
  * otherwise), at most 8 per stream; scenarios beyond that are queued cheapest-first (ascending missile-arrival step,
  * hw5.cu:574-585) and dropped once they cannot beat a feasible device (hw5.cu:490-493).  `devices` spreads the
  * scenarios over several GPUs (the reference's task parallelism, hw5.cu:564-567,587-588).
- * Environment: NB_SOLVE_MAX_BATCH=2..8 lowers the scenarios per launch stream (exercises the queue). */
+ * n > 128: the per-step engine instead — P1, P2 and the Problem-3 runs each replay their own graph of launches on their
+ * own stream (one shared graph per GPU up to 256 bodies); a Problem-3 run starts from the snapshot P2 takes at its
+ * missile's arrival (hw5.cu:265-287,482-489) as soon as P2's monitor shows it, one per GPU at a time in arrival order.
+ * Environment (tuning / tests): NB_SOLVE_MAX_BATCH=2..8 scenarios per persistent launch; NB_SOLVE_ENGINE=steps|persistent;
+ * NB_SOLVE_STREAMS=merged|split; NB_SOLVE_P3_PARALLEL=k Problem-3 runs at a time; NB_SOLVE_TRACE=1 timeline on stderr. */
 typedef struct nb_answer {
     double min_dist;
     int32_t hit_time_step;

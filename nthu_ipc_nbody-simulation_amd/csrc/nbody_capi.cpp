@@ -700,6 +700,7 @@ struct GraphSlot {
     bool active = true;  // false: dormant follower
     int done_at = -1;    // >= 0: finished; index of the last state computed
     int inflight = 0;    // replays enqueued with this slot active and not yet collected
+    bool cancelled = false;  // follower dropped because a device that arrived earlier turned out feasible
     // follower: a MISSILE run that starts from the snapshot which slot `parent_slot` of `parent` (a FIRST_HIT scenario
     // with snapshots) takes when the missile of its watched device `parent_watch` arrives (hw5.cu:265-287,482-489)
     GraphGroup* parent = nullptr;
@@ -848,44 +849,79 @@ int group_collect(GraphGroup& g) {
     return NB_OK;
 }
 
-// dormant followers whose parent has seen the arrival start from its snapshot; those whose parent ended without one end
-int activate_followers(GraphGroup& g) {
+// start one dormant follower from its parent's arrival snapshot (hw5.cu:482-489)
+int activate_follower(GraphGroup& g, GraphSlot& f, int arr) {
     nb_context* c0 = g.lead;
-    for (GraphSlot& f : g.slots) {
-        if (f.done_at >= 0 || f.active || !f.parent) continue;
-        GraphSlot& p = f.parent->slots[(size_t)f.parent_slot];
-        const int arr = p.c->mon_host->arrival_step[f.parent_watch];
-        if (arr == -2) {
-            if (p.done_at >= 0) f.done_at = f.scn->first_step;  // never started: arrival_step stays -2
-            continue;
-        }
-        const size_t n = (size_t)f.c->n, B = 3 * n * sizeof(double);
-        const double* sq = p.c->snap_q + (size_t)f.parent_watch * 3 * n;
-        const double* sv = p.c->snap_v + (size_t)f.parent_watch * 3 * n;
-        if (p.c->cfg.device == f.c->cfg.device) {  // the parent's replay that took the snapshot has been synchronised
-            if (int rc = bind(c0)) return rc;
-            NB_HIP(c0, hipMemcpyAsync(f.c->q[f.c->cur], sq, B, hipMemcpyDeviceToDevice, c0->stream));
-            NB_HIP(c0, hipMemcpyAsync(f.c->v, sv, B, hipMemcpyDeviceToDevice, c0->stream));
-        } else {  // another GPU: through the host
-            std::vector<double> hq(3 * n), hv(3 * n);
-            if (int rc = bind(p.c)) return rc;
-            NB_HIP(c0, hipMemcpy(hq.data(), sq, B, hipMemcpyDeviceToHost));
-            NB_HIP(c0, hipMemcpy(hv.data(), sv, B, hipMemcpyDeviceToHost));
-            if (int rc = bind(c0)) return rc;
-            NB_HIP(c0, hipMemcpy(f.c->q[f.c->cur], hq.data(), B, hipMemcpyHostToDevice));
-            NB_HIP(c0, hipMemcpy(f.c->v, hv.data(), B, hipMemcpyHostToDevice));
-        }
-        f.base = arr;
-        f.active = true;
+    GraphSlot& p = f.parent->slots[(size_t)f.parent_slot];
+    const size_t n = (size_t)f.c->n, B = 3 * n * sizeof(double);
+    const double* sq = p.c->snap_q + (size_t)f.parent_watch * 3 * n;
+    const double* sv = p.c->snap_v + (size_t)f.parent_watch * 3 * n;
+    if (p.c->cfg.device == f.c->cfg.device) {  // the parent's replay that took the snapshot is complete (see group_collect)
         if (int rc = bind(c0)) return rc;
-        if (int rc = upload_ctl(c0, f, c0->stream)) return rc;
+        NB_HIP(c0, hipMemcpyAsync(f.c->q[f.c->cur], sq, B, hipMemcpyDeviceToDevice, c0->stream));
+        NB_HIP(c0, hipMemcpyAsync(f.c->v, sv, B, hipMemcpyDeviceToDevice, c0->stream));
+    } else {  // another GPU: through the host
+        std::vector<double> hq(3 * n), hv(3 * n);
+        if (int rc = bind(p.c)) return rc;
+        NB_HIP(c0, hipMemcpy(hq.data(), sq, B, hipMemcpyDeviceToHost));
+        NB_HIP(c0, hipMemcpy(hv.data(), sv, B, hipMemcpyDeviceToHost));
+        if (int rc = bind(c0)) return rc;
+        NB_HIP(c0, hipMemcpy(f.c->q[f.c->cur], hq.data(), B, hipMemcpyHostToDevice));
+        NB_HIP(c0, hipMemcpy(f.c->v, hv.data(), B, hipMemcpyHostToDevice));
+    }
+    f.base = arr;
+    f.active = true;
+    if (int rc = bind(c0)) return rc;
+    return upload_ctl(c0, f, c0->stream);
+}
+
+// The Problem-3 work queue (hw5.cu:490-493,574-596) over the followers of all groups: candidates are the devices whose
+// missile has arrived on the parent (P2) trajectory, cheapest first = ascending arrival step; at most `parallel` of them
+// run at a time (the reference: one per GPU); a run that ends feasible cancels every candidate that arrived later —
+// it cannot cost less (PROBLEM3_BREAK) — and a run that ends in a hit hands its place to the next candidate.
+int schedule_followers(std::vector<GraphGroup*>& groups, int parallel) {
+    struct Cand { GraphGroup* g; GraphSlot* f; int arr; };
+    std::vector<Cand> waiting;
+    int active = 0, best = std::numeric_limits<int>::max();
+    for (GraphGroup* g : groups)
+        for (GraphSlot& f : g->slots) {
+            if (!f.parent) continue;
+            GraphSlot& p = f.parent->slots[(size_t)f.parent_slot];
+            const int arr = p.c->mon_host->arrival_step[f.parent_watch];
+            if (f.done_at >= 0) {
+                if (f.active && !f.cancelled && f.done_at == f.scn->last_step && f.c->mon_host->hit_step == -2)
+                    best = std::min(best, arr);  // ended feasible
+            } else if (f.active) {
+                ++active;
+            } else if (arr != -2) {
+                waiting.push_back(Cand{g, &f, arr});
+            } else if (p.done_at >= 0) {
+                f.done_at = f.scn->first_step;  // the parent ended before this missile arrived: never starts
+            }
+        }
+    for (GraphGroup* g : groups)  // nothing that arrived after a feasible device can beat it
+        for (GraphSlot& f : g->slots) {
+            if (!f.parent || f.done_at >= 0) continue;
+            const int arr = f.parent->slots[(size_t)f.parent_slot].c->mon_host->arrival_step[f.parent_watch];
+            if (arr != -2 && arr > best) {
+                if (f.active) --active;
+                f.cancelled = true;
+                f.done_at = f.active ? std::min(f.base, f.scn->last_step) : f.scn->first_step;
+            }
+        }
+    std::stable_sort(waiting.begin(), waiting.end(), [](const Cand& a, const Cand& b) { return a.arr < b.arr; });
+    for (const Cand& c : waiting) {
+        if (c.f->done_at >= 0) continue;  // cancelled above
+        if (active >= parallel) break;
+        if (int rc = activate_follower(*c.g, *c.f, c.arr)) return rc;
+        ++active;
     }
     return NB_OK;
 }
 
 // all groups to completion, one host thread: every running group keeps up to two replays in flight (the second is
 // enqueued while the first executes, so neither the host's enqueue work nor its look at the monitors idles the GPU)
-int run_groups_graph(std::vector<GraphGroup*>& groups) {
+int run_groups_graph(std::vector<GraphGroup*>& groups, int follower_parallel = 1 << 30) {
     for (;;) {
         bool progressed = false;
         for (GraphGroup* g : groups)
@@ -900,8 +936,8 @@ int run_groups_graph(std::vector<GraphGroup*>& groups) {
                 progressed = true;
             }
         bool dormant_left = false, inflight = false;
+        if (int rc = schedule_followers(groups, follower_parallel)) return rc;
         for (GraphGroup* g : groups) {
-            if (int rc = activate_followers(*g)) return rc;
             for (const GraphSlot& s : g->slots) dormant_left |= (s.done_at < 0);
             inflight |= g->launched > g->collected;
         }
@@ -1485,7 +1521,14 @@ int solve_impl(int n, int planet, int asteroid, const double* qx, const double* 
         s.scn.watch[0] = dev_idx[k];
         s.device_k = (int)k;
     }
-    if (n > SMALL_N_MAX) {
+    // NB_SOLVE_ENGINE=steps|persistent overrides the choice by system size (tests run small systems through both)
+    bool per_step = n > SMALL_N_MAX;
+    if (const char* e = getenv("NB_SOLVE_ENGINE")) {
+        if (!strcmp(e, "steps")) per_step = true;
+        else if (!strcmp(e, "persistent") && n <= SMALL_N_MAX) per_step = false;
+    }
+    if (per_step) {
+        for (SolveSlot& sl : slots) sl.scn.engine = 1;
         // Per-step engine: one stream + replayed graph each for P1, for P2, and for the Problem-3 runs (at most two
         // streams of those per GPU: four hardware queues).  A Problem-3 run is dormant until P2's monitor reports the
         // missile's arrival at its device; it then starts from the snapshot P2 took at that step (hw5.cu:265-287,
@@ -1555,7 +1598,11 @@ int solve_impl(int n, int planet, int asteroid, const double* qx, const double* 
         std::vector<GraphGroup*> live;
         for (GraphGroup& g : groups)
             if (g.lead) live.push_back(&g);
-        if (int rc = run_groups_graph(live)) return set_error(rc, nb_last_error(live[0]->lead));
+        // Problem-3 runs at a time: one per GPU, like the reference's one worker thread per GPU (hw5.cu:587-588); the
+        // others wait their turn in arrival order.  NB_SOLVE_P3_PARALLEL overrides (e.g. 16 = all at once).
+        int p3_parallel = (int)G;
+        if (const char* e = getenv("NB_SOLVE_P3_PARALLEL")) p3_parallel = std::max(1, atoi(e));
+        if (int rc = run_groups_graph(live, p3_parallel)) return set_error(rc, nb_last_error(live[0]->lead));
         stamp(merged ? "graph-driven scenarios done (one stream per GPU)" : "graph-driven scenarios done (stream per scenario)");
         for (GraphGroup* g : live)
             for (GraphSlot& gs : g->slots) {

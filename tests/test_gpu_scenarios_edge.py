@@ -42,14 +42,25 @@ CASES = {
     "coincident_and_massless": [PLANET, ((3e8, 0, 0), (-3e3, 0, 0), 1e12, 0), ((0, 7e8, 0), (0, 0, 0), 1e18, 0),
                                 ((0, 7e8, 0), (0, 0, 0), 1e18, 0), ((1e9, 0, 4e8), (0, 10, 0), 0.0, 0),
                                 ((2e8, -1e8, 0), (0, 0, 0), 1e16, 1)],
+    # the light device next to the planet is reached first (step 2) but destroying it changes nothing; the heavy one
+    # (step 4) is what pulls the asteroid in: the cheapest-first queue must hand over after the first run fails
+    "first_arrival_useless_second_saves": [PLANET, ((4e8, 6e7, 0), (-2e3, 0, 0), 1e12, 0), ((5e7, 5e7, 0), (0, 0, 0), 1e10, 1),
+                                           ((1e8, -2e8, 0), (0, 0, 0), 3e24, 1)],
     # a heavy device that pulls the asteroid into the planet: destroying it in time avoids the hit
     "device_causes_hit": [PLANET, ((4e8, 6e7, 0), (-2e3, 0, 0), 1e12, 0), ((1e8, -2e8, 0), (0, 0, 0), 3e24, 1),
                           ((-9e8, 9e8, 0), (0, 0, 0), 1e10, 1)],
 }
 
 
+@pytest.mark.parametrize("engine", ["persistent", "steps", "steps-all-at-once"])
 @pytest.mark.parametrize("name", list(CASES))
-def test_solve_matches_oracle(nb, oracle, name, tmp_path):
+def test_solve_matches_oracle(nb, oracle, name, engine, tmp_path, monkeypatch):
+    """engine: the whole program through the persistent engine (what these small systems get by default), through the
+    per-step engine (graph replay, a stream per scenario, Problem-3 runs queued cheapest-first), and through it with every
+    Problem-3 run started as soon as its missile arrives."""
+    monkeypatch.setenv("NB_SOLVE_ENGINE", engine.split("-")[0])
+    if engine.endswith("all-at-once"):
+        monkeypatch.setenv("NB_SOLVE_P3_PARALLEL", "16")
     s = _system(oracle, CASES[name])
     ref_min = oracle.problem1(s)
     ref, details = oracle.problem23(s)
@@ -78,6 +89,9 @@ def test_expected_shapes_of_the_edge_cases(oracle):
     r, d = res["device_causes_hit"]
     assert r.hit_time_step > 0 and d[0]["feasible"] and r.gravity_device_id == 2 and r.missile_cost > 0
     assert d[1]["arrival_step"] > d[0]["arrival_step"] and not d[1]["feasible"]  # the far, light device cannot help
+    r, d = res["first_arrival_useless_second_saves"]
+    assert d[0]["arrival_step"] < d[1]["arrival_step"] < r.hit_time_step and not d[0]["feasible"] and d[1]["feasible"]
+    assert r.gravity_device_id == 3 and r.missile_cost == d[1]["cost"]
 
 
 def test_abi_error_paths(nb):

@@ -27,6 +27,17 @@ def test_solve_spread_over_two_device_slots(nb, oracle, case):
     assert text == gold
 
 
+@pytest.mark.parametrize("streams,p3", [("merged", "1"), ("split", "1"), ("split", "16")])
+@pytest.mark.parametrize("case", ["b200", "b512"])
+def test_solve_stream_layouts_agree(nb, oracle, case, streams, p3, monkeypatch):
+    """The per-step engine's two stream layouts (one shared graph per GPU / a stream per scenario) and both Problem-3
+    policies (queued cheapest-first / all at once) give the golden answers."""
+    monkeypatch.setenv("NB_SOLVE_STREAMS", streams)
+    monkeypatch.setenv("NB_SOLVE_P3_PARALLEL", p3)
+    text, gold = _solve_case(nb, oracle, case)
+    assert text == gold
+
+
 @pytest.mark.parametrize("case,cap", [("b30", 2), ("b80", 3), ("b200", 4)])
 def test_solve_queue_beyond_one_stream(nb, oracle, case, cap, monkeypatch):
     """NB_SOLVE_MAX_BATCH < 2 + D: the devices that do not fit the first wave are queued in ascending arrival step
