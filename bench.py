@@ -151,6 +151,8 @@ def main():
     ap.add_argument("--wg-size", type=int, default=0, help="0 auto, 256, 512 (with --targets-per-lane 8), 1024 (4)")
     ap.add_argument("--overlap", action="store_true", help="multi-GPU: two-phase step, own-shard sources while the "
                     "all-gather of the other shards is in flight (SURVEY 8(f)-3); default off, see overlap_ab in the JSON")
+    ap.add_argument("--exchange", choices=["in_place", "staged", "ring"], default="in_place", help="multi-GPU: in-place "
+                    "all-gather (default), all-gather from a cloned shard, or the ring pass (no rank holds all positions)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--report-every", type=int, default=0, help="sustained runs (configs[4]): every R steps synchronise "
                     "and print steps done + running pairs/s to stderr")
@@ -198,7 +200,7 @@ def main():
         vel = np.concatenate([v.T, np.zeros((hi - lo, 1))], axis=1)
     compute = hip_compute(acc64, args.targets_per_lane, args.j_split, args.source_path, args.wg_size)
     sysm = ShardedSystem(n, torch.from_numpy(pos), torch.from_numpy(vel), synthetic.EPS, synthetic.DT, device,
-                         compute=compute, acc64=acc64, overlap=args.overlap)
+                         compute=compute, acc64=acc64, overlap=args.overlap, exchange=args.exchange)
 
     # --- kernel-only timing: HIP events on the stream the kernel is launched on (torch's current stream), recorded by
     #     ShardedSystem.step() around its launches
@@ -298,9 +300,10 @@ def main():
         flops_launch = FLOP_PER_PAIR * sysm.n_tgt * (n - 1)
         achieved = flops_launch / (k_ms * 1e-3) / 1e12
         ws_bytes = capi.workspace_bytes_f32(sysm.n_tgt, acc64)  # what hip_compute sizes its workspace from
-        kname = capi.kernel_name_f32(n, sysm.n_tgt, acc64, args.targets_per_lane, args.j_split, ws_bytes,
+        n_cover = sysm.n_tgt if sysm.ring else n  # sources one launch sequence covers (ring pass: one travelling block)
+        kname = capi.kernel_name_f32(n_cover, sysm.n_tgt, acc64, args.targets_per_lane, args.j_split, ws_bytes,
                                      source_path=args.source_path, wg_size=args.wg_size)
-        tpl, jsp, wgs = capi.plan_f32(n, sysm.n_tgt, acc64, args.targets_per_lane, args.j_split, ws_bytes,
+        tpl, jsp, wgs = capi.plan_f32(n_cover, sysm.n_tgt, acc64, args.targets_per_lane, args.j_split, ws_bytes,
                                       args.source_path, args.wg_size)
         reducer = f"nbody_reduce_update_f32<{'true' if acc64 else 'false'}, false>"
         traffic, reduce_share = load_traffic(n, world, kname, jsp)
@@ -319,7 +322,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"N={n} synthetic uniform-random bodies (splitmix64 seed 42), all-pairs "
                                    f"force + fused kick-drift, eps=1e-3, dt=1e-4", "bodies": n,
-                       "parallelism": f"index-sharded x{world}, 1 RCCL all-gather of float4 positions/step"
+                       "parallelism": (f"index-sharded x{world}, ring pass of float4 position blocks" if sysm.ring else
+                                       f"index-sharded x{world}, 1 RCCL all-gather of float4 positions/step")
                        if world > 1 else "single GPU"},
             "exchange": sysm.exchange_mode,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",

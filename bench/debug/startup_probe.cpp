@@ -23,6 +23,23 @@ int main() {
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
     printf("hipGetDeviceProperties %7.1f ms\n", ms(t0));
+    {
+        auto t1 = std::chrono::steady_clock::now();
+        hipStream_t s2; hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+        printf("  second stream create   +%.2f ms\n", ms(t1)); t1 = std::chrono::steady_clock::now();
+        hipEvent_t e; hipEventCreate(&e);
+        printf("  event create           +%.2f ms\n", ms(t1)); t1 = std::chrono::steady_clock::now();
+        void* d; hipMalloc(&d, 200 * 14 * 8 + 512);
+        printf("  small hipMalloc        +%.2f ms\n", ms(t1)); t1 = std::chrono::steady_clock::now();
+        void* h; hipHostMalloc(&h, 256);
+        printf("  small hipHostMalloc    +%.2f ms\n", ms(t1)); t1 = std::chrono::steady_clock::now();
+        void* h2; hipHostMalloc(&h2, 256);
+        printf("  second hipHostMalloc   +%.2f ms\n", ms(t1)); t1 = std::chrono::steady_clock::now();
+        hipHostFree(h); hipHostFree(h2); hipFree(d);
+        printf("  frees                  +%.2f ms\n", ms(t1)); t1 = std::chrono::steady_clock::now();
+        hipStreamDestroy(s2); hipEventDestroy(e);
+        printf("  stream/event destroy   +%.2f ms\n", ms(t1));
+    }
     nb_config cfg;
     nb_config_default(&cfg);
     cfg.n = 200;

@@ -194,7 +194,7 @@ int nb_solve(int n, int planet, int asteroid, const double* qx, const double* qy
  * torch.distributed/RCCL: bench.py, nbody_amd.distributed).  fp32 body record = float4 {x, y, z, G*m}.
  *
  *   src      float4[n_src]   all source bodies (the gathered array every rank holds)
- *   tgt_off  first target index in src; targets are src[tgt_off .. tgt_off+n_tgt)
+ *   tgt_off  first target index in src; targets are src[tgt_off .. tgt_off+n_tgt)   (unless `tgt` is given)
  *   out      float4[n_src]   the OTHER (ping-pong) gathered array; only [tgt_off, tgt_off+n_tgt) is written
  *   vel      float4[n_tgt]   this rank's velocities, in place ({vx,vy,vz,unused})
  *   F32_ACC64 additionally keeps fp64 masters: pos64/vel64 = double4[n_tgt] ({x,y,z,G*m} / {vx,vy,vz,0})
@@ -224,6 +224,9 @@ typedef struct nb_launch_f32 {
                                  the running sums live in `workspace` between them (required unless NB_PHASE_WHOLE) */
     int64_t src_begin;        /* sources of this launch: src[src_begin .. src_end); 0,0 = all n_src.  src_begin must be */
     int64_t src_end;          /* a multiple of 256, src_end a multiple of 256 or n_src */
+    const void* tgt;          /* NULL: the targets are src[tgt_off .. tgt_off+n_tgt).  Otherwise float4[n_tgt], the targets'
+                                 own records, for hosts whose sources travel in blocks (ring pass: `src` is the block in
+                                 hand, tgt_off then only places the result in `out`, and may exceed n_src) */
 } nb_launch_f32;
 typedef enum nb_launch_phase {
     NB_PHASE_WHOLE = 0,  /* the whole step in one call: start the sums, run the epilogue */

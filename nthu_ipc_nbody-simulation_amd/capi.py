@@ -48,7 +48,8 @@ class NbLaunchF32(C.Structure):
                 ("workspace_bytes", C.c_int64), ("n_src", C.c_int64), ("tgt_off", C.c_int64),
                 ("n_tgt", C.c_int64), ("eps2", C.c_float), ("dt", C.c_float), ("acc64", C.c_int32),
                 ("targets_per_lane", C.c_int32), ("j_split", C.c_int32), ("source_path", C.c_int32),
-                ("wg_size", C.c_int32), ("phase", C.c_int32), ("src_begin", C.c_int64), ("src_end", C.c_int64)]
+                ("wg_size", C.c_int32), ("phase", C.c_int32), ("src_begin", C.c_int64), ("src_end", C.c_int64),
+                ("tgt", C.c_void_p)]
 
 
 # every symbol include/nbody_amd.h declares: (restype, argtypes)
@@ -418,16 +419,17 @@ class Sharded:
 
 def _launch_struct(src_ptr, out_ptr, n_src, tgt_off, n_tgt, eps2, dt, vel_ptr=0, pos64_ptr=0, vel64_ptr=0, acc_ptr=0,
                    acc64=False, targets_per_lane=0, j_split=0, workspace_ptr=0, workspace_bytes=0, source_path=0,
-                   wg_size=0, phase=NB_PHASE_WHOLE, src_begin=0, src_end=0):
+                   wg_size=0, phase=NB_PHASE_WHOLE, src_begin=0, src_end=0, tgt_ptr=0):
     return NbLaunchF32(src_ptr or None, out_ptr or None, vel_ptr or None, pos64_ptr or None, vel64_ptr or None,
                        acc_ptr or None, workspace_ptr or None, workspace_bytes, n_src, tgt_off, n_tgt, eps2, dt,
-                       int(acc64), targets_per_lane, j_split, source_path, wg_size, phase, src_begin, src_end)
+                       int(acc64), targets_per_lane, j_split, source_path, wg_size, phase, src_begin, src_end,
+                       tgt_ptr or None)
 
 
 def launch_f32(src_ptr, out_ptr, n_src, tgt_off, n_tgt, eps2, dt, stream, accel_only=False, **kw):
     """Raw launch on caller-owned device memory (pointers as ints, e.g. torch.Tensor.data_ptr()).
     kw: vel_ptr, pos64_ptr, vel64_ptr, acc_ptr, acc64, targets_per_lane, j_split, workspace_ptr, workspace_bytes,
-    source_path, wg_size, phase, src_begin, src_end."""
+    source_path, wg_size, phase, src_begin, src_end, tgt_ptr."""
     a = _launch_struct(src_ptr, out_ptr, n_src, tgt_off, n_tgt, eps2, dt, **kw)
     f = lib().nb_launch_accel_f32 if accel_only else lib().nb_launch_step_f32
     _check(f(C.byref(a), C.c_void_p(stream)), "nb_launch_accel_f32" if accel_only else "nb_launch_step_f32")

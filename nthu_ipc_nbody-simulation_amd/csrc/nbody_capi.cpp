@@ -1701,8 +1701,8 @@ int nb_solve(int n, int planet, int asteroid, const double* qx, const double* qy
 
 // ---------------------------------------------------------------- raw launches on caller-owned HBM
 static int check_launch(const nb_launch_f32* a, bool accel_only) {
-    if (!a || !a->src || a->n_src <= 0 || a->n_tgt <= 0 || a->tgt_off < 0 || a->tgt_off + a->n_tgt > a->n_src)
-        return NB_ERR_INVALID;
+    if (!a || !a->src || a->n_src <= 0 || a->n_tgt <= 0 || a->tgt_off < 0) return NB_ERR_INVALID;
+    if (!a->tgt && a->tgt_off + a->n_tgt > a->n_src) return NB_ERR_INVALID;  // targets are a window of the sources
     if (!(a->eps2 > 0.f)) return NB_ERR_INVALID;
     if (accel_only ? !a->acc : (!a->out || (a->acc64 ? (!a->pos64 || !a->vel64) : !a->vel))) return NB_ERR_INVALID;
     const int r = a->targets_per_lane;
@@ -1737,6 +1737,7 @@ static F32Plan resolve_plan(const nb_launch_f32* a) {
 static F32Args to_args(const nb_launch_f32* a) {
     F32Args k{};
     k.src = (const float4*)a->src;
+    k.tgt = (const float4*)a->tgt;  // null -> src + tgt_off
     k.out = (float4*)a->out;
     k.vel = (float4*)a->vel;
     k.pos64 = (double4*)a->pos64;

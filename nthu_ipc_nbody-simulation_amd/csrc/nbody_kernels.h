@@ -14,6 +14,8 @@ constexpr int MAX_WATCH = 16;
 // ---------------------------------------------------------------- fp32 / fp32+fp64acc (large N)
 struct F32Args {
     const float4* src;  // [n_src] {x,y,z,G*m}
+    const float4* tgt;  // [n_tgt] the targets' own records: src + tgt_off (launch_f32 fills it in when null), or a separate
+                        // array when the sources of this launch are a block that travels (ring pass)
     float4* out;        // [n_src] other ping-pong array; [tgt_off, tgt_off+n_tgt) written
     float4* vel;        // [n_tgt]
     double4* pos64;     // [n_tgt] fp64 masters (ACC64 only)

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(WGS, (WGS == 1024 ? 4 : WGS == 512 ? 2 : (P >= 4 ? 
         for (int h = 0; h < 2; ++h) {
             long i = base + (long)(2 * p + h) * WG + t;
             long ic = i < a.n_tgt ? i : a.n_tgt - 1;  // tail lanes recompute the last body, never store
-            b[h] = a.src[a.tgt_off + ic];
+            b[h] = a.tgt[ic];
         }
         xi[p] = (v2f){b[0].x, b[1].x}; yi[p] = (v2f){b[0].y, b[1].y};
         zi[p] = (v2f){b[0].z, b[1].z}; gmi[p] = (v2f){b[0].w, b[1].w};
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(WG) void nbody_reduce_update_f32(F32Args a, int gy,
             run.x += p.x; run.y += p.y; run.z += p.z;
         }
         if (last) {
-            const float4 b = a.src[a.tgt_off + i];
+            const float4 b = a.tgt[i];
             finish_target<true, ACCEL_ONLY>(a, i, run.x, run.y, run.z, b.x, b.y, b.z, b.w);
         } else {
             ws[run_at] = run;
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(WG) void nbody_reduce_update_f32(F32Args a, int gy,
             y = p.z - c.z; t = run.z + y; c.z = (t - run.z) - y; run.z = t;
         }
         if (last) {
-            const float4 b = a.src[a.tgt_off + i];
+            const float4 b = a.tgt[i];
             finish_target<false, ACCEL_ONLY>(a, i, run.x, run.y, run.z, b.x, b.y, b.z, b.w);
         } else {
             ws[run_at] = run;
@@ -289,6 +289,7 @@ static int launch_one(const F32Args& a0, int js, hipStream_t stream) {
     const long blocks = (a0.n_tgt + per_block - 1) / per_block;
     if (blocks <= 0 || blocks > 0x7fffffffL) return (int)hipErrorInvalidValue;
     F32Args a = a0;
+    if (!a.tgt) a.tgt = a.src + a.tgt_off;
     if (a.src_begin == 0 && a.src_end == 0) a.src_end = a.n_src;
     if (a.src_begin % TILE || a.src_begin < 0 || a.src_end > a.n_src || a.src_begin > a.src_end) return (int)hipErrorInvalidValue;
     if (js <= 1 && a.phase == F32_PHASE_WHOLE) {

@@ -16,6 +16,13 @@ first (final as soon as this rank's previous launch has written it) while the as
 shards is still in flight, the remote shards after it — with the running sums kept in the kernel's workspace between
 the phases.  Off by default: bench.py reports both on the multi-GPU node (`overlap_ab`).
 
+`exchange="ring"` is the memory-scalable alternative (the ring-attention analogue): no rank ever holds all N
+positions.  A rank keeps its own shard (ping-pong) and two travelling blocks of N/P sources; a step is P phases — the own
+shard, then the block that has arrived from rank r-1 while the previous phase computed and the block before it was already
+on its way to rank r+1 — so the footprint is 4·N/P records instead of 2·N and every transfer overlaps a phase.  With
+288 GB per GPU the all-gather form never needs it at the BASELINE sizes (256 MiB at N = 2^24); it is here for systems
+whose positions do not fit twice on one device, parity-tested against the all-gather form.
+
 torch is used for device memory, the stream and the collective only; the arithmetic is the HIP kernel behind
 `capi.launch_f32`.  `compute` is injectable so the sharding/exchange logic can be exercised on CPU with gloo
 (tests/test_distributed_gloo.py passes the oracle there — test infrastructure, not a product fallback).
@@ -39,7 +46,8 @@ def hip_compute(acc64=False, targets_per_lane=0, j_split=0, source_path=0, wg_si
     (partial sums when a shard's targets alone cannot fill the chip) is a torch tensor allocated once."""
     ws = {}
 
-    def compute(src, out, vel, off, n_tgt, eps2, dt, pos64=None, vel64=None, src_range=None, phase=capi.NB_PHASE_WHOLE):
+    def compute(src, out, vel, off, n_tgt, eps2, dt, pos64=None, vel64=None, src_range=None, phase=capi.NB_PHASE_WHOLE,
+                tgt=None):
         if not src.is_cuda:
             raise RuntimeError("nbody_amd has no CPU compute path: tensors must live on a HIP device")
         key = (src.device, src.shape[0], n_tgt)
@@ -56,9 +64,22 @@ def hip_compute(acc64=False, targets_per_lane=0, j_split=0, source_path=0, wg_si
                         wg_size=wg_size,
                         workspace_ptr=w.data_ptr() if w is not None else 0,
                         workspace_bytes=w.numel() if w is not None else 0, phase=phase,
-                        src_begin=src_range[0] if src_range else 0, src_end=src_range[1] if src_range else 0)
+                        src_begin=src_range[0] if src_range else 0, src_end=src_range[1] if src_range else 0,
+                        tgt_ptr=tgt.data_ptr() if tgt is not None else 0)
 
     return compute
+
+
+class _StagedRecv:
+    """gloo rehearsal with device tensors: the receive lands in host memory and is copied to the device on wait()."""
+
+    def __init__(self, works, host, dev):
+        self.works, self.host, self.dev = works, host, dev
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        self.dev.copy_(self.host)
 
 
 class ShardedSystem:
@@ -76,9 +97,10 @@ class ShardedSystem:
         assert tuple(pos_shard.shape) == (self.n_tgt, 4) and tuple(vel_shard.shape) == (self.n_tgt, 4)
         self.eps2, self.dt = float(eps) * float(eps), float(dt)
         self.acc64 = acc64
-        if exchange not in ("in_place", "staged"):
-            raise ValueError(f"exchange={exchange!r}: expected 'in_place' or 'staged'")
+        if exchange not in ("in_place", "staged", "ring"):
+            raise ValueError(f"exchange={exchange!r}: expected 'in_place', 'staged' or 'ring'")
         self.exchange = exchange
+        self.ring = exchange == "ring" and self.world > 1
         # two-phase step: sources are cut at shard boundaries, which must be whole 256-body tiles of the kernel
         self.overlap = bool(overlap) and self.world > 1
         if self.overlap and self.n_tgt % 256:
@@ -87,8 +109,26 @@ class ShardedSystem:
         self.kernel_events = None  # a list: step() appends (start, end) torch.cuda.Event pairs around its launches
         self.trace = trace and torch.cuda.is_available()  # roctx ranges (torch.cuda.nvtx -> roctx on ROCm) for rocprofv3
         self.compute = compute or hip_compute(acc64)
-        self.pos = [torch.zeros((n, 4), dtype=torch.float32, device=device) for _ in range(2)]
         self.vel = vel_shard.to(device=device, dtype=torch.float32).contiguous()
+        if self.ring:
+            if overlap:
+                raise ValueError("the ring pass overlaps every transfer by construction: overlap=True has no meaning")
+            if acc64 and self.n_tgt % 256:
+                raise ValueError("ring pass: n/world must be a multiple of 256")
+            # own shard (ping-pong) + two travelling blocks: 4*N/P records, never all N
+            self.own = [pos_shard.to(device=device, dtype=torch.float32).contiguous().clone() for _ in range(2)]
+            self.blk = [torch.empty_like(self.own[0]) for _ in range(2)]
+            self.pos = None
+            self.pos64 = self.vel64 = None
+            if acc64:
+                self.pos64 = pos_shard.to(device=device, dtype=torch.float64).contiguous()
+                self.vel64 = vel_shard.to(device=device, dtype=torch.float64).contiguous()
+            self.cur = 0
+            self.overlap = False
+            self._pending = None
+            self.kernel_events = None
+            return
+        self.pos = [torch.zeros((n, 4), dtype=torch.float32, device=device) for _ in range(2)]
         self.pos64 = self.vel64 = None
         if acc64:
             self.pos64 = pos_shard.to(device=device, dtype=torch.float64).contiguous()
@@ -105,6 +145,8 @@ class ShardedSystem:
         "list" (gloo rehearsal / CPU tests)."""
         if not self.dist_on:
             return "none"
+        if self.ring:
+            return "ring"
         if dist.get_backend(self.group) == "nccl":
             return self.exchange
         return "list"
@@ -131,7 +173,43 @@ class ShardedSystem:
             self._pending.wait()
             self._pending = None
 
+    def _pass_block(self, send, recv):
+        """Start moving `send` to rank r+1 and the next block from rank r-1 into `recv`; -> handles to wait on."""
+        nxt, prv = (self.rank + 1) % self.world, (self.rank - 1) % self.world
+        if dist.get_backend(self.group) == "nccl":
+            return dist.batch_isend_irecv([dist.P2POp(dist.isend, send, nxt, self.group),
+                                           dist.P2POp(dist.irecv, recv, prv, self.group)])
+        # gloo (rehearsal / CPU tests): point-to-point on host memory
+        host_s = send if not send.is_cuda else send.cpu()
+        host_r = recv if not recv.is_cuda else torch.empty_like(recv, device="cpu")
+        works = [dist.isend(host_s, nxt, self.group), dist.irecv(host_r, prv, self.group)]
+        return [_StagedRecv(works, host_r, recv)] if recv.is_cuda else works
+
+    def _step_ring(self):
+        """P phases over the travelling blocks; block k (k = 0: own shard) holds the bodies of rank (r - k) mod P."""
+        tgt, out, P = self.own[self.cur], self.own[self.cur ^ 1], self.world
+        common = (out, self.vel, 0, self.n_tgt, self.eps2, self.dt, self.pos64, self.vel64)
+        pending = self._pass_block(tgt, self.blk[0])  # the own shard starts its round trip
+        self.compute(tgt, *common, phase=capi.NB_PHASE_FIRST, tgt=tgt)
+        for k in range(1, P):
+            have = self.blk[(k - 1) & 1]
+            for w in pending:
+                w.wait()  # block k is here (and the block sent before has left its buffer)
+            if k < P - 1:  # hand it on while it is being consumed; the other buffer is free since phase k - 1 computed
+                pending = self._pass_block(have, self.blk[k & 1])
+            self.compute(have, *common, phase=capi.NB_PHASE_LAST if k == P - 1 else capi.NB_PHASE_MIDDLE, tgt=tgt)
+        self.cur ^= 1
+
     def step(self):
+        if self.ring:
+            if self.kernel_events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            self._step_ring()
+            if self.kernel_events is not None:
+                e1.record()
+                self.kernel_events.append((e0, e1))
+            return
         src, out = self.pos[self.cur], self.pos[self.cur ^ 1]
         args = (src, out, self.vel, self.lo, self.n_tgt, self.eps2, self.dt, self.pos64, self.vel64)
         if self.trace:
@@ -166,6 +244,17 @@ class ShardedSystem:
 
     @property
     def positions(self):
+        """All N positions on this rank.  The ring pass never holds them: there they are gathered on demand (inspection
+        and checks only, not part of a step)."""
+        if self.ring:
+            full = torch.empty((self.n, 4), dtype=torch.float32, device=self.own[0].device)
+            mine = self.own[self.cur]
+            if dist.get_backend(self.group) == "nccl":
+                dist.all_gather_into_tensor(full, mine, group=self.group)
+            else:
+                dist.all_gather([full[r * self.n_tgt:(r + 1) * self.n_tgt] for r in range(self.world)], mine.clone(),
+                                group=self.group)
+            return full
         self._wait_gather()
         return self.pos[self.cur]
 

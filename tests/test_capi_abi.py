@@ -30,7 +30,7 @@ def test_struct_layouts_match_header(nb):
     assert C.sizeof(c.NbScenario) == 6 * 4 + 16 * 4 + 4 * 4 + 16  # ints, watch[], sync_every/engine/flags/reserved, 2 doubles
     assert C.sizeof(c.NbStateHeader) == 8 + 4 * 4 + 3 * 8
     assert C.sizeof(c.NbAnswer) == 24
-    assert C.sizeof(c.NbLaunchF32) == 7 * 8 + 4 * 8 + 8 * 4 + 2 * 8
+    assert C.sizeof(c.NbLaunchF32) == 7 * 8 + 4 * 8 + 8 * 4 + 3 * 8
 
 
 def test_no_cpu_fallback(nb):

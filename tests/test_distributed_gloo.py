@@ -23,7 +23,7 @@ N, STEPS = 512, 3
 def _oracle_compute(O, G, eps):
     carry = {}
 
-    def compute(src, out, vel, off, n_tgt, eps2, dt, pos64=None, vel64=None, src_range=None, phase=0):
+    def compute(src, out, vel, off, n_tgt, eps2, dt, pos64=None, vel64=None, src_range=None, phase=0, tgt=None):
         p = src.numpy().astype(np.float64)
         q = np.ascontiguousarray(p[:, :3].T)
         gm = np.ascontiguousarray(p[:, 3] / G)
@@ -31,7 +31,14 @@ def _oracle_compute(O, G, eps):
             mask = np.zeros_like(gm)
             mask[src_range[0]:src_range[1]] = 1.0
             gm = gm * mask
-        a = O.accel_rows(q, gm, G, eps, off, off + n_tgt, omp=False)
+        if tgt is not None:  # ring pass: `src` is a travelling block, the targets are a separate array
+            t = tgt.numpy().astype(np.float64)
+            d = p[None, :, :3] - t[:, None, :3]                      # (targets, sources, 3); the self pair is d = 0
+            w = (G * gm)[None, :] * (np.square(d).sum(axis=2) + eps * eps) ** -1.5
+            a = (w[:, :, None] * d).sum(axis=1).T
+            p = t  # the update below reads the targets' own records
+        else:
+            a = O.accel_rows(q, gm, G, eps, off, off + n_tgt, omp=False)
         if phase in (2, 3):   # NB_PHASE_LAST / NB_PHASE_MIDDLE continue the running sum
             a = carry["a"] + a
         if phase in (1, 3):   # NB_PHASE_FIRST / NB_PHASE_MIDDLE keep it for the next phase
@@ -42,11 +49,11 @@ def _oracle_compute(O, G, eps):
         newp = p[off:off + n_tgt, :3] + v[:, :3].astype(np.float64) * dt
         o = out.numpy()
         o[off:off + n_tgt, :3] = newp.astype(np.float32)
-        o[off:off + n_tgt, 3] = src.numpy()[off:off + n_tgt, 3]
+        o[off:off + n_tgt, 3] = p[off:off + n_tgt, 3].astype(np.float32)
     return compute
 
 
-def _run(rank, world, port, result_path, overlap=False):
+def _run(rank, world, port, result_path, overlap=False, exchange="in_place"):
     sys.path.insert(0, ROOT)
     import nbody_amd  # noqa: F401
     from nbody_amd import synthetic
@@ -57,8 +64,9 @@ def _run(rank, world, port, result_path, overlap=False):
     lo, hi = shard_range(N, rank, world)
     pos, vel = synthetic.body4_f32(N, lo, hi)
     sysm = ShardedSystem(N, torch.from_numpy(pos), torch.from_numpy(vel), synthetic.EPS, 1e-2, torch.device("cpu"),
-                         compute=_oracle_compute(O, synthetic.G, synthetic.EPS), overlap=overlap)
+                         compute=_oracle_compute(O, synthetic.G, synthetic.EPS), overlap=overlap, exchange=exchange)
     assert (sysm.lo, sysm.hi) == (lo, hi) and sysm.overlap == (overlap and world > 1)
+    assert sysm.exchange_mode == ("none" if world == 1 else "ring" if exchange == "ring" else "list")
     for _ in range(STEPS):
         sysm.step()
     # every rank must hold the same full position array after the exchange
@@ -104,6 +112,18 @@ def test_overlapped_two_phase_step_equals_plain_step(oracle, tmp_path):
     one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
     _run(0, 1, 0, one)
     mp.spawn(_run, args=(2, _free_port(), two, True), nprocs=2, join=True)
+    a, b = np.load(one), np.load(two)
+    assert np.abs(a["pos"] - b["pos"]).max() <= 1.2e-7 and np.abs(a["vel"] - b["vel"]).max() <= 1e-9
+    assert np.array_equal(a["pos"][:, 3], b["pos"][:, 3])
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_ring_pass_equals_all_gather(oracle, tmp_path, world):
+    """exchange="ring": no rank holds all positions; blocks of N/P sources travel rank to rank while the previous one is
+    consumed (P phases per step, running sums carried between them).  Same trajectory as the one-rank run."""
+    one, two = str(tmp_path / "one.npz"), str(tmp_path / "ring.npz")
+    _run(0, 1, 0, one)
+    mp.spawn(_run, args=(world, _free_port(), two, False, "ring"), nprocs=world, join=True)
     a, b = np.load(one), np.load(two)
     assert np.abs(a["pos"] - b["pos"]).max() <= 1.2e-7 and np.abs(a["vel"] - b["vel"]).max() <= 1e-9
     assert np.array_equal(a["pos"][:, 3], b["pos"][:, 3])

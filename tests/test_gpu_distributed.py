@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 N, STEPS = 16384, 4
 
 
-def _run(rank, world, port, path, acc64=False, backend="gloo", overlap=False):
+def _run(rank, world, port, path, acc64=False, backend="gloo", overlap=False, exchange="in_place"):
     sys.path.insert(0, ROOT)
     import nbody_amd  # noqa: F401
     from nbody_amd import synthetic
@@ -36,7 +36,7 @@ def _run(rank, world, port, path, acc64=False, backend="gloo", overlap=False):
         pos = np.concatenate([q.T, (synthetic.G * m)[:, None]], axis=1)
         vel = np.concatenate([v.T, np.zeros((hi - lo, 1))], axis=1)
     sysm = ShardedSystem(N, torch.from_numpy(pos), torch.from_numpy(vel), synthetic.EPS, 1e-2, dev, acc64=acc64,
-                         overlap=overlap)
+                         overlap=overlap, exchange=exchange)
     if backend == "nccl":
         assert sysm.exchange_mode == "in_place"
         before = sysm.positions.clone()
@@ -134,6 +134,23 @@ def test_overlapped_step_on_one_gpu_matches_single(nb, tmp_path, world, acc64):
     one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
     mp.spawn(_run, args=(1, 0, one, acc64), nprocs=1, join=True)
     mp.spawn(_run, args=(world, _free_port(), two, acc64, "gloo", True), nprocs=world, join=True)
+    a, b = np.load(one), np.load(two)
+    if acc64:
+        assert np.abs(a["pos64"] - b["pos64"])[:, :3].max() < 1e-9 and np.abs(a["vel"] - b["vel"]).max() < 1e-7
+    else:
+        assert np.abs(a["pos"] - b["pos"]).max() < 5e-7 and np.abs(a["vel"] - b["vel"]).max() < 1e-5
+    p0, _ = nb.synthetic.body4_f32(N)
+    assert np.abs(b["pos"][:, :3] - p0[:, :3]).max() > 1e-6 and np.array_equal(b["pos"][:, 3], p0[:, 3])
+
+
+@pytest.mark.parametrize("world,acc64", [(2, False), (4, False), (4, True)])
+def test_ring_pass_on_one_gpu_matches_single(nb, tmp_path, world, acc64):
+    """exchange="ring" with the real kernel: the sources of every phase are a travelling block of N/P bodies, the targets
+    a separate array (nb_launch_f32.tgt), P phases per step with the running sums in the workspace; no rank holds all N
+    positions.  Same trajectory as the unsharded run, to the rounding of a reordered sum."""
+    one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
+    mp.spawn(_run, args=(1, 0, one, acc64), nprocs=1, join=True)
+    mp.spawn(_run, args=(world, _free_port(), two, acc64, "gloo", False, "ring"), nprocs=world, join=True)
     a, b = np.load(one), np.load(two)
     if acc64:
         assert np.abs(a["pos64"] - b["pos64"])[:, :3].max() < 1e-9 and np.abs(a["vel"] - b["vel"]).max() < 1e-7
