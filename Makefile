@@ -2,7 +2,7 @@
 # (here bin/hw5 plus a ./hw5 copy) — now an MI355X program — and the shared library behind it.
 #   make            libnbody_amd.so + bin/hw5 (+ ./hw5)
 #   make oracle     the CPU checker under oracle/ (test infrastructure; builds oracle/_ref when /root/reference exists)
-#   make ubench     VALU issue-rate microbenchmark
+#   make ubench     microbenchmarks: VALU issue rate, force-loop variants, launch rate (eager vs hipGraph)
 HIPCC    ?= /opt/rocm/bin/hipcc
 ARCH     ?= gfx950
 PKG      := nthu_ipc_nbody-simulation_amd
@@ -46,11 +46,13 @@ bin/io_check_asan: $(SRC)/io_check.cpp $(SRC)/nbody_io.cpp $(SRC)/nbody_io.h
 	@mkdir -p bin
 	g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=all -o $@ $(SRC)/io_check.cpp $(SRC)/nbody_io.cpp
 
-ubench: bench/ubench/valu_rate bench/ubench/force_variants
+ubench: bench/ubench/valu_rate bench/ubench/force_variants bench/ubench/launch_rate
+bench/ubench/launch_rate: bench/ubench/launch_rate.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
 bench/ubench/force_variants: bench/ubench/force_variants.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -o $@ $<
 bench/ubench/valu_rate: bench/ubench/valu_rate.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
 
 clean:
-	rm -f $(LIB) bin/hw5 bin/nbody_bench bin/nbconv hw5 bench/ubench/valu_rate bench/ubench/force_variants
+	rm -f $(LIB) bin/hw5 bin/nbody_bench bin/nbconv hw5 bench/ubench/valu_rate bench/ubench/force_variants bench/ubench/launch_rate

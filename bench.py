@@ -158,6 +158,10 @@ def main():
                     "and print steps done + running pairs/s to stderr")
     ap.add_argument("--time-box", type=float, default=0.0, help="sustained runs: stop at a report point once this many "
                     "seconds have elapsed; the JSON then carries the steps actually completed")
+    ap.add_argument("--checkpoint", default="", help="sustained runs: NBODYST2 state file of the whole system, written by "
+                    "rank 0 every --checkpoint-every steps (a collective; costs wall time inside the timed region)")
+    ap.add_argument("--checkpoint-every", type=int, default=0)
+    ap.add_argument("--resume", default="", help="start from this checkpoint instead of the synthetic initial state")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; gloo + --single-device rehearses "
                     "the multi-rank path on a one-GPU box (RCCL refuses two ranks on one device)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
@@ -192,12 +196,21 @@ def main():
     n = args.bodies
     acc64 = args.precision == "f32acc64"
     lo, hi = shard_range(n, rank, world)
-    pos, vel = synthetic.body4_f32(n, lo, hi)
-    if acc64:
+    first_step = 0
+    if args.resume:
+        hdr, pos, vel = ShardedSystem.load_checkpoint_shard(args.resume, rank, world)
+        if hdr["n"] != n or hdr["dt"] != synthetic.DT or hdr["eps"] != synthetic.EPS:
+            raise SystemExit(f"--resume: {args.resume} holds n={hdr['n']} dt={hdr['dt']} eps={hdr['eps']}")
+        first_step = hdr["step"]
+        if not acc64:
+            pos, vel = pos.astype("float32"), vel.astype("float32")
+    elif acc64:
         q, v, m = synthetic.bodies(n, lo, hi)
         import numpy as np
-        pos = np.concatenate([q.T, (synthetic.G * m)[:, None]], axis=1)
-        vel = np.concatenate([v.T, np.zeros((hi - lo, 1))], axis=1)
+        pos = np.ascontiguousarray(np.concatenate([q.T, (synthetic.G * m)[:, None]], axis=1))
+        vel = np.ascontiguousarray(np.concatenate([v.T, np.zeros((hi - lo, 1))], axis=1))
+    else:
+        pos, vel = synthetic.body4_f32(n, lo, hi)
     compute = hip_compute(acc64, args.targets_per_lane, args.j_split, args.source_path, args.wg_size)
     sysm = ShardedSystem(n, torch.from_numpy(pos), torch.from_numpy(vel), synthetic.EPS, synthetic.DT, device,
                          compute=compute, acc64=acc64, overlap=args.overlap, exchange=args.exchange)
@@ -221,6 +234,8 @@ def main():
     for k in range(args.steps):
         sysm.step()
         steps_done += 1
+        if args.checkpoint and args.checkpoint_every and steps_done % args.checkpoint_every == 0:
+            sysm.save_checkpoint(args.checkpoint, first_step + args.warmup + steps_done, synthetic.G)
         if args.report_every and steps_done % args.report_every == 0 and steps_done < args.steps:
             torch.cuda.synchronize()
             el = time.perf_counter() - t0

@@ -95,7 +95,7 @@ class ShardedSystem:
         self.lo, self.hi = shard_range(n, self.rank, self.world)
         self.n_tgt = self.hi - self.lo
         assert tuple(pos_shard.shape) == (self.n_tgt, 4) and tuple(vel_shard.shape) == (self.n_tgt, 4)
-        self.eps2, self.dt = float(eps) * float(eps), float(dt)
+        self.eps, self.eps2, self.dt = float(eps), float(eps) * float(eps), float(dt)
         self.acc64 = acc64
         if exchange not in ("in_place", "staged", "ring"):
             raise ValueError(f"exchange={exchange!r}: expected 'in_place', 'staged' or 'ring'")
@@ -245,7 +245,7 @@ class ShardedSystem:
     @property
     def positions(self):
         """All N positions on this rank.  The ring pass never holds them: there they are gathered on demand (inspection
-        and checks only, not part of a step)."""
+        and checks only, not part of a step) — a COLLECTIVE in that mode: every rank must read the property."""
         if self.ring:
             full = torch.empty((self.n, 4), dtype=torch.float32, device=self.own[0].device)
             mine = self.own[self.cur]
@@ -257,6 +257,50 @@ class ShardedSystem:
             return full
         self._wait_gather()
         return self.pos[self.cur]
+
+    # ---- checkpoints of a sharded run (the 1000-step N = 2^24 run takes hours) ----
+    def _gather_rows(self, shard):
+        """(n_tgt, k) shard of every rank -> (N, k) on every rank (a collective)."""
+        if not self.dist_on or self.world == 1:
+            return shard.clone()
+        full = torch.empty((self.n,) + tuple(shard.shape[1:]), dtype=shard.dtype, device=shard.device)
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_gather_into_tensor(full, shard.contiguous(), group=self.group)
+        else:
+            dist.all_gather([full[r * self.n_tgt:(r + 1) * self.n_tgt] for r in range(self.world)], shard.contiguous(),
+                            group=self.group)
+        return full
+
+    def save_checkpoint(self, path, step, G):
+        """One NBODYST2 state file (include/nbody_amd.h) for the whole system, written by rank 0: q, v as the fp64 masters
+        (NB_F32_ACC64) or the widened fp32 state (NB_F32), m = (G*m)/G from the fp32 records.  A COLLECTIVE: every rank
+        calls it (velocities, and in the fp64-master and ring modes positions, live only on their owners)."""
+        self._wait_gather()
+        if self.acc64:
+            pos = self._gather_rows(self.pos64)
+            vel = self._gather_rows(self.vel64)
+        else:
+            pos = self.positions if self.ring or self.pos is None else self.pos[self.cur]
+            vel = self._gather_rows(self.vel)
+        if self.rank == 0:
+            p = pos.detach().cpu().numpy().astype("float64")
+            v = vel.detach().cpu().numpy().astype("float64")
+            capi.write_state_file(path, p[:, :3].T.copy(), v[:, :3].T.copy(), p[:, 3] / G,
+                                  precision=capi.NB_F32_ACC64 if self.acc64 else capi.NB_F32, step=step, G=G,
+                                  eps=self.eps, dt=self.dt)
+        if self.dist_on:
+            dist.barrier(group=self.group)  # the file is complete when any rank returns
+
+    @staticmethod
+    def load_checkpoint_shard(path, rank, world):
+        """-> (header, pos_shard (n_tgt,4) float64 {x,y,z,G*m}, vel_shard (n_tgt,4) float64) of this rank, ready for the
+        constructor; every rank reads the file itself (no collective)."""
+        import numpy as np
+        hdr, q, v, m, _ = capi.read_state_file(path)
+        lo, hi = shard_range(hdr["n"], rank, world)
+        pos = np.ascontiguousarray(np.concatenate([q[:, lo:hi].T, (hdr["G"] * m[lo:hi])[:, None]], axis=1))
+        vel = np.ascontiguousarray(np.concatenate([v[:, lo:hi].T, np.zeros((hi - lo, 1))], axis=1))
+        return hdr, pos, vel
 
     def pairs_per_step(self):
         """Interactions the whole job evaluates per step, counted as the reference does (nbody.cc:57-60): N(N-1)."""

@@ -12,7 +12,24 @@ TESTCASES = os.path.join(GOLDEN, "testcases")
 ALL_CASES = ["b20", "b30", "b40", "b50", "b60", "b70", "b80", "b90", "b100", "b200", "b512", "b1024"]
 
 
+_CONFIG = None
+
+
+def pytest_runtest_logreport(report):
+    """Push the progress dots out after every test: on the GPU box the runner's output goes through a pipe, and a run
+    that writes nothing for minutes is taken to be hung."""
+    tr = _CONFIG.pluginmanager.get_plugin("terminalreporter") if _CONFIG is not None else None
+    if tr is not None:
+        try:
+            tr._tw.flush()
+        except Exception:  # noqa: BLE001
+            pass
+    sys.stdout.flush()
+
+
 def pytest_configure(config):
+    global _CONFIG
+    _CONFIG = config
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long CPU-only oracle runs, opt in with NB_SLOW=1")
 

@@ -53,7 +53,7 @@ def _oracle_compute(O, G, eps):
     return compute
 
 
-def _run(rank, world, port, result_path, overlap=False, exchange="in_place"):
+def _run(rank, world, port, result_path, overlap=False, exchange="in_place", ckpt=None):
     sys.path.insert(0, ROOT)
     import nbody_amd  # noqa: F401
     from nbody_amd import synthetic
@@ -67,7 +67,14 @@ def _run(rank, world, port, result_path, overlap=False, exchange="in_place"):
                          compute=_oracle_compute(O, synthetic.G, synthetic.EPS), overlap=overlap, exchange=exchange)
     assert (sysm.lo, sysm.hi) == (lo, hi) and sysm.overlap == (overlap and world > 1)
     assert sysm.exchange_mode == ("none" if world == 1 else "ring" if exchange == "ring" else "list")
-    for _ in range(STEPS):
+    if ckpt:  # stop after the first step, write a checkpoint, and continue in a NEW system built from the file
+        sysm.step()
+        sysm.save_checkpoint(ckpt, 1, synthetic.G)
+        hdr, p2, v2 = ShardedSystem.load_checkpoint_shard(ckpt, rank, world)
+        assert (hdr["n"], hdr["step"], hdr["dt"], hdr["eps"], hdr["G"]) == (N, 1, 1e-2, synthetic.EPS, synthetic.G)
+        sysm = ShardedSystem(N, torch.from_numpy(p2), torch.from_numpy(v2), hdr["eps"], hdr["dt"], torch.device("cpu"),
+                             compute=_oracle_compute(O, synthetic.G, synthetic.EPS), overlap=overlap, exchange=exchange)
+    for _ in range(STEPS - (1 if ckpt else 0)):
         sysm.step()
     # every rank must hold the same full position array after the exchange
     full = sysm.positions.clone()
@@ -127,6 +134,20 @@ def test_ring_pass_equals_all_gather(oracle, tmp_path, world):
     a, b = np.load(one), np.load(two)
     assert np.abs(a["pos"] - b["pos"]).max() <= 1.2e-7 and np.abs(a["vel"] - b["vel"]).max() <= 1e-9
     assert np.array_equal(a["pos"][:, 3], b["pos"][:, 3])
+
+
+@pytest.mark.parametrize("exchange", ["in_place", "ring"])
+def test_sharded_checkpoint_resume_is_bitwise(oracle, tmp_path, exchange):
+    """SURVEY §8(f)-4 for the sharded host: rank 0 writes one NBODYST2 file for the whole system (velocities gathered from
+    their owners), every rank restarts from its slice of it; the resumed trajectory equals the uninterrupted one."""
+    ref, res = str(tmp_path / "ref.npz"), str(tmp_path / "res.npz")
+    mp.spawn(_run, args=(2, _free_port(), ref, False, exchange), nprocs=2, join=True)
+    mp.spawn(_run, args=(2, _free_port(), res, False, exchange, str(tmp_path / "ck.nbst")), nprocs=2, join=True)
+    a, b = np.load(ref), np.load(res)
+    assert np.array_equal(a["pos"], b["pos"]) and np.array_equal(a["vel"], b["vel"])
+    import nbody_amd  # noqa: F401
+    from nbody_amd import capi
+    assert capi.state_file_info(str(tmp_path / "ck.nbst")) == (N, capi.NB_F32, 1)
 
 
 def test_overlap_needs_tile_aligned_shards(nb):

@@ -58,9 +58,10 @@ def _run(rank, world, port, path, acc64=False, backend="gloo", overlap=False, ex
         allv = torch.cat(vels)
     else:
         allv = myv
+    full = sysm.positions  # every rank: with exchange="ring" this is a collective (no rank holds all positions)
     if rank == 0:
         extra = dict(pos64=pos64) if acc64 else {}
-        np.savez(path, pos=sysm.positions.cpu().numpy(), vel=allv.cpu().numpy(), **extra)
+        np.savez(path, pos=full.cpu().numpy(), vel=allv.cpu().numpy(), **extra)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
