@@ -15,6 +15,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <future>
 #include <limits>
 #include <memory>
 #include <new>
@@ -261,7 +263,20 @@ int nb_create(nb_context** out, const nb_config* cfg) {
     hipDeviceProp_t prop;
     NB_HIP(c, hipGetDeviceProperties(&prop, cfg->device));
     c->n_cus = prop.multiProcessorCount;
-    NB_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    // experiment knob (bench/scenario_concurrency.py): NB_CU_MASK=lo|hi|even|odd confines this context's stream to half
+    // of the compute units, so that two scenario streams do not share CUs
+    if (const char* e = getenv("NB_CU_MASK")) {
+        uint32_t mask[8];
+        const int cus = std::min(256, c->n_cus);
+        for (int w = 0; w < 8; ++w) mask[w] = 0;
+        for (int i = 0; i < cus; ++i) {
+            const bool on = !strcmp(e, "lo") ? i < cus / 2 : !strcmp(e, "hi") ? i >= cus / 2 : !strcmp(e, "even") ? !(i & 1) : (i & 1);
+            if (on) mask[i >> 5] |= 1u << (i & 31);
+        }
+        NB_HIP(c, hipExtStreamCreateWithCUMask(&c->stream, 8, mask));
+    } else {
+        NB_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    }
     NB_HIP(c, hipEventCreate(&c->ev0));
     NB_HIP(c, hipEventCreate(&c->ev1));
     const size_t n = (size_t)c->n;
@@ -541,7 +556,9 @@ int ensure_fst_table(nb_context* c, int last_step) {
         std::vector<double> tab((size_t)need);
         for (int k = 0; k < need; ++k) tab[(size_t)k] = fst_of(k, c->cfg.dt);
         NB_HIP(c, hipMalloc(&c->fst_dev, (size_t)need * sizeof(double)));
-        NB_HIP(c, hipMemcpy(c->fst_dev, tab.data(), (size_t)need * sizeof(double), hipMemcpyHostToDevice));
+        // (never the legacy stream: another host thread may be capturing a graph on its own context's stream)
+        NB_HIP(c, hipMemcpyAsync(c->fst_dev, tab.data(), (size_t)need * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        NB_HIP(c, hipStreamSynchronize(c->stream));
         c->fst_len = need;
     }
     return NB_OK;
@@ -761,7 +778,9 @@ int group_prepare(GraphGroup& g) {
     NB_HIP(c0, hipStreamSynchronize(stream));
 
     const int count = (int)g.slots.size();
-    NB_HIP(c0, hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    // relaxed mode: the capture restricts neither this thread's nor other host threads' HIP calls on OTHER streams
+    // (distinct contexts may be driven from distinct threads); nothing but the launches below touches `stream` meanwhile
+    NB_HIP(c0, hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed));
     hipError_t bad = hipSuccess;
     for (int t = 0; t < GRAPH_CHUNK && bad == hipSuccess; ++t) {
         F64BatchArgs args{};
@@ -863,11 +882,13 @@ int activate_follower(GraphGroup& g, GraphSlot& f, int arr) {
     } else {  // another GPU: through the host
         std::vector<double> hq(3 * n), hv(3 * n);
         if (int rc = bind(p.c)) return rc;
-        NB_HIP(c0, hipMemcpy(hq.data(), sq, B, hipMemcpyDeviceToHost));
-        NB_HIP(c0, hipMemcpy(hv.data(), sv, B, hipMemcpyDeviceToHost));
+        NB_HIP(c0, hipMemcpyAsync(hq.data(), sq, B, hipMemcpyDeviceToHost, p.c->stream));
+        NB_HIP(c0, hipMemcpyAsync(hv.data(), sv, B, hipMemcpyDeviceToHost, p.c->stream));
+        NB_HIP(c0, hipStreamSynchronize(p.c->stream));
         if (int rc = bind(c0)) return rc;
-        NB_HIP(c0, hipMemcpy(f.c->q[f.c->cur], hq.data(), B, hipMemcpyHostToDevice));
-        NB_HIP(c0, hipMemcpy(f.c->v, hv.data(), B, hipMemcpyHostToDevice));
+        NB_HIP(c0, hipMemcpyAsync(f.c->q[f.c->cur], hq.data(), B, hipMemcpyHostToDevice, f.c->stream));
+        NB_HIP(c0, hipMemcpyAsync(f.c->v, hv.data(), B, hipMemcpyHostToDevice, f.c->stream));
+        NB_HIP(c0, hipStreamSynchronize(f.c->stream));  // host staging buffers die here; the group's stream starts later
     }
     f.base = arr;
     f.active = true;
@@ -924,11 +945,26 @@ int schedule_followers(std::vector<GraphGroup*>& groups, int parallel) {
 int run_groups_graph(std::vector<GraphGroup*>& groups, int follower_parallel = 1 << 30) {
     for (;;) {
         bool progressed = false;
+        // enqueueing a replay costs the host about a millisecond per 1000 nodes: groups enqueue side by side (graphs are
+        // captured serially, on the calling thread, the first time round)
+        std::vector<GraphGroup*> due;
         for (GraphGroup* g : groups)
             if (g->running() && g->anything_active() && g->launched - g->collected < 2) {
-                if (int rc = group_launch(*g)) return rc;
-                progressed = true;
+                if (!g->prepared)
+                    if (int rc = group_prepare(*g)) return rc;
+                due.push_back(g);
             }
+        if (!due.empty()) {
+            std::vector<std::future<int>> side;
+            for (size_t k = 1; k < due.size(); ++k) side.push_back(std::async(std::launch::async, group_launch, std::ref(*due[k])));
+            int rc = group_launch(*due[0]);
+            for (auto& f : side) {
+                const int r = f.get();
+                if (!rc) rc = r;
+            }
+            if (rc) return rc;
+            progressed = true;
+        }
         for (GraphGroup* g : groups)
             if (g->launched > g->collected && (g->launched - g->collected == 2 || !g->running() || !g->anything_active() ||
                                                !progressed)) {
@@ -1122,8 +1158,11 @@ static int nb_restore_snapshot_impl(nb_context* dst, nb_context* src, int slot) 
     const size_t n = (size_t)src->n;
     std::vector<double> q(3 * n), v(3 * n);
     if (int rc = bind(src)) return rc;
-    NB_HIP(src, hipMemcpy(q.data(), src->snap_q + (size_t)slot * 3 * n, 3 * n * sizeof(double), hipMemcpyDeviceToHost));
-    NB_HIP(src, hipMemcpy(v.data(), src->snap_v + (size_t)slot * 3 * n, 3 * n * sizeof(double), hipMemcpyDeviceToHost));
+    NB_HIP(src, hipMemcpyAsync(q.data(), src->snap_q + (size_t)slot * 3 * n, 3 * n * sizeof(double), hipMemcpyDeviceToHost,
+                               src->stream));
+    NB_HIP(src, hipMemcpyAsync(v.data(), src->snap_v + (size_t)slot * 3 * n, 3 * n * sizeof(double), hipMemcpyDeviceToHost,
+                               src->stream));
+    NB_HIP(src, hipStreamSynchronize(src->stream));
     return nb_set_state(dst, q.data(), q.data() + n, q.data() + 2 * n, v.data(), v.data() + n, v.data() + 2 * n,
                         src->m_host.data(), src->dev_host.data());
 }

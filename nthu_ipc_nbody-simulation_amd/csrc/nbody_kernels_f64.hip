@@ -126,11 +126,27 @@ __device__ __forceinline__ void step_f64_body(const F64Args& a) {
             const int idx = step - 1;
             const bool rec = blockIdx.x == 0;
             F64Monitor* mon = a.mon;
+            // every load the monitor can need is issued up front, unconditionally, so that thread 0 pays ONE memory round
+            // trip — the whole workgroup waits for its decisions at the barrier below (P2 and the Problem-3 runs are the
+            // critical chain of the program).  Devices beyond the first PRE watched ones take the dependent path.
+            constexpr int PRE = 4;
             const double d2 = dist2_bodies(a.qin, n, sc.planet, sc.asteroid);
+            int hit = -2, arr_pre[PRE];
+            double m_pre[PRE], d2_pre[PRE];
+            if (sc.kind != 0) {
+                hit = mon->hit_step;
+#pragma unroll
+                for (int k = 0; k < PRE; ++k) {
+                    const bool on = k < sc.n_watch;
+                    const int d = on ? sc.watch[k] : sc.planet;
+                    arr_pre[k] = on ? mon->arrival_step[k] : -2;
+                    m_pre[k] = a.m[d];
+                    d2_pre[k] = dist2_bodies(a.qin, n, sc.planet, d);
+                }
+            }
             if (sc.kind == 0) {  // MIN_DIST: nbody.cc:118-121 (min of squares; sqrt on the host)
                 if (rec && d2 < mon->min_d2) mon->min_d2 = d2;
             } else {
-                int hit = mon->hit_step;
                 if (hit == -2 && d2 < sc.R2) {  // nbody.cc:134-137 ; hw5.cu:295-298 (hit test comes first)
                     hit = idx;
                     if (rec) mon->hit_step = idx;
@@ -138,15 +154,21 @@ __device__ __forceinline__ void step_f64_body(const F64Args& a) {
                 if (hit != -2) {
                     skip = 1;  // P2 stops at the first hit; a destroyed-device run has failed
                 } else {
+                    const double md = sc.missile_dstep * idx;  // hw5.cu:274,303
                     for (int k = 0; k < sc.n_watch; ++k) {
-                        int arr = mon->arrival_step[k];
                         const int d = sc.watch[k];
-                        if (arr == -2 && a.m[d] != 0.0) {  // hw5.cu:299 m[d] != 0
-                            double md = sc.missile_dstep * idx;  // hw5.cu:274,303
-                            if (dist2_bodies(a.qin, n, sc.planet, d) < md * md) {
-                                arr = idx;
-                                if (rec) mon->arrival_step[k] = idx;
-                            }
+                        int arr;
+                        double mk, dk2;
+                        if (k < PRE) {
+                            arr = arr_pre[k]; mk = m_pre[k]; dk2 = d2_pre[k];
+                        } else {
+                            arr = mon->arrival_step[k];
+                            mk = a.m[d];
+                            dk2 = (arr == -2 && mk != 0.0) ? dist2_bodies(a.qin, n, sc.planet, d) : 0.0;
+                        }
+                        if (arr == -2 && mk != 0.0 && dk2 < md * md) {  // hw5.cu:299 m[d] != 0
+                            arr = idx;
+                            if (rec) mon->arrival_step[k] = idx;
                         }
                         if (arr == idx) snap |= 1u << k;                                // hw5.cu:277-285
                         if (arr != -2 && sc.destroy_on_arrival) destroyed |= 1u << k;   // hw5.cu:306
@@ -657,9 +679,10 @@ int launch_f64(const F64Args& a, int S, hipStream_t stream) {
     return (int)hipErrorInvalidValue;
 }
 
-// lanes per target so that n*S threads give about one 256-thread workgroup per TWO CUs.  The launch is latency-bound
-// and every workgroup stages the whole system, so more workgroups only add L2 traffic: measured at n = 1024,
-// S = 32 (128 workgroups) 5.9 us/step, S = 64 (256 workgroups) 6.2 us/step (profiles/r01_f64_step_timing.txt).
+// lanes per target: as many as keep n*S threads within one 256-thread workgroup per CU — S = 64 (a whole wave per target)
+// for every testcase size, n = 1024 included (256 workgroups of 4 targets).  The launch is latency-bound, so the shortest
+// per-lane pair loop wins: measured at n = 1024 with graph replay, S = 64 5.3 us/step, S = 32 (128 workgroups, 32 pairs per
+// lane) 7.1, S = 16 10.5 (profiles/r02_scenario_batch_timing.txt; NB_F64_SPLIT overrides for experiments).
 int auto_split_f64(int n, int n_cus) {
     // beyond the testcase sizes the launch is compute-bound instead: give every SIMD ~4 waves of fp64 work
     long want = (long)n_cus * WG * (n > K2_TILE ? 8 : 1);

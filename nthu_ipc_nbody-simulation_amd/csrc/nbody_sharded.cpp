@@ -293,16 +293,19 @@ int set_state_impl(nb_sharded* s, const double* qx, const double* qy, const doub
         for (size_t i = 0; i < per; ++i) v[i] = make_float4((float)vx[lo + i], (float)vy[lo + i], (float)vz[lo + i], 0.f);
         // both ping-pong arrays get every body once: the slots other GPUs own are refreshed by the all-gather, and the
         // G*m column never changes
-        SH_HIP(s, hipMemcpy(k.pos[0], p.data(), N * sizeof(float4), hipMemcpyHostToDevice));
-        SH_HIP(s, hipMemcpy(k.pos[1], p.data(), N * sizeof(float4), hipMemcpyHostToDevice));
-        SH_HIP(s, hipMemcpy(k.vel, v.data(), per * sizeof(float4), hipMemcpyHostToDevice));
+        // (stream-ordered, never the legacy stream: another host thread may be capturing a graph)
+        SH_HIP(s, hipMemcpyAsync(k.pos[0], p.data(), N * sizeof(float4), hipMemcpyHostToDevice, k.stream));
+        SH_HIP(s, hipMemcpyAsync(k.pos[1], p.data(), N * sizeof(float4), hipMemcpyHostToDevice, k.stream));
+        SH_HIP(s, hipMemcpyAsync(k.vel, v.data(), per * sizeof(float4), hipMemcpyHostToDevice, k.stream));
+        SH_HIP(s, hipStreamSynchronize(k.stream));  // `v` is refilled for the next GPU
         if (acc64(s)) {
             for (size_t i = 0; i < per; ++i) {
                 p64[i] = make_double4(qx[lo + i], qy[lo + i], qz[lo + i], s->G * m[lo + i]);
                 v64[i] = make_double4(vx[lo + i], vy[lo + i], vz[lo + i], 0.0);
             }
-            SH_HIP(s, hipMemcpy(k.pos64, p64.data(), per * sizeof(double4), hipMemcpyHostToDevice));
-            SH_HIP(s, hipMemcpy(k.vel64, v64.data(), per * sizeof(double4), hipMemcpyHostToDevice));
+            SH_HIP(s, hipMemcpyAsync(k.pos64, p64.data(), per * sizeof(double4), hipMemcpyHostToDevice, k.stream));
+            SH_HIP(s, hipMemcpyAsync(k.vel64, v64.data(), per * sizeof(double4), hipMemcpyHostToDevice, k.stream));
+            SH_HIP(s, hipStreamSynchronize(k.stream));
         }
     }
     s->cur = 0;
@@ -318,8 +321,9 @@ int get_state_impl(nb_sharded* s, double* qx, double* qy, double* qz, double* vx
         std::vector<double4> p(per), v(per);
         for (Rank& k : s->rank) {
             SH_HIP(s, hipSetDevice(k.device));
-            SH_HIP(s, hipMemcpy(p.data(), k.pos64, per * sizeof(double4), hipMemcpyDeviceToHost));
-            SH_HIP(s, hipMemcpy(v.data(), k.vel64, per * sizeof(double4), hipMemcpyDeviceToHost));
+            SH_HIP(s, hipMemcpyAsync(p.data(), k.pos64, per * sizeof(double4), hipMemcpyDeviceToHost, k.stream));
+            SH_HIP(s, hipMemcpyAsync(v.data(), k.vel64, per * sizeof(double4), hipMemcpyDeviceToHost, k.stream));
+            SH_HIP(s, hipStreamSynchronize(k.stream));
             const size_t lo = (size_t)k.lo;
             for (size_t i = 0; i < per; ++i) {
                 qx[lo + i] = p[i].x; qy[lo + i] = p[i].y; qz[lo + i] = p[i].z;
@@ -333,11 +337,13 @@ int get_state_impl(nb_sharded* s, double* qx, double* qy, double* qz, double* vx
     std::vector<float4> p(N), v(per);
     Rank& last = s->rank.back();
     SH_HIP(s, hipSetDevice(last.device));
-    SH_HIP(s, hipMemcpy(p.data(), last.pos[s->cur], N * sizeof(float4), hipMemcpyDeviceToHost));
+    SH_HIP(s, hipMemcpyAsync(p.data(), last.pos[s->cur], N * sizeof(float4), hipMemcpyDeviceToHost, last.stream));
+    SH_HIP(s, hipStreamSynchronize(last.stream));
     for (size_t i = 0; i < N; ++i) { qx[i] = p[i].x; qy[i] = p[i].y; qz[i] = p[i].z; }
     for (Rank& k : s->rank) {
         SH_HIP(s, hipSetDevice(k.device));
-        SH_HIP(s, hipMemcpy(v.data(), k.vel, per * sizeof(float4), hipMemcpyDeviceToHost));
+        SH_HIP(s, hipMemcpyAsync(v.data(), k.vel, per * sizeof(float4), hipMemcpyDeviceToHost, k.stream));
+        SH_HIP(s, hipStreamSynchronize(k.stream));
         const size_t lo = (size_t)k.lo;
         for (size_t i = 0; i < per; ++i) { vx[lo + i] = v[i].x; vy[lo + i] = v[i].y; vz[lo + i] = v[i].z; }
     }
