@@ -51,5 +51,9 @@ int main(int argc, char** argv) {
         fprintf(stderr, "hw5: cannot write %s\n", argv[2]);
         return 1;
     }
-    return 0;
+    // The answer is on disk (write_output closes the file) and nb_solve has released everything it created: leave without
+    // running the HIP runtime's exit handlers — they take 60-90 ms of a 0.5-1.6 s program (profiles/r02_startup_probe.txt)
+    // and free only what the kernel driver reclaims at process exit anyway.
+    fflush(nullptr);
+    std::_Exit(0);
 }

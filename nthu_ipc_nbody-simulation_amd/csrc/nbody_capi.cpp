@@ -32,6 +32,8 @@ struct nb_context {
     int n = 0;
     int n_cus = 0;
     hipStream_t stream = nullptr;
+    bool owns_stream = true;  // false: borrowed from another context of the same GPU (nb_solve: a stream costs ~8 ms to
+                              // create, and only the leader of a launch stream ever enqueues on it)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool have_state = false;
     char err[512] = {0};
@@ -121,7 +123,7 @@ void release(nb_context* c) {
     free_dev(c->partial);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream && c->owns_stream) (void)hipStreamDestroy(c->stream);
 }
 
 F64Args base_args(nb_context* c, int step) {
@@ -246,7 +248,22 @@ const char* nb_strerror(int code) {
 
 const char* nb_last_error(const nb_context* ctx) { return ctx ? ctx->err : g_err; }
 
-int nb_create(nb_context** out, const nb_config* cfg) {
+}  // extern "C"
+
+namespace {
+int create_context(nb_context** out, const nb_config* cfg, hipStream_t borrowed);
+}
+
+extern "C" {
+
+int nb_create(nb_context** out, const nb_config* cfg) { return create_context(out, cfg, nullptr); }
+
+}  // extern "C"
+
+namespace {
+
+// `borrowed`: use this stream (of another context on the same GPU, which must outlive this one) instead of creating one
+int create_context(nb_context** out, const nb_config* cfg, hipStream_t borrowed) {
     if (!out || !cfg || cfg->n <= 0) return NB_ERR_INVALID;
     if (cfg->precision < NB_F64 || cfg->precision > NB_F32_ACC64) return NB_ERR_INVALID;
     if (cfg->precision != NB_F64 && !(cfg->eps > 0)) return NB_ERR_INVALID;  // fp32 kernels evaluate the self pair
@@ -265,7 +282,10 @@ int nb_create(nb_context** out, const nb_config* cfg) {
     c->n_cus = prop.multiProcessorCount;
     // experiment knob (bench/scenario_concurrency.py): NB_CU_MASK=lo|hi|even|odd confines this context's stream to half
     // of the compute units, so that two scenario streams do not share CUs
-    if (const char* e = getenv("NB_CU_MASK")) {
+    if (borrowed) {
+        c->stream = borrowed;
+        c->owns_stream = false;
+    } else if (const char* e = getenv("NB_CU_MASK")) {
         uint32_t mask[8];
         const int cus = std::min(256, c->n_cus);
         for (int w = 0; w < 8; ++w) mask[w] = 0;
@@ -323,6 +343,10 @@ int nb_create(nb_context** out, const nb_config* cfg) {
     }
     return NB_OK;
 }
+
+}  // namespace
+
+extern "C" {
 
 int nb_destroy(nb_context* ctx) {
     if (!ctx) return NB_ERR_INVALID;
@@ -1032,7 +1056,15 @@ int run_batched_impl(nb_context** ctxs, const nb_scenario* scns, nb_scenario_res
             at[b] = scns[b].first_step;
             if (int rc = ensure_done_word(ctxs[b])) { snprintf(c0->err, sizeof c0->err, "%s", ctxs[b]->err); return rc; }
         }
+        const bool trace = getenv("NB_SOLVE_TRACE") != nullptr;
+        const auto t_k3 = std::chrono::steady_clock::now();
+        auto lap = [&](const char* what, int a0, int a1) {
+            if (trace)
+                fprintf(stderr, "[K3 batch] %8.1f ms  %s %d %d\n",
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_k3).count(), what, a0, a1);
+        };
         if (int rc = ensure_fst_table(c0, max_last)) return rc;  // same dt everywhere: one table serves the batch
+        lap("|sin| table ready, entries", max_last + 3, 0);
         int running = count;
         while (running > 0) {
             F64SmallBatchArgs args{};
@@ -1040,7 +1072,9 @@ int run_batched_impl(nb_context** ctxs, const nb_scenario* scns, nb_scenario_res
             int to[MAX_BATCH];
             for (int b = 0; b < count; ++b) {
                 if (done_at[b] >= 0) continue;  // finished slot: item[b].n stays 0
-                to[b] = std::min(scns[b].last_step, at[b] + SMALL_CHUNK);
+                // each workgroup runs to the end of its own scenario (it stops by itself at a hit): chunking the launch would
+                // make every scenario wait for the slowest one of the batch at each chunk boundary
+                to[b] = scns[b].last_step;
                 args.item[b] = small_args(ctxs[b], sc[b], snap[b], c0->fst_dev, at[b], to[b], scns[b].last_step);
             }
             NB_HIP(c0, (hipError_t)launch_f64_small_batched(args, c0->n, stream));
@@ -1050,9 +1084,11 @@ int run_batched_impl(nb_context** ctxs, const nb_scenario* scns, nb_scenario_res
                 NB_HIP(c0, hipMemcpyAsync(ctxs[b]->done_host, ctxs[b]->done_dev, sizeof(int), hipMemcpyDeviceToHost, stream));
             }
             NB_HIP(c0, hipStreamSynchronize(stream));
+            lap("launch returned, slots still running before it", running, 0);
             for (int b = 0; b < count; ++b) {
                 if (done_at[b] >= 0) continue;
                 at[b] = *ctxs[b]->done_host;
+                lap("  slot reached state", b, at[b]);
                 if (ctxs[b]->mon_host->hit_step != -2 || at[b] < to[b] || at[b] >= scns[b].last_step) {
                     done_at[b] = at[b];
                     --running;
@@ -1405,6 +1441,13 @@ struct CtxDeleter {
 };
 using CtxPtr = std::unique_ptr<nb_context, CtxDeleter>;
 
+struct CtxList {  // destroyed newest first: a context that borrows a stream dies before the context that owns it
+    std::vector<CtxPtr> v;
+    ~CtxList() {
+        while (!v.empty()) v.pop_back();
+    }
+};
+
 struct ThreadJoiner {  // no exception may leave joinable threads behind (std::terminate)
     std::vector<std::thread>& ts;
     ~ThreadJoiner() {
@@ -1436,7 +1479,8 @@ void run_group(const SolveInput& in, int gpu, const std::vector<SolveSlot*>& slo
     try {
         for (size_t at = 0; at < slots.size(); at += (size_t)cap) {
             const int cnt = (int)std::min(slots.size() - at, (size_t)cap);
-            std::vector<CtxPtr> owned;
+            CtxList list;
+            std::vector<CtxPtr>& owned = list.v;
             nb_context* ctxs[MAX_BATCH];
             nb_scenario scns[MAX_BATCH];
             nb_scenario_result ress[MAX_BATCH];
@@ -1448,7 +1492,8 @@ void run_group(const SolveInput& in, int gpu, const std::vector<SolveSlot*>& slo
                 cfg.n = in.n;
                 cfg.device = gpu;
                 nb_context* c = nullptr;
-                rc = nb_create(&c, &cfg);
+                // one launch stream serves the whole batch: only its leader creates a stream
+                rc = create_context(&c, &cfg, k > 0 && ctxs[0] ? ctxs[0]->stream : nullptr);
                 owned.emplace_back(c);
                 if (!rc)
                     rc = nb_set_state(c, in.qx, in.qy, in.qz, in.vx, in.vy, in.vz,
@@ -1574,13 +1619,14 @@ int solve_impl(int n, int planet, int asteroid, const double* qx, const double* 
         // 482-489) at most one replay (GRAPH_CHUNK steps) behind, so the whole program ends one replay after P1 does.
         // Independent streams keep the scenarios out of phase — one's latency-bound launch prologue overlaps another's
         // pair loop — which a lock-step batch of large systems cannot (profiles/r02_scenario_batch_timing.txt).
-        std::vector<CtxPtr> owned;
-        auto make = [&](int gpu, bool zero_devices, nb_context** c) -> int {
+        CtxList list;
+        std::vector<CtxPtr>& owned = list.v;
+        auto make = [&](int gpu, bool zero_devices, nb_context** c, hipStream_t borrowed) -> int {
             nb_config cfg;
             nb_config_default(&cfg);
             cfg.n = n;
             cfg.device = gpu;
-            int rc = nb_create(c, &cfg);
+            int rc = create_context(c, &cfg, borrowed);
             owned.emplace_back(*c);
             if (rc) return set_error(rc, *c ? nb_last_error(*c) : "nb_create");
             rc = nb_set_state(*c, qx, qy, qz, vx, vy, vz, zero_devices ? m_no_devices.data() : m, is_device);
@@ -1598,8 +1644,9 @@ int solve_impl(int n, int planet, int asteroid, const double* qx, const double* 
         if (const char* e = getenv("NB_SOLVE_STREAMS")) merged = !strcmp(e, "merged");
         std::vector<GraphGroup> groups(merged ? 3 * G : 2 + 2 * G);
         std::vector<nb_context*> cs(slots.size(), nullptr);
-        if (int rc = make(gpus[0], true, &cs[0])) return rc;
-        if (int rc = make(gpus[1 % G], false, &cs[1])) return rc;
+        // a launch stream's leader creates the stream (~8 ms each); the other scenarios of that stream borrow it
+        if (int rc = make(gpus[0], true, &cs[0], nullptr)) return rc;
+        if (int rc = make(gpus[1 % G], false, &cs[1], (merged && G == 1) ? cs[0]->stream : nullptr)) return rc;
         GraphGroup* p2_group = nullptr;
         int p2_slot = 0;
         for (size_t i = 0; i < 2; ++i) {
@@ -1613,7 +1660,6 @@ int solve_impl(int n, int planet, int asteroid, const double* qx, const double* 
         }
         for (size_t k = 0; k < D; ++k) {
             const size_t gi = (2 + k) % G;  // GPU of this device's run
-            if (int rc = make(gpus[gi], false, &cs[2 + k])) return rc;
             GraphGroup* g = nullptr;
             if (merged) {  // the GPU's shared graph while it has room (8 scenarios per launch), then two overflow graphs
                 for (size_t j = 0; j < 3 && !g; ++j)
@@ -1623,6 +1669,7 @@ int solve_impl(int n, int planet, int asteroid, const double* qx, const double* 
                 if (g->slots.size() >= (size_t)MAX_BATCH) g = nullptr;
             }
             if (!g) return set_error(NB_ERR_INVALID, "too many gravity devices per stream");
+            if (int rc = make(gpus[gi], false, &cs[2 + k], g->lead ? g->lead->stream : nullptr)) return rc;
             if (!g->lead) g->lead = cs[2 + k];
             GraphSlot f;
             f.c = cs[2 + k];

@@ -296,8 +296,14 @@ __global__ __launch_bounds__(WG) void nbody_step_f64_batched(F64BatchArgs b) {
 // from LDS (identical inputs -> identical, hence workgroup-uniform, decisions): no flags, no inter-workgroup protocol,
 // no grid barrier, every wave reaches the loop exit.  Same arithmetic as K2 (same G*m_eff rounding, same pair term,
 // same non-contracted kick/drift); only the summation split S differs.
-template <int S, bool SELFCHECK>
+// FEW: at most SMALL_FEW watched devices (the reference's inputs have 2-4) — their arrival steps live in registers and the
+// monitor is straight-line code over them, with every LDS read it can need issued up front.  (A runtime-indexed arr[k] would
+// live in scratch memory: measured +0.45 us per step at n = 20, +0.75 us at n = 100 for the FIRST_HIT / MISSILE scenarios.)
+// !FEW: up to MAX_WATCH devices, same code unrolled over all of them.
+constexpr int SMALL_FEW = 4;
+template <int S, bool SELFCHECK, bool FEW>
 __device__ __forceinline__ void scenario_small_body(const F64SmallArgs& a) {
+    constexpr int NW = FEW ? SMALL_FEW : MAX_WATCH;
     __shared__ double sq[2][3][SMALL_N_MAX];
     __shared__ double sg[2][SMALL_N_MAX];
     const int t = threadIdx.x;
@@ -321,11 +327,11 @@ __device__ __forceinline__ void scenario_small_body(const F64SmallArgs& a) {
     // scenario state, replicated in every thread (all derive it from the same LDS words)
     double min_d2 = a.mon->min_d2;
     int hit = a.mon->hit_step;
-    int arr[MAX_WATCH];
+    int arr[NW];
     int dead_j = -1;  // MISSILE: the destroyed device's index once its missile has arrived
     unsigned alive = 0;  // bit k: watched device k has a non-zero base mass (hw5.cu:299), read once
 #pragma unroll
-    for (int k = 0; k < MAX_WATCH; ++k) {
+    for (int k = 0; k < NW; ++k) {
         arr[k] = a.mon->arrival_step[k];
         if (k < sc.n_watch && a.m[sc.watch[k]] != 0.0) alive |= 1u << k;
     }
@@ -347,23 +353,28 @@ __device__ __forceinline__ void scenario_small_body(const F64SmallArgs& a) {
             if (d2 < min_d2) min_d2 = d2;
             return false;
         }
+        // planet-device distances of the devices still waiting for their missile: all LDS reads in flight together
+        double dk[NW];
+#pragma unroll
+        for (int k = 0; k < NW; ++k)
+            dk[k] = (k < sc.n_watch && arr[k] == -2) ? d2_of(buf, sc.planet, sc.watch[k]) : 0.0;
         if (d2 < sc.R2) {  // nbody.cc:134-137 ; hw5.cu:295-298
             hit = idx;
             return true;
         }
-        for (int k = 0; k < sc.n_watch; ++k) {
-            const int d = sc.watch[k];
-            if (arr[k] == -2 && (alive & (1u << k))) {  // hw5.cu:299
-                const double md = sc.missile_dstep * idx;
-                if (d2_of(buf, sc.planet, d) < md * md) {
-                    arr[k] = idx;
-                    if (sc.destroy_on_arrival) dead_j = d;  // hw5.cu:306
-                    if (a.snap_q && owner) {                // hw5.cu:277-285
-                        double* dq = a.snap_q + (size_t)k * 3 * n;
-                        double* dv = a.snap_v + (size_t)k * 3 * n;
-                        dq[i] = sq[buf][0][i]; dq[n + i] = sq[buf][1][i]; dq[2 * n + i] = sq[buf][2][i];
-                        dv[i] = vx; dv[n + i] = vy; dv[2 * n + i] = vz;
-                    }
+        const double md = sc.missile_dstep * idx;
+        const double md2 = md * md;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            if (k < sc.n_watch && arr[k] == -2 && (alive & (1u << k)) && dk[k] < md2) {  // hw5.cu:299
+                const int d = sc.watch[k];
+                arr[k] = idx;
+                if (sc.destroy_on_arrival) dead_j = d;  // hw5.cu:306
+                if (a.snap_q && owner) {                // hw5.cu:277-285
+                    double* dq = a.snap_q + (size_t)k * 3 * n;
+                    double* dv = a.snap_v + (size_t)k * 3 * n;
+                    dq[i] = sq[buf][0][i]; dq[n + i] = sq[buf][1][i]; dq[2 * n + i] = sq[buf][2][i];
+                    dv[i] = vx; dv[n + i] = vy; dv[2 * n + i] = vz;
                 }
             }
         }
@@ -428,31 +439,38 @@ __device__ __forceinline__ void scenario_small_body(const F64SmallArgs& a) {
     if (t == 0) {
         a.mon->min_d2 = min_d2;
         a.mon->hit_step = hit;
-        for (int k = 0; k < MAX_WATCH; ++k) a.mon->arrival_step[k] = arr[k];
+#pragma unroll
+        for (int k = 0; k < NW; ++k) a.mon->arrival_step[k] = arr[k];  // (slots beyond NW are not watched in this mode)
         *a.steps_done = done;
     }
 }
 
-template <int S, bool SELFCHECK>
+template <int S, bool SELFCHECK, bool FEW>
 __global__ __launch_bounds__(SMALL_N_MAX * S) void nbody_scenario_small_f64(F64SmallArgs a) {
-    scenario_small_body<S, SELFCHECK>(a);
+    scenario_small_body<S, SELFCHECK, FEW>(a);
 }
 
 // Up to MAX_BATCH scenarios of equally sized small systems in ONE launch: workgroup k runs scenario k from its own
 // state, with its own monitor, completely independently of the others (own LDS, no inter-workgroup traffic) — the whole
 // reference program (P1, P2 and one Problem-3 run per device, hw5.cu:564-567,587-588) is then a single kernel launch on
 // 2 + D compute units, with no host thread, stream or hardware queue per scenario.
-template <int S, bool SELFCHECK>
+template <int S, bool SELFCHECK, bool FEW>
 __global__ __launch_bounds__(SMALL_N_MAX * S) void nbody_scenario_small_f64_batched(F64SmallBatchArgs b) {
     const F64SmallArgs& a = b.item[blockIdx.x];
     if (a.n <= 0) return;  // finished slot (workgroup-uniform)
-    scenario_small_body<S, SELFCHECK>(a);
+    scenario_small_body<S, SELFCHECK, FEW>(a);
 }
 
 template <int S>
 static int launch_small_s(const F64SmallArgs& a, int threads, hipStream_t stream) {
-    if (a.eps2 > 0.0) hipLaunchKernelGGL((nbody_scenario_small_f64<S, false>), dim3(1), dim3(threads), 0, stream, a);
-    else hipLaunchKernelGGL((nbody_scenario_small_f64<S, true>), dim3(1), dim3(threads), 0, stream, a);
+    const bool few = a.scn.n_watch <= SMALL_FEW;
+    if (a.eps2 > 0.0) {
+        if (few) hipLaunchKernelGGL((nbody_scenario_small_f64<S, false, true>), dim3(1), dim3(threads), 0, stream, a);
+        else hipLaunchKernelGGL((nbody_scenario_small_f64<S, false, false>), dim3(1), dim3(threads), 0, stream, a);
+    } else {
+        if (few) hipLaunchKernelGGL((nbody_scenario_small_f64<S, true, true>), dim3(1), dim3(threads), 0, stream, a);
+        else hipLaunchKernelGGL((nbody_scenario_small_f64<S, true, false>), dim3(1), dim3(threads), 0, stream, a);
+    }
     return (int)hipGetLastError();
 }
 
@@ -470,10 +488,19 @@ int launch_f64_small_batched(const F64SmallBatchArgs& b, int n, hipStream_t stre
     if (n <= 0 || n > SMALL_N_MAX || b.count <= 0 || b.count > MAX_BATCH) return (int)hipErrorInvalidValue;
     constexpr int S = 8;
     const int threads = ((n * S + 63) / 64) * 64;
-    bool eps_positive = true;
-    for (int k = 0; k < b.count; ++k) eps_positive &= (b.item[k].n <= 0 || b.item[k].eps2 > 0.0);
-    if (eps_positive) hipLaunchKernelGGL((nbody_scenario_small_f64_batched<S, false>), dim3(b.count), dim3(threads), 0, stream, b);
-    else hipLaunchKernelGGL((nbody_scenario_small_f64_batched<S, true>), dim3(b.count), dim3(threads), 0, stream, b);
+    bool eps_positive = true, few = true;
+    for (int k = 0; k < b.count; ++k) {
+        eps_positive &= (b.item[k].n <= 0 || b.item[k].eps2 > 0.0);
+        few &= (b.item[k].n <= 0 || b.item[k].scn.n_watch <= SMALL_FEW);
+    }
+    const dim3 grid(b.count), block(threads);
+    if (eps_positive) {
+        if (few) hipLaunchKernelGGL((nbody_scenario_small_f64_batched<S, false, true>), grid, block, 0, stream, b);
+        else hipLaunchKernelGGL((nbody_scenario_small_f64_batched<S, false, false>), grid, block, 0, stream, b);
+    } else {
+        if (few) hipLaunchKernelGGL((nbody_scenario_small_f64_batched<S, true, true>), grid, block, 0, stream, b);
+        else hipLaunchKernelGGL((nbody_scenario_small_f64_batched<S, true, false>), grid, block, 0, stream, b);
+    }
     return (int)hipGetLastError();
 }
 
