@@ -802,6 +802,7 @@ int group_prepare(GraphGroup& g) {
     NB_HIP(c0, hipStreamSynchronize(stream));
 
     const int count = (int)g.slots.size();
+    const auto t_prep = std::chrono::steady_clock::now();
     // relaxed mode: the capture restricts neither this thread's nor other host threads' HIP calls on OTHER streams
     // (distinct contexts may be driven from distinct threads); nothing but the launches below touches `stream` meanwhile
     NB_HIP(c0, hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed));
@@ -844,8 +845,13 @@ int group_prepare(GraphGroup& g) {
     hipError_t e = hipStreamEndCapture(stream, &g.graph);
     if (bad != hipSuccess) return fail_hip(c0, bad, "capturing the step graph");
     if (e != hipSuccess) return fail_hip(c0, e, "hipStreamEndCapture");
+    const auto t_cap = std::chrono::steady_clock::now();
     NB_HIP(c0, hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
     for (hipEvent_t& e : g.ev) NB_HIP(c0, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (getenv("NB_SOLVE_TRACE"))
+        fprintf(stderr, "[graph] %d slots: capture %.2f ms, instantiate %.2f ms\n", count,
+                std::chrono::duration<double, std::milli>(t_cap - t_prep).count(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_cap).count());
     g.prepared = true;
     return NB_OK;
 }
