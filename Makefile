@@ -46,7 +46,9 @@ bin/io_check_asan: $(SRC)/io_check.cpp $(SRC)/nbody_io.cpp $(SRC)/nbody_io.h
 	@mkdir -p bin
 	g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=all -o $@ $(SRC)/io_check.cpp $(SRC)/nbody_io.cpp
 
-ubench: bench/ubench/valu_rate bench/ubench/force_variants bench/ubench/launch_rate
+ubench: bench/ubench/valu_rate bench/ubench/force_variants bench/ubench/launch_rate bench/debug/startup_probe
+bench/debug/startup_probe: bench/debug/startup_probe.cpp $(LIB)
+	$(HIPCC) -O2 -std=c++17 -Wno-unused-value -o $@ $< -L$(PKG) -lnbody_amd -Wl,-rpath,'$$ORIGIN/../../$(PKG)'
 bench/ubench/launch_rate: bench/ubench/launch_rate.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
 bench/ubench/force_variants: bench/ubench/force_variants.hip
@@ -55,4 +57,4 @@ bench/ubench/valu_rate: bench/ubench/valu_rate.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
 
 clean:
-	rm -f $(LIB) bin/hw5 bin/nbody_bench bin/nbconv hw5 bench/ubench/valu_rate bench/ubench/force_variants bench/ubench/launch_rate
+	rm -f $(LIB) bin/hw5 bin/nbody_bench bin/nbconv hw5 bench/ubench/valu_rate bench/ubench/force_variants bench/ubench/launch_rate bench/debug/startup_probe

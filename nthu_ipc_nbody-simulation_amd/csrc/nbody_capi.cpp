@@ -1562,7 +1562,7 @@ int solve_impl(int n, int planet, int asteroid, const double* qx, const double* 
     const size_t D = dev_idx.size();
     if (D > NB_MAX_WATCH) return NB_ERR_INVALID;
     const bool trace = getenv("NB_SOLVE_TRACE") != nullptr;  // stderr timeline of the driver's phases
-    static std::chrono::steady_clock::time_point t_start;
+    static thread_local std::chrono::steady_clock::time_point t_start;
     t_start = std::chrono::steady_clock::now();
     auto stamp_fn = +[](const char* what) {
         fprintf(stderr, "[nb_solve] %8.1f ms  %s\n",
@@ -1591,12 +1591,14 @@ int solve_impl(int n, int planet, int asteroid, const double* qx, const double* 
         return s;
     };
 
-    // Every scenario of the program starts at step 0 and they all advance together — P1 (devices massless,
-    // nbody.cc:109-122), P2 (nbody.cc:124-138) and one Problem-3 run per gravity device (hw5.cu:289-309 applied from the
-    // first step: until its missile arrives a device's run IS the P2 trajectory, so nothing waits for P2's snapshots,
-    // hw5.cu:265-287,482-489).  On one GPU that is ONE launch stream: a single persistent launch with a workgroup per
-    // scenario for n <= 128, one batched launch per step otherwise; the critical path of the whole program is one
-    // 200 000-step scenario.  Several GPUs each take a share of the scenarios (the reference's task parallelism).
+    // The scenarios of the program: P1 (devices massless, nbody.cc:109-122), P2 (nbody.cc:124-138) and one Problem-3 run per
+    // gravity device (hw5.cu:289-309).  Two engines, chosen by system size below:
+    //  * persistent (n <= 128): every scenario starts at step 0 in ONE launch with a workgroup per scenario — until its
+    //    missile arrives a device's run IS the P2 trajectory, so nothing waits for P2's snapshots (hw5.cu:265-287,482-489)
+    //    and the critical path of the whole program is one 200 000-step scenario;
+    //  * per-step (n > 128): replayed graphs of launches, a stream per scenario, Problem-3 runs started from P2's arrival
+    //    snapshots in arrival order.
+    // Several GPUs each take a share of the scenarios (the reference's task parallelism, hw5.cu:564-567,587-588).
     std::vector<SolveSlot> slots(2 + D);
     slots[0].scn = base_scn(NB_SCN_MIN_DIST);
     slots[0].zero_devices = true;
