@@ -54,6 +54,8 @@ int main(int argc, char** argv) {
     // The answer is on disk (write_output closes the file) and nb_solve has released everything it created: leave without
     // running the HIP runtime's exit handlers — they take 60-90 ms of a 0.5-1.6 s program (profiles/r02_startup_probe.txt)
     // and free only what the kernel driver reclaims at process exit anyway.
+    // (NB_HW5_CLEAN_EXIT=1 returns normally instead: profilers write their files from exit handlers.)
+    if (getenv("NB_HW5_CLEAN_EXIT")) return 0;
     fflush(nullptr);
     std::_Exit(0);
 }

@@ -646,8 +646,18 @@ F64SmallArgs small_args(nb_context* c, const F64Scenario& sc, bool want_snap, co
 }
 
 constexpr int SMALL_CHUNK = 50000;  // K3: steps per launch, so that the host can stop relaunching after a hit
-constexpr int GRAPH_CHUNK = 1000;      // K2, graph-driven: steps per replay (even: the ping-pong buffers are back in
-                                       // place after a chunk)
+constexpr int GRAPH_CHUNK_DEFAULT = 1000;  // K2, graph-driven: steps per replay (even: the ping-pong buffers are back
+                                           // in place after a chunk)
+// NB_GRAPH_CHUNK=<even, 2..4000> overrides (rocprofv3 1.1's kernel tracing crashes inside hipGraphLaunch on a 1000-node
+// graph; 100 nodes profile fine).  Read once per process.
+int graph_chunk() {
+    static const int chunk = [] {
+        const char* e = getenv("NB_GRAPH_CHUNK");
+        const int v = e ? atoi(e) : 0;
+        return (v >= 2 && v <= 4000 && v % 2 == 0) ? v : GRAPH_CHUNK_DEFAULT;
+    }();
+    return chunk;
+}
 constexpr int GRAPH_MIN_STEPS = 4000;  // shorter ranges are launched eagerly: capture + instantiate would cost more
 
 int run_batched_impl(nb_context** ctxs, const nb_scenario* scns, nb_scenario_result* results, int count);
@@ -782,7 +792,7 @@ int upload_ctl(nb_context* err, GraphSlot& s, hipStream_t stream) {
     return NB_OK;
 }
 
-// monitors, control words, tables, and the captured graph of GRAPH_CHUNK batched launches + the advance node
+// monitors, control words, tables, and the captured graph of graph_chunk() batched launches + the advance node
 int group_prepare(GraphGroup& g) {
     nb_context* c0 = g.lead;
     if (int rc = bind(c0)) return rc;
@@ -807,7 +817,8 @@ int group_prepare(GraphGroup& g) {
     // (distinct contexts may be driven from distinct threads); nothing but the launches below touches `stream` meanwhile
     NB_HIP(c0, hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed));
     hipError_t bad = hipSuccess;
-    for (int t = 0; t < GRAPH_CHUNK && bad == hipSuccess; ++t) {
+    const int chunk = graph_chunk();
+    for (int t = 0; t < chunk && bad == hipSuccess; ++t) {
         F64BatchArgs args{};
         args.count = count;
         for (int b = 0; b < count; ++b) {
@@ -840,7 +851,7 @@ int group_prepare(GraphGroup& g) {
         F64CtlBatch cb{};
         cb.count = count;
         for (int b = 0; b < count; ++b) cb.ctl[b] = g.slots[(size_t)b].c->ctl;
-        bad = (hipError_t)launch_ctl_advance(cb, GRAPH_CHUNK, stream);
+        bad = (hipError_t)launch_ctl_advance(cb, chunk, stream);
     }
     hipError_t e = hipStreamEndCapture(stream, &g.graph);
     if (bad != hipSuccess) return fail_hip(c0, bad, "capturing the step graph");
@@ -856,7 +867,7 @@ int group_prepare(GraphGroup& g) {
     return NB_OK;
 }
 
-// one replay = GRAPH_CHUNK steps of every active slot, then the monitors travel to their pinned host copies
+// one replay = graph_chunk() steps of every active slot, then the monitors travel to their pinned host copies
 int group_launch(GraphGroup& g) {
     nb_context* c0 = g.lead;
     if (int rc = bind(c0)) return rc;
@@ -886,7 +897,7 @@ int group_collect(GraphGroup& g) {
         --s.inflight;
         if (s.done_at >= 0) continue;  // ended at an earlier replay: the launches of this one returned at once
         const int before = s.base, last = s.scn->last_step;
-        s.base += GRAPH_CHUNK;  // what nbody_ctl_advance did
+        s.base += graph_chunk();  // what nbody_ctl_advance did
         const int hit = s.c->mon_host->hit_step;
         if (s.scn->kind != NB_SCN_MIN_DIST && hit != -2) {
             s.done_at = hit;  // the launch after state `hit` saw it and every later one returned at once
@@ -1624,7 +1635,7 @@ int solve_impl(int n, int planet, int asteroid, const double* qx, const double* 
         // Per-step engine: one stream + replayed graph each for P1, for P2, and for the Problem-3 runs (at most two
         // streams of those per GPU: four hardware queues).  A Problem-3 run is dormant until P2's monitor reports the
         // missile's arrival at its device; it then starts from the snapshot P2 took at that step (hw5.cu:265-287,
-        // 482-489) at most one replay (GRAPH_CHUNK steps) behind, so the whole program ends one replay after P1 does.
+        // 482-489) at most one replay (1000 steps) behind, so the whole program ends one replay after P1 does.
         // Independent streams keep the scenarios out of phase — one's latency-bound launch prologue overlaps another's
         // pair loop — which a lock-step batch of large systems cannot (profiles/r02_scenario_batch_timing.txt).
         CtxList list;

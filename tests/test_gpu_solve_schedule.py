@@ -227,3 +227,11 @@ def test_graph_replay_stops_at_the_hit(nb, oracle):
     ref = s.copy()
     oracle.run_steps(ref, 1, 4321, omp=True)
     assert np.all(np.abs(qa - ref.q) <= 1e-9 * np.abs(ref.q).max())
+
+
+def test_cli_with_a_shorter_graph_chunk(nb, tmp_path):
+    """NB_GRAPH_CHUNK=100: ten times as many, shorter replays (what profiling under rocprofv3 needs) — same three lines."""
+    out = str(tmp_path / "out")
+    env = dict(os.environ, NB_GRAPH_CHUNK="100")
+    subprocess.run([os.path.join(ROOT, "bin", "hw5"), case_path("b200", "in"), out], check=True, timeout=300, env=env)
+    assert open(out).read() == read_golden("b200")[4]
