@@ -159,3 +159,47 @@ def test_ring_pass_on_one_gpu_matches_single(nb, tmp_path, world, acc64):
         assert np.abs(a["pos"] - b["pos"]).max() < 5e-7 and np.abs(a["vel"] - b["vel"]).max() < 1e-5
     p0, _ = nb.synthetic.body4_f32(N)
     assert np.abs(b["pos"][:, :3] - p0[:, :3]).max() > 1e-6 and np.array_equal(b["pos"][:, 3], p0[:, 3])
+
+
+@pytest.mark.parametrize("acc64", [False, True])
+def test_sharded_checkpoint_resume_is_bitwise_on_gpu(nb, tmp_path, acc64):
+    """ShardedSystem.save_checkpoint / load_checkpoint_shard with the real kernels (one rank; the two-rank form runs on CPU
+    in tests/test_distributed_gloo.py): 2 steps + checkpoint + a NEW system from the file + 2 steps = 4 uninterrupted steps,
+    bit for bit, in NB_F32 and with fp64 masters."""
+    from nbody_amd.distributed import ShardedSystem
+    syn, c = nb.synthetic, nb.capi
+    dev = torch.device("cuda", 0)
+    n = 8192 + 256
+
+    def fresh():
+        if acc64:
+            q, v, m = syn.bodies(n)
+            pos = np.ascontiguousarray(np.concatenate([q.T, (syn.G * m)[:, None]], axis=1))
+            vel = np.ascontiguousarray(np.concatenate([v.T, np.zeros((n, 1))], axis=1))
+        else:
+            pos, vel = syn.body4_f32(n)
+        return ShardedSystem(n, torch.from_numpy(pos), torch.from_numpy(vel), syn.EPS, 1e-2, dev, acc64=acc64)
+
+    def state(s):
+        torch.cuda.synchronize()
+        return (s.pos64 if acc64 else s.positions).cpu().numpy().copy(), (s.vel64 if acc64 else s.vel).cpu().numpy().copy()
+
+    ref = fresh()
+    for _ in range(4):
+        ref.step()
+    a = fresh()
+    for _ in range(2):
+        a.step()
+    path = str(tmp_path / "ck.nbst")
+    a.save_checkpoint(path, 2, syn.G)
+    assert c.state_file_info(path) == (n, c.NB_F32_ACC64 if acc64 else c.NB_F32, 2)
+    hdr, pos, vel = ShardedSystem.load_checkpoint_shard(path, 0, 1)
+    assert (hdr["dt"], hdr["eps"]) == (1e-2, syn.EPS)
+    if not acc64:
+        pos, vel = pos.astype(np.float32), vel.astype(np.float32)
+    b = ShardedSystem(n, torch.from_numpy(pos), torch.from_numpy(vel), hdr["eps"], hdr["dt"], dev, acc64=acc64)
+    for _ in range(2):
+        b.step()
+    (p0, v0), (p1, v1) = state(ref), state(b)
+    assert np.array_equal(p0[:, :3], p1[:, :3]) and np.array_equal(v0[:, :3], v1[:, :3])
+    assert np.array_equal(ref.positions.cpu().numpy(), b.positions.cpu().numpy())  # incl. the G*m column of the fp32 records
