@@ -129,10 +129,12 @@ int nb_step_timed(nb_context* ctx, int first_step, int count, float* ms_per_step
  * After a scenario that ends in a hit the context's (q,v) are unspecified — the reference discards that state too
  * (nbody.cc:136 breaks out of the loop); reload with nb_set_state / nb_restore_snapshot / nb_load_state. */
 int nb_run_scenario(nb_context* ctx, const nb_scenario* scn, nb_scenario_result* res);
-/* `count` (<= 8) scenarios of equally sized NB_F64 systems on ONE GPU in lock step: one launch per step serves all of
- * them, each with its own context (state), step range and monitors — hw5.cu's one-thread-per-device Problem-3 loop
- * (hw5.cu:587-588) without one launch stream per device.  MIN_DIST and MISSILE scenarios (and FIRST_HIT without
- * watched devices); results[k] as nb_run_scenario would give for (ctxs[k], scns[k]). */
+/* `count` (<= 8) scenarios of equally sized NB_F64 systems on ONE GPU, one launch stream for all of them, each with its
+ * own context (state), step range and monitors — hw5.cu's one-thread-per-device Problem-3 loop (hw5.cu:587-588) without a
+ * launch stream per device.  Persistent engine (n <= 128): ONE launch, workgroup k runs scenario k to its end.  Per-step
+ * engine: one launch per step serves all of them in lock step (blockIdx.y), replayed from a hipGraph for long runs.  All
+ * scenario kinds (FIRST_HIT with snapshots included); every scns[k].engine must agree; results[k] as nb_run_scenario
+ * would give for (ctxs[k], scns[k]). */
 int nb_run_scenarios_batched(nb_context** ctxs, const nb_scenario* scns, nb_scenario_result* results, int count);
 /* load the (q,v) snapshot that the last FIRST_HIT scenario on `src` took at watched device `watch_slot`'s
  * missile arrival into `dst` (same n, precision F64, same GPU or not); hw5.cu:482-484 */
@@ -169,11 +171,10 @@ int nb_write_state_file(const char* path, const nb_state_header* hdr, const doub
                         const uint8_t* is_device /* may be NULL */);
 
 /* ---- whole reference program: P1, P2, P3 (nbody.cc:106-146 ; hw5.cu:532-606) ----
- * All 2 + D scenarios (P1, P2, one Problem-3 run per gravity device) start at step 0 and advance together in one launch
- * stream per GPU (a workgroup per scenario in one persistent launch for n <= 128; one batched launch per step
- * otherwise), at most 8 per stream; scenarios beyond that are queued cheapest-first (ascending missile-arrival step,
- * hw5.cu:574-585) and dropped once they cannot beat a feasible device (hw5.cu:490-493).  `devices` spreads the
- * scenarios over several GPUs (the reference's task parallelism, hw5.cu:564-567,587-588).
+ * n <= 128: all 2 + D scenarios (P1, P2, one Problem-3 run per gravity device) start at step 0 in ONE persistent launch
+ * per GPU, a workgroup per scenario, at most 8 per launch; scenarios beyond that are queued cheapest-first (ascending
+ * missile-arrival step, hw5.cu:574-585) and dropped once they cannot beat a feasible device (hw5.cu:490-493).  `devices`
+ * spreads the scenarios over several GPUs (the reference's task parallelism, hw5.cu:564-567,587-588).
  * n > 128: the per-step engine instead — P1, P2 and the Problem-3 runs each replay their own graph of launches on their
  * own stream (one shared graph per GPU up to 256 bodies); a Problem-3 run starts from the snapshot P2 takes at its
  * missile's arrival (hw5.cu:265-287,482-489) as soon as P2's monitor shows it, one per GPU at a time in arrival order.
