@@ -46,6 +46,12 @@ CASES = {
     # (step 4) is what pulls the asteroid in: the cheapest-first queue must hand over after the first run fails
     "first_arrival_useless_second_saves": [PLANET, ((4e8, 6e7, 0), (-2e3, 0, 0), 1e12, 0), ((5e7, 5e7, 0), (0, 0, 0), 1e10, 1),
                                            ((1e8, -2e8, 0), (0, 0, 0), 3e24, 1)],
+    # six devices (more than the four whose monitor state the kernels keep in registers; 2 + 6 scenarios = one full batch):
+    # five light bystanders, one of which is reached at the same step (4) as the heavy culprit
+    "six_devices_with_a_tie": [PLANET, ((4e8, 6e7, 0), (-2e3, 0, 0), 1e12, 0), ((5e7, 5e7, 0), (0, 0, 0), 1e10, 1),
+                               ((-2e8, 1e8, 0), (0, 0, 0), 1e11, 1), ((3e8, -3e8, 1e8), (0, 0, 0), 1e9, 1),
+                               ((-4e8, -1e8, 0), (0, 0, 0), 1e10, 1), ((1e8, -2e8, 0), (0, 0, 0), 3e24, 1),
+                               ((6e8, 6e8, 0), (0, 0, 0), 1e10, 1)],
     # a heavy device that pulls the asteroid into the planet: destroying it in time avoids the hit
     "device_causes_hit": [PLANET, ((4e8, 6e7, 0), (-2e3, 0, 0), 1e12, 0), ((1e8, -2e8, 0), (0, 0, 0), 3e24, 1),
                           ((-9e8, 9e8, 0), (0, 0, 0), 1e10, 1)],
@@ -80,7 +86,7 @@ def test_solve_matches_oracle(nb, oracle, name, engine, tmp_path, monkeypatch):
 
 def test_expected_shapes_of_the_edge_cases(oracle):
     """Make sure the hand-made systems really exercise what their names say (guards against a vacuous test)."""
-    res = {k: oracle.problem23(_system(oracle, v)) for k, v in CASES.items()}
+    res = {k: oracle.problem23(_system(oracle, v), max_detail=16) for k, v in CASES.items()}
     assert res["no_hit"][0].hit_time_step == -2
     assert res["hit_at_step_0"][0].hit_time_step == 0
     assert res["hit_no_devices"][0].hit_time_step > 0 and res["hit_no_devices"][0].gravity_device_id == -1
@@ -89,6 +95,9 @@ def test_expected_shapes_of_the_edge_cases(oracle):
     r, d = res["device_causes_hit"]
     assert r.hit_time_step > 0 and d[0]["feasible"] and r.gravity_device_id == 2 and r.missile_cost > 0
     assert d[1]["arrival_step"] > d[0]["arrival_step"] and not d[1]["feasible"]  # the far, light device cannot help
+    r, d = res["six_devices_with_a_tie"]
+    assert len(d) == 6 and [x["arrival_step"] for x in d] == [2, 4, 8, 7, 4, 15] and [x["feasible"] for x in d] == \
+        [False, False, False, False, True, False] and r.gravity_device_id == 6
     r, d = res["first_arrival_useless_second_saves"]
     assert d[0]["arrival_step"] < d[1]["arrival_step"] < r.hit_time_step and not d[0]["feasible"] and d[1]["feasible"]
     assert r.gravity_device_id == 3 and r.missile_cost == d[1]["cost"]
