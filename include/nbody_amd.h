@@ -91,7 +91,7 @@ typedef struct nb_scenario {
 typedef struct nb_scenario_result {
     double min_dist2;                     /* MIN_DIST: min squared planet–asteroid distance (sqrt on the host) */
     int32_t hit_step;                     /* FIRST_HIT / MISSILE: first hit step, -2 = none */
-    int32_t steps_done;                   /* index of the last state computed */
+    int32_t steps_done;                   /* index of the last state computed: last_step, or the hit step when a hit ended it */
     int32_t arrival_step[NB_MAX_WATCH];   /* per watched device, -2 = never (before the hit) */
     double missile_cost[NB_MAX_WATCH];    /* 1e5 + 1e3*(arrival+1)*dt   hw5.cu:305 ; nbody.cc:19 */
 } nb_scenario_result;

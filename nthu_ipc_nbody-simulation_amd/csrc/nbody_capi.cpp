@@ -728,7 +728,9 @@ int run_scenario_impl(nb_context* c, const nb_scenario* s, nb_scenario_result* r
     }
     NB_HIP(c, hipMemcpyAsync(mh, c->mon, sizeof(F64Monitor), hipMemcpyDeviceToHost, c->stream));
     NB_HIP(c, hipStreamSynchronize(c->stream));
-    fill_result(c, s, sc, stopped ? step : s->last_step, res);
+    // a hit ends the scenario at the state it was seen in, whichever poll noticed it (the launches after it returned at once)
+    (void)stopped;
+    fill_result(c, s, sc, (can_stop && mh->hit_step != -2) ? mh->hit_step : s->last_step, res);
     return NB_OK;
 }
 
@@ -1176,7 +1178,11 @@ int run_batched_impl(nb_context** ctxs, const nb_scenario* scns, nb_scenario_res
     for (int b = 0; b < count; ++b)
         NB_HIP(c0, hipMemcpyAsync(ctxs[b]->mon_host, ctxs[b]->mon, sizeof(F64Monitor), hipMemcpyDeviceToHost, stream));
     NB_HIP(c0, hipStreamSynchronize(stream));
-    for (int b = 0; b < count; ++b) fill_result(ctxs[b], &scns[b], sc[b], done_at[b], &results[b]);
+    for (int b = 0; b < count; ++b) {
+        const int hit = ctxs[b]->mon_host->hit_step;  // as above: a hit ends the scenario at the state it was seen in
+        if (scns[b].kind != NB_SCN_MIN_DIST && hit != -2) done_at[b] = hit;
+        fill_result(ctxs[b], &scns[b], sc[b], done_at[b], &results[b]);
+    }
     return NB_OK;
 }
 

@@ -174,3 +174,42 @@ def test_arrival_on_the_final_state_takes_a_complete_snapshot(nb, oracle, engine
         c3.restore_snapshot_from(ctx, 0)
         q, v = c3.get_state()
     assert np.all(np.abs(q - ref.q) <= 1e-12 * np.abs(ref.q).max()) and np.all(np.abs(v - ref.v) <= 1e-12 * np.abs(ref.v).max())
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_engines_agree_on_perturbed_systems(nb, oracle, seed):
+    """Differential test of the three scenario engines on randomly perturbed copies of the hand-made systems (positions,
+    velocities and masses within +-8 %, a random number of far-away filler bodies): eager per-step launches and their
+    hipGraph replay must agree bit for bit; the persistent engine must report the same hit / arrival steps (its summation
+    split differs, so its states agree to rounding only); and everything must match the oracle's bookkeeping."""
+    c = nb.capi
+    rng = np.random.default_rng(1000 + seed)
+    name = list(CASES)[seed % len(CASES)]
+    bodies = []
+    for q, v, m, d in CASES[name]:
+        f = lambda x: tuple(np.asarray(x, dtype=float) * (1 + 0.08 * (2 * rng.random(3) - 1)))  # noqa: E731
+        bodies.append((f(q), f(v), m * (1 + 0.08 * (2 * rng.random() - 1)), d))
+    for _ in range(int(rng.integers(0, 40))):  # fillers: light, far, slow
+        bodies.append((tuple(5e9 * (2 * rng.random(3) - 1) + 2e10), tuple(10 * rng.random(3)), 1e8 * rng.random(), 0))
+    s = _system(oracle, bodies)
+    devs = [int(i) for i in np.flatnonzero(s.is_device)]
+    last = 9000 + int(rng.integers(0, 7))
+    p = oracle.make_params(n_steps=last)
+    ref, details = oracle.problem23(s, params=p, max_detail=16)
+    runs = {}
+    for label, engine, flags in (("eager", 1, c.NB_SCN_EAGER), ("graph", 1, 0), ("persistent", 2, 0)):
+        with c.Context(s.n) as x:
+            x.set_state(s.q, s.v, s.m, s.is_device)
+            r = x.run_scenario(c.NB_SCN_FIRST_HIT, s.planet, s.asteroid, watch=devs, last_step=last, engine=engine, flags=flags)
+            runs[label] = (r, x.get_state())
+    (re_, se), (rg, sg), (rp, sp) = runs["eager"], runs["graph"], runs["persistent"]
+    assert re_ == rg, (name, re_, rg)
+    assert (rp["hit_step"], rp["arrival_step"]) == (re_["hit_step"], re_["arrival_step"]), (name, rp, re_)
+    assert re_["hit_step"] == ref.hit_time_step
+    # arrival steps are recorded until the hit ends the scenario (the oracle's per-device details follow each device's own run)
+    for k, d in enumerate(details):
+        if d["arrival_step"] != -2 and (ref.hit_time_step == -2 or d["arrival_step"] < ref.hit_time_step):
+            assert re_["arrival_step"][k] == d["arrival_step"], (name, k, re_, d)
+    if re_["hit_step"] == -2:  # states are specified only when no hit ended the run
+        assert np.array_equal(se[0], sg[0]) and np.array_equal(se[1], sg[1])
+        assert np.all(np.abs(sp[0] - se[0]) <= 1e-9 * np.abs(se[0]).max())
