@@ -17,8 +17,9 @@ HDR  := $(SRC)/nbody_kernels.h include/nbody_amd.h
 all: lib hw5 nbody_bench nbconv
 
 lib: $(LIB)
-$(LIB): $(KSRC) $(SRC)/nbody_capi.cpp $(SRC)/nbody_sharded.cpp $(HDR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(KSRC) -x hip $(SRC)/nbody_capi.cpp $(SRC)/nbody_sharded.cpp -lpthread -ldl
+HOSTSRC := $(SRC)/nbody_capi.cpp $(SRC)/nbody_scenario.cpp $(SRC)/nbody_solve.cpp $(SRC)/nbody_statefile.cpp $(SRC)/nbody_sharded.cpp
+$(LIB): $(KSRC) $(HOSTSRC) $(HDR) $(SRC)/nbody_internal.h
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(KSRC) -x hip $(HOSTSRC) -lpthread -ldl
 
 hw5: bin/hw5
 bin/hw5: $(SRC)/main_hw5.cpp $(SRC)/nbody_io.cpp $(SRC)/nbody_io_state.cpp $(SRC)/nbody_io.h $(LIB)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Two (or more) independent scenario streams at once: per-step cost of each when they share the chip, and when each is
-confined to half of the compute units (NB_CU_MASK, an experiment knob of nb_create).  Feeds nb_solve's stream layout for
+confined to half of the compute units (nb_config.cu_mask).  Feeds nb_solve's stream layout for
 n > 256.   python bench/scenario_concurrency.py [b1024 ...]"""
 import os
 import sys
@@ -19,15 +19,11 @@ STEPS = 40000
 def run(case, masks):
     s = O.read_input(os.path.join(ROOT, "tests/golden/testcases", case + ".in"))
     ctxs = []
+    how = {None: c.NB_CU_ALL, "lo": c.NB_CU_LOW, "hi": c.NB_CU_HIGH, "even": c.NB_CU_EVEN, "odd": c.NB_CU_ODD}
     for m in masks:
-        if m:
-            os.environ["NB_CU_MASK"] = m
-        else:
-            os.environ.pop("NB_CU_MASK", None)
-        x = c.Context(s.n)
+        x = c.Context(s.n, cu_mask=how[m])
         x.set_state(s.q, s.v, s.m, s.is_device)
         ctxs.append(x)
-    os.environ.pop("NB_CU_MASK", None)
     out = [0.0] * len(ctxs)
 
     def work(k):

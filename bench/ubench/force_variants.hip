@@ -56,9 +56,57 @@ struct Acc {
     }
 };
 
-template <int P>
+// ORDER (round 3, the s_nop question): how one source meets the lane's P target pairs
+//   0  the product loop of rounds 1-2: pair after pair; the compiler leaves `sc = gm*rinv ; sc *= rinv2` adjacent and
+//      pads the packed-result forwarding hazard with one s_nop per (source, pair)
+//   1  same pair-after-pair order, mul chain rinv2 = rinv*rinv ; r3 = rinv2*rinv ; sc = r3*gm (SGPR operand last)
+//   2  pairs in groups of G = 2: every stage of the chain for both pairs before the next stage (dependent packed ops are
+//      never adjacent; 16 more temporaries live)
+//   3  G = 4: all P pairs stage by stage (40 temporaries)
+template <int P, int ORDER = 0>
 __device__ __forceinline__ void interact(const float4 s, const v2f* xi, const v2f* yi, const v2f* zi, v2f eps2, Acc<P>& A) {
     const v2f qx = splat(s.x), qy = splat(s.y), qz = splat(s.z), gm = splat(s.w);
+    if constexpr (ORDER == 1) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            v2f dx = qx - xi[p], dy = qy - yi[p], dz = qz - zi[p];
+            v2f r2 = pk_fma(dx, dx, eps2);
+            r2 = pk_fma(dy, dy, r2);
+            r2 = pk_fma(dz, dz, r2);
+            v2f rinv = (v2f){__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
+            v2f r3 = rinv * rinv;
+            r3 = r3 * rinv;
+            v2f sc = r3 * gm;
+            A.ax[p] = pk_fma(dx, sc, A.ax[p]);
+            A.ay[p] = pk_fma(dy, sc, A.ay[p]);
+            A.az[p] = pk_fma(dz, sc, A.az[p]);
+        }
+        return;
+    }
+    if constexpr (ORDER >= 2) {
+        constexpr int G = ORDER == 2 ? 2 : 4;
+        static_assert(P % G == 0, "");
+#pragma unroll
+        for (int p0 = 0; p0 < P; p0 += G) {
+            v2f dx[G], dy[G], dz[G], r2[G], ri[G], sc[G];
+#define STG(stmt) _Pragma("unroll") for (int g = 0; g < G; ++g) { const int p = p0 + g; (void)p; stmt; }
+            STG(dx[g] = qx - xi[p])
+            STG(dy[g] = qy - yi[p])
+            STG(dz[g] = qz - zi[p])
+            STG(r2[g] = pk_fma(dx[g], dx[g], eps2))
+            STG(r2[g] = pk_fma(dy[g], dy[g], r2[g]))
+            STG(r2[g] = pk_fma(dz[g], dz[g], r2[g]))
+            STG(ri[g] = ((v2f){__builtin_amdgcn_rsqf(r2[g].x), __builtin_amdgcn_rsqf(r2[g].y)}))
+            STG(sc[g] = gm * ri[g])
+            STG(ri[g] = ri[g] * ri[g])
+            STG(sc[g] = sc[g] * ri[g])
+            STG(A.ax[p] = pk_fma(dx[g], sc[g], A.ax[p]))
+            STG(A.ay[p] = pk_fma(dy[g], sc[g], A.ay[p]))
+            STG(A.az[p] = pk_fma(dz[g], sc[g], A.az[p]))
+#undef STG
+        }
+        return;
+    }
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         v2f dx = qx - xi[p], dy = qy - yi[p], dz = qz - zi[p];
@@ -97,7 +145,7 @@ __device__ __forceinline__ void interact_staged(const float4* s, const v2f* xi, 
 #undef ST
 }
 
-template <int P, int VAR, int U, int MINW, int WGS = 256, bool SYNC = false, int STAG = 0, int PF = 0>
+template <int P, int VAR, int U, int MINW, int WGS = 256, bool SYNC = false, int STAG = 0, int PF = 0, int ORDER = 0>
 __global__ __launch_bounds__(WGS, MINW) void force(const float4* __restrict__ src_all, long n_src_all, long n_tgt,
                                                   float4* __restrict__ acc_all, float eps2s) {
     const long n_src = n_src_all / gridDim.y;
@@ -157,7 +205,7 @@ __global__ __launch_bounds__(WGS, MINW) void force(const float4* __restrict__ sr
                 asm volatile("global_load_dword %0, %1, off" : "=v"(junk) : "v"(src + jp) : "memory");
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u) interact<P>(cur[u], xi, yi, zi, eps2, A);
+            for (int u = 0; u < U; ++u) interact<P, ORDER>(cur[u], xi, yi, zi, eps2, A);
 #pragma unroll
             for (int u = 0; u < U; ++u) cur[u] = nxt[u];
             if (((j + U) & (TILE - 1)) == 0) {
@@ -204,10 +252,10 @@ __global__ __launch_bounds__(WGS, MINW) void force(const float4* __restrict__ sr
 
 static std::vector<float4> ref_acc;
 
-template <int P, int VAR, int U, int MINW, int WGS = 256, bool SYNC = false, int STAG = 0, int PF = 0>
+template <int P, int VAR, int U, int MINW, int WGS = 256, bool SYNC = false, int STAG = 0, int PF = 0, int ORDER = 0>
 static void run(const char* name, const float4* d_src, long n_src, long n_tgt, float4* d_acc, int js = 1) {
     const long blocks = (n_tgt + WGS * 2 * P - 1) / (WGS * 2 * P);
-    auto launch = [&] { hipLaunchKernelGGL((force<P, VAR, U, MINW, WGS, SYNC, STAG, PF>), dim3(blocks, js), dim3(WGS), 0, 0, d_src, n_src, n_tgt, d_acc, 1e-6f); };
+    auto launch = [&] { hipLaunchKernelGGL((force<P, VAR, U, MINW, WGS, SYNC, STAG, PF, ORDER>), dim3(blocks, js), dim3(WGS), 0, 0, d_src, n_src, n_tgt, d_acc, 1e-6f); };
     launch();
     CK(hipDeviceSynchronize());
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -244,14 +292,17 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&d_src, n_tgt * sizeof(float4))); CK(hipMalloc(&d_acc, 16 * n_tgt * sizeof(float4)));
     CK(hipMemcpy(d_src, h.data(), n_tgt * sizeof(float4), hipMemcpyHostToDevice));
     printf("n_tgt=%ld n_src=%ld\n", n_tgt, n_src);
-    run<4, V_SMEM, 8, 2, 512, true>("SMEM P=4 U=8 wg512 sync", d_src, n_src, n_tgt, d_acc);
-    run<4, V_SMEM, 8, 2, 512, true, 0, 4096>("SMEM P=4 U=8 wg512 sync pf4K", d_src, n_src, n_tgt, d_acc);
-    run<4, V_SMEM, 8, 2, 512, true, 0, 16384>("SMEM P=4 U=8 wg512 sync pf16K", d_src, n_src, n_tgt, d_acc);
-    run<4, V_SMEM, 8, 2, 512, true, 0, 65536>("SMEM P=4 U=8 wg512 sync pf64K", d_src, n_src, n_tgt, d_acc);
-    run<4, V_SMEM, 8, 2, 512, true, 0, 262144>("SMEM P=4 U=8 wg512 sync pf256K", d_src, n_src, n_tgt, d_acc);
-    run<4, V_SMEM, 8, 2, 512, true>("SMEM P=4 U=8 wg512 sync (again)", d_src, n_src, n_tgt, d_acc);
-    run<4, V_SMEM, 8, 2, 512, true, 0, 0>("SMEM P=4 U=8 wg512 sync js16", d_src, n_src, n_tgt, d_acc, 16);
-    run<2, V_SMEM, 8, 4, 1024, true, 0, 16384>("SMEM P=2 U=8 wg1024 sync pf16K", d_src, n_src, n_tgt, d_acc);
-    run<2, V_SMEM, 8, 4, 1024, true>("SMEM P=2 U=8 wg1024 sync", d_src, n_src, n_tgt, d_acc);
+    // round 3: the order in which a source meets the P pairs (s_nop / forwarding-hazard question), product shape
+    // (512-thread workgroups, P = 4, U = 8, barrier per tile), whole range and 16 slices, each variant twice (A/B/A/B)
+    for (int rep = 0; rep < 2; ++rep) {
+        run<4, V_SMEM, 8, 2, 512, true, 0, 0, 0>("SMEM P=4 U=8 wg512 order0 (product)", d_src, n_src, n_tgt, d_acc);
+        run<4, V_SMEM, 8, 2, 512, true, 0, 0, 1>("SMEM P=4 U=8 wg512 order1 gm-last", d_src, n_src, n_tgt, d_acc);
+        run<4, V_SMEM, 8, 2, 512, true, 0, 0, 2>("SMEM P=4 U=8 wg512 order2 pairs-of-2", d_src, n_src, n_tgt, d_acc);
+        run<4, V_SMEM, 8, 2, 512, true, 0, 0, 3>("SMEM P=4 U=8 wg512 order3 staged-4", d_src, n_src, n_tgt, d_acc);
+        run<4, V_SMEM, 8, 2, 512, true, 0, 0, 0>("SMEM P=4 U=8 wg512 order0 js16", d_src, n_src, n_tgt, d_acc, 16);
+        run<4, V_SMEM, 8, 2, 512, true, 0, 0, 1>("SMEM P=4 U=8 wg512 order1 js16", d_src, n_src, n_tgt, d_acc, 16);
+        run<4, V_SMEM, 8, 2, 512, true, 0, 0, 2>("SMEM P=4 U=8 wg512 order2 js16", d_src, n_src, n_tgt, d_acc, 16);
+        run<4, V_SMEM, 8, 2, 512, true, 0, 0, 3>("SMEM P=4 U=8 wg512 order3 js16", d_src, n_src, n_tgt, d_acc, 16);
+    }
     return 0;
 }

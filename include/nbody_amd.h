@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NB_ABI_VERSION 2
+#define NB_ABI_VERSION 3
 
 typedef enum nb_status {
     NB_OK = 0,
@@ -51,10 +51,15 @@ typedef struct nb_config {
     int32_t precision; /* nb_precision */
     int32_t device;    /* HIP device ordinal */
     int32_t f64_large_min; /* NB_F64: from this many bodies on, nb_step/nb_accel use the large-n kernel; 0 = default (32768) */
+    int32_t f64_split;     /* NB_F64: lanes of a wave that share one target in the step kernel; 0 = auto, else a power of two <= 64 */
+    int32_t cu_mask;       /* nb_cu_mask: confine the context's stream to half of the compute units (measurements of
+                              concurrent scenario streams, bench/scenario_concurrency.py); 0 = all CUs */
     double G;   /* 6.674e-11 */
     double eps; /* 1e-3  (Plummer softening; r2 + eps*eps) */
     double dt;  /* 60 */
 } nb_config;
+
+typedef enum nb_cu_mask { NB_CU_ALL = 0, NB_CU_LOW = 1, NB_CU_HIGH = 2, NB_CU_EVEN = 3, NB_CU_ODD = 4 } nb_cu_mask;
 
 /* scenario drivers — the loops main() runs around run_step */
 typedef enum nb_scenario_kind {
@@ -80,7 +85,7 @@ typedef struct nb_scenario {
     int32_t engine;                /* 0 = auto; 1 = one launch per step (any n; long runs replay a hipGraph of launches);
                                       2 = whole step loop inside one persistent single-workgroup launch (n <= 128) */
     int32_t flags;                 /* NB_SCN_NO_SNAPSHOT: FIRST_HIT records arrival steps but keeps no (q,v) snapshots */
-    int32_t reserved;
+    int32_t graph_chunk;           /* per-step engine: launches per replayed hipGraph; 0 = 1000, else even, 2..4000 */
     double planet_radius;          /* 1e7   nbody.cc:17 */
     double missile_speed;          /* 1e6   nbody.cc:18 */
 } nb_scenario;
@@ -178,8 +183,9 @@ int nb_write_state_file(const char* path, const nb_state_header* hdr, const doub
  * n > 128: the per-step engine instead — P1, P2 and the Problem-3 runs each replay their own graph of launches on their
  * own stream (one shared graph per GPU up to 256 bodies); a Problem-3 run starts from the snapshot P2 takes at its
  * missile's arrival (hw5.cu:265-287,482-489) as soon as P2's monitor shows it, one per GPU at a time in arrival order.
- * Environment (tuning / tests): NB_SOLVE_MAX_BATCH=2..8 scenarios per persistent launch; NB_SOLVE_ENGINE=steps|persistent;
- * NB_SOLVE_STREAMS=merged|split; NB_SOLVE_P3_PARALLEL=k Problem-3 runs at a time; NB_SOLVE_TRACE=1 timeline on stderr. */
+ * Tuning and test hooks travel in nb_solve_options (nb_solve_ex); the library reads ONE environment variable,
+ * NB_SOLVE_TRACE=1: a timeline of the driver's phases on stderr, no change of behaviour.  bin/hw5 maps its NB_SOLVE_* /
+ * NB_GRAPH_CHUNK environment onto the options (csrc/main_hw5.cpp). */
 typedef struct nb_answer {
     double min_dist;
     int32_t hit_time_step;
@@ -189,6 +195,23 @@ typedef struct nb_answer {
 int nb_solve(int n, int planet, int asteroid, const double* qx, const double* qy, const double* qz,
              const double* vx, const double* vy, const double* vz, const double* m, const uint8_t* is_device,
              const int* devices /* HIP ordinals to spread scenarios over */, int n_devices, nb_answer* out);
+typedef struct nb_solve_options { /* zero-initialise; every 0 = the default nb_solve uses */
+    int32_t max_batch;   /* persistent engine: scenarios per launch, 2..8 (default 8); fewer queues the other devices */
+    int32_t engine;      /* 0 = by system size; 1 = per-step engine (graph replay); 2 = persistent engine (n <= 128) */
+    int32_t streams;     /* per-step engine: 0 = by system size; 1 = one shared graph per GPU; 2 = a stream per scenario */
+    int32_t p3_parallel; /* per-step engine: Problem-3 runs at a time; 0 = one per listed GPU (hw5.cu:587-588) */
+    int32_t graph_chunk; /* per-step engine: launches per replayed graph; 0 = 1000, else even, 2..4000 */
+    int32_t handoff;     /* nb_solve_handoff: how P2's arrival snapshot reaches a Problem-3 run (hw5.cu:482-484) */
+    int32_t reserved[2];
+} nb_solve_options;
+typedef enum nb_solve_handoff {
+    NB_HANDOFF_AUTO = 0,       /* device copy on the same GPU ordinal, through host memory between different ones */
+    NB_HANDOFF_HOST_STAGED = 1 /* through host memory whenever the run sits on another entry of `devices` than P2, even if
+                                  both entries name the same GPU: executes the cross-GPU path on a one-GPU box */
+} nb_solve_handoff;
+int nb_solve_ex(int n, int planet, int asteroid, const double* qx, const double* qy, const double* qz,
+                const double* vx, const double* vy, const double* vz, const double* m, const uint8_t* is_device,
+                const int* devices, int n_devices, const nb_solve_options* options /* NULL = defaults */, nb_answer* out);
 
 /* ---- raw launches on caller-owned HBM (device pointers + a hipStream_t as void*) ----
  * For hosts that own device memory and the exchange step themselves (one process per GPU with
@@ -255,6 +278,11 @@ int64_t nb_workspace_bytes_f32(int64_t n_tgt, int acc64);
 typedef struct nb_sharded nb_sharded;
 #define NB_SHARDED_OVERLAP 1 /* two-phase step: own-shard sources while the all-gather of the other shards is in flight
                                 on a second stream, remote sources after it; n/P must be a multiple of 256 */
+#define NB_SHARDED_COPY_EXCHANGE 2 /* the per-step all-gather as P-1 peer copies per GPU (hipMemcpyPeerAsync on the exchange
+                                stream: SDMA engines over xGMI, no CU taken from the force kernel, RCCL not loaded) instead of
+                                ncclAllGather.  The only exchange that accepts an ordinal more than once in `devices` — ranks
+                                sharing a GPU, each with its own streams and arrays — which is how a one-GPU box executes the
+                                P > 1 host logic (tests/test_gpu_sharded_native.py) */
 int nb_sharded_create(nb_sharded** out, const int* devices, int n_devices, int64_t n, int precision, double G,
                       double eps, double dt, int flags);
 int nb_sharded_destroy(nb_sharded* s);

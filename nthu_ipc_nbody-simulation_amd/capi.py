@@ -17,13 +17,14 @@ _u8p = C.POINTER(C.c_uint8)
 
 class NbConfig(C.Structure):
     _fields_ = [("n", C.c_int32), ("precision", C.c_int32), ("device", C.c_int32), ("f64_large_min", C.c_int32),
-                ("G", C.c_double), ("eps", C.c_double), ("dt", C.c_double)]
+                ("f64_split", C.c_int32), ("cu_mask", C.c_int32), ("G", C.c_double), ("eps", C.c_double),
+                ("dt", C.c_double)]
 
 
 class NbScenario(C.Structure):
     _fields_ = [("kind", C.c_int32), ("first_step", C.c_int32), ("last_step", C.c_int32), ("planet", C.c_int32),
                 ("asteroid", C.c_int32), ("n_watch", C.c_int32), ("watch", C.c_int32 * NB_MAX_WATCH),
-                ("sync_every", C.c_int32), ("engine", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32),
+                ("sync_every", C.c_int32), ("engine", C.c_int32), ("flags", C.c_int32), ("graph_chunk", C.c_int32),
                 ("planet_radius", C.c_double), ("missile_speed", C.c_double)]
 
 
@@ -40,6 +41,11 @@ class NbStateHeader(C.Structure):
 class NbAnswer(C.Structure):
     _fields_ = [("min_dist", C.c_double), ("hit_time_step", C.c_int32), ("gravity_device_id", C.c_int32),
                 ("missile_cost", C.c_double)]
+
+
+class NbSolveOptions(C.Structure):
+    _fields_ = [("max_batch", C.c_int32), ("engine", C.c_int32), ("streams", C.c_int32), ("p3_parallel", C.c_int32),
+                ("graph_chunk", C.c_int32), ("handoff", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class NbLaunchF32(C.Structure):
@@ -79,6 +85,8 @@ SYMBOLS = {
     "nb_write_state_file": (C.c_int, [C.c_char_p, C.POINTER(NbStateHeader), _dp, _dp, _dp, _dp, _dp, _dp, _dp, _u8p]),
     "nb_solve": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _u8p,
                            C.POINTER(C.c_int), C.c_int, C.POINTER(NbAnswer)]),
+    "nb_solve_ex": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _u8p,
+                              C.POINTER(C.c_int), C.c_int, C.POINTER(NbSolveOptions), C.POINTER(NbAnswer)]),
     "nb_launch_step_f32": (C.c_int, [C.POINTER(NbLaunchF32), C.c_void_p]),
     "nb_launch_accel_f32": (C.c_int, [C.POINTER(NbLaunchF32), C.c_void_p]),
     "nb_kernel_name_f32": (C.c_char_p, [C.POINTER(NbLaunchF32), C.c_int]),
@@ -96,6 +104,9 @@ SYMBOLS = {
                                  C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 }
 NB_SHARDED_OVERLAP = 1
+NB_CU_ALL, NB_CU_LOW, NB_CU_HIGH, NB_CU_EVEN, NB_CU_ODD = 0, 1, 2, 3, 4
+NB_HANDOFF_AUTO, NB_HANDOFF_HOST_STAGED = 0, 1
+NB_SHARDED_COPY_EXCHANGE = 2
 
 
 class NBodyError(RuntimeError):
@@ -181,11 +192,12 @@ def _d(a):
 class Context:
     """One nb_context: a system of n bodies resident on one GPU."""
 
-    def __init__(self, n, precision=NB_F64, device=0, G=None, eps=None, dt=None, f64_large_min=0):
+    def __init__(self, n, precision=NB_F64, device=0, G=None, eps=None, dt=None, f64_large_min=0, f64_split=0,
+                 cu_mask=NB_CU_ALL):
         cfg = NbConfig()
         _check(lib().nb_config_default(C.byref(cfg)), "nb_config_default")
         cfg.n, cfg.precision, cfg.device = n, precision, device
-        cfg.f64_large_min = f64_large_min
+        cfg.f64_large_min, cfg.f64_split, cfg.cu_mask = f64_large_min, f64_split, cu_mask
         if G is not None:
             cfg.G = G
         if eps is not None:
@@ -252,9 +264,9 @@ class Context:
         return a
 
     def run_scenario(self, kind, planet, asteroid, first_step=0, last_step=200000, watch=(), sync_every=2000,
-                     planet_radius=1e7, missile_speed=1e6, engine=0, flags=0):
+                     planet_radius=1e7, missile_speed=1e6, engine=0, flags=0, graph_chunk=0):
         s = _scenario_struct(kind, planet, asteroid, first_step, last_step, watch, sync_every, planet_radius,
-                             missile_speed, engine, flags)
+                             missile_speed, engine, flags, graph_chunk)
         r = NbScenarioResult()
         _check(lib().nb_run_scenario(self._h, C.byref(s), C.byref(r)), "nb_run_scenario", self._h)
         return dict(min_dist2=r.min_dist2, hit_step=r.hit_step, steps_done=r.steps_done,
@@ -277,14 +289,14 @@ NB_SCN_EAGER = 2
 
 
 def _scenario_struct(kind, planet, asteroid, first_step=0, last_step=200000, watch=(), sync_every=2000,
-                     planet_radius=1e7, missile_speed=1e6, engine=0, flags=0):
+                     planet_radius=1e7, missile_speed=1e6, engine=0, flags=0, graph_chunk=0):
     s = NbScenario()
     s.kind, s.first_step, s.last_step, s.planet, s.asteroid = kind, first_step, last_step, planet, asteroid
     s.n_watch = len(watch)
     for k, w in enumerate(watch):
         s.watch[k] = w
     s.sync_every, s.planet_radius, s.missile_speed, s.engine = sync_every, planet_radius, missile_speed, engine
-    s.flags = flags
+    s.flags, s.graph_chunk = flags, graph_chunk
     return s
 
 
@@ -335,8 +347,14 @@ def write_state_file(path, q, v, m, is_device=None, planet=-1, asteroid=-1, prec
     _check(lib().nb_write_state_file(os.fsencode(path), C.byref(h), *[p for _, p in keep], dev), "nb_write_state_file")
 
 
-def solve(n, planet, asteroid, q, v, m, is_device, devices=None):
-    """The whole reference program (P1, P2, P3) on the GPU: nb_solve."""
+_ENGINES = {None: 0, "auto": 0, "steps": 1, "persistent": 2}
+_STREAMS = {None: 0, "auto": 0, "merged": 1, "split": 2}
+
+
+def solve(n, planet, asteroid, q, v, m, is_device, devices=None, engine=None, streams=None, max_batch=0,
+          p3_parallel=0, graph_chunk=0, handoff=NB_HANDOFF_AUTO):
+    """The whole reference program (P1, P2, P3) on the GPU: nb_solve_ex.  The keyword arguments after `devices` are
+    nb_solve_options (engine: steps|persistent, streams: merged|split; 0/None = the library's defaults)."""
     keep = [_d(q[0]), _d(q[1]), _d(q[2]), _d(v[0]), _d(v[1]), _d(v[2]), _d(m)]
     dev_arr = np.ascontiguousarray(is_device, dtype=np.uint8)
     ans = NbAnswer()
@@ -344,9 +362,11 @@ def solve(n, planet, asteroid, q, v, m, is_device, devices=None):
     if devices:
         gpus = (C.c_int * len(devices))(*devices)
         ng = len(devices)
-    rc = lib().nb_solve(n, planet, asteroid, *[p for _, p in keep], dev_arr.ctypes.data_as(_u8p), gpus, ng,
-                        C.byref(ans))
-    _check(rc, "nb_solve")
+    opt = NbSolveOptions(max_batch=max_batch, engine=_ENGINES[engine], streams=_STREAMS[streams],
+                         p3_parallel=p3_parallel, graph_chunk=graph_chunk, handoff=handoff)
+    rc = lib().nb_solve_ex(n, planet, asteroid, *[p for _, p in keep], dev_arr.ctypes.data_as(_u8p), gpus, ng,
+                           C.byref(opt), C.byref(ans))
+    _check(rc, "nb_solve_ex")
     return ans.min_dist, ans.hit_time_step, ans.gravity_device_id, ans.missile_cost
 
 
@@ -355,14 +375,18 @@ NB_PHASE_WHOLE, NB_PHASE_FIRST, NB_PHASE_LAST, NB_PHASE_MIDDLE = 0, 1, 2, 3
 
 class Sharded:
     """nb_sharded: N bodies sharded by index over the GPUs `devices` of this node, driven by this one process
-    (one stream + one in-place RCCL all-gather per GPU per step)."""
+    (one stream + one in-place all-gather per GPU per step: RCCL, or with exchange="copy" peer copies on the copy
+    engines — the form that lets several ranks share one GPU)."""
 
-    def __init__(self, n, devices=(0,), precision=NB_F32, G=6.674e-11, eps=1e-3, dt=60.0, overlap=False):
+    def __init__(self, n, devices=(0,), precision=NB_F32, G=6.674e-11, eps=1e-3, dt=60.0, overlap=False,
+                 exchange="rccl"):
+        if exchange not in ("rccl", "copy"):
+            raise ValueError("exchange must be 'rccl' or 'copy'")
         self.n = n
         self._h = C.c_void_p()
         devs = (C.c_int * len(devices))(*devices)
-        rc = lib().nb_sharded_create(C.byref(self._h), devs, len(devices), n, precision, G, eps, dt,
-                                     NB_SHARDED_OVERLAP if overlap else 0)
+        flags = (NB_SHARDED_OVERLAP if overlap else 0) | (NB_SHARDED_COPY_EXCHANGE if exchange == "copy" else 0)
+        rc = lib().nb_sharded_create(C.byref(self._h), devs, len(devices), n, precision, G, eps, dt, flags)
         if rc != NB_OK:
             h, self._h = self._h, C.c_void_p()
             detail = lib().nb_sharded_last_error(h).decode()

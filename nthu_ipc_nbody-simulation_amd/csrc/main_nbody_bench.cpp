@@ -1,7 +1,9 @@
 // main_nbody_bench.cpp — a compiled host of the C ABI for large N (no Python, no torch):
-//     bin/nbody_bench [N=1048576] [steps=10] [warmup=2] [precision: f32|f32acc64|f64] [gpus=0] [overlap=0]
+//     bin/nbody_bench [N=1048576] [steps=10] [warmup=2] [precision: f32|f32acc64|f64] [gpus=0] [overlap=0] [exchange=rccl]
 // gpus >= 1 runs the index-sharded stepper (nb_sharded_*: this one process drives GPUs 0..gpus-1, one in-place RCCL
 // all-gather of positions per GPU per step; overlap=1 = two-phase step hiding the gather); gpus = 0 the plain context.
+// exchange: rccl | copy (peer copies on the copy engines, NB_SHARDED_COPY_EXCHANGE) | copy-one-gpu (the same with all
+// `gpus` ranks on device 0 — every P > 1 line of the host runs on a one-GPU box; the ranks then share the chip).
 // Generates the synthetic bodies of SURVEY §8(d) (same splitmix64 stream as nbody_amd/synthetic.py), uploads them with
 // nb_set_state, advances `steps` steps with nb_step_timed (HIP events on the context's stream) and prints pairs/s.
 // Shows what a C/C++ caller of libnbody_amd looks like and gives rocprofv3 a target without an interpreter in front.
@@ -29,6 +31,13 @@ int main(int argc, char** argv) {
     const char* prec = argc > 4 ? argv[4] : "f32";
     const int gpus = argc > 5 ? atoi(argv[5]) : 0;
     const int overlap = argc > 6 ? atoi(argv[6]) : 0;
+    const char* exchange = argc > 7 ? argv[7] : "rccl";
+    const bool one_gpu = !strcmp(exchange, "copy-one-gpu");
+    const bool copy = one_gpu || !strcmp(exchange, "copy");
+    if (!copy && strcmp(exchange, "rccl")) {
+        fprintf(stderr, "exchange must be rccl, copy or copy-one-gpu\n");
+        return 2;
+    }
     nb_config cfg;
     nb_config_default(&cfg);
     cfg.n = (int32_t)n;
@@ -47,10 +56,10 @@ int main(int argc, char** argv) {
             return 2;
         }
         std::vector<int> devs(gpus);
-        for (int g = 0; g < gpus; ++g) devs[g] = g;
+        for (int g = 0; g < gpus; ++g) devs[g] = one_gpu ? 0 : g;
         nb_sharded* sh = nullptr;
         int rc = nb_sharded_create(&sh, devs.data(), gpus, n, cfg.precision, cfg.G, cfg.eps, cfg.dt,
-                                   overlap ? NB_SHARDED_OVERLAP : 0);
+                                   (overlap ? NB_SHARDED_OVERLAP : 0) | (copy ? NB_SHARDED_COPY_EXCHANGE : 0));
         if (!rc) rc = nb_sharded_set_state(sh, &q[0], &q[n], &q[2 * n], &v[0], &v[n], &v[2 * n], m.data());
         if (!rc && warmup > 0) rc = nb_sharded_step(sh, warmup);
         double ms = 0;
@@ -63,9 +72,9 @@ int main(int argc, char** argv) {
         int tpl = 0, js = 0, wg = 0;
         int64_t per = 0;
         nb_sharded_info(sh, nullptr, &per, &tpl, &js, &wg);
-        printf("{\"n\": %ld, \"precision\": \"%s\", \"gpus\": %d, \"overlap\": %d, \"steps\": %d, \"ms_per_step\": %.4f, "
+        printf("{\"n\": %ld, \"precision\": \"%s\", \"gpus\": %d, \"exchange\": \"%s\", \"overlap\": %d, \"steps\": %d, \"ms_per_step\": %.4f, "
                "\"pairs_per_s\": %.6e, \"tflops_20flop\": %.2f, \"targets_per_gpu\": %lld, \"plan\": [%d, %d, %d]}\n",
-               n, prec, gpus, overlap, steps, ms, pairs / (ms * 1e-3), pairs / (ms * 1e-3) * 20 / 1e12, (long long)per, tpl, js,
+               n, prec, gpus, exchange, overlap, steps, ms, pairs / (ms * 1e-3), pairs / (ms * 1e-3) * 20 / 1e12, (long long)per, tpl, js,
                wg);
         nb_sharded_destroy(sh);
         return 0;

@@ -1,102 +1,37 @@
-// nbody_capi.cpp — implementation of the C ABI in include/nbody_amd.h on top of the gfx950 kernels.
-//
-// Host-side equivalents of the reference's orchestration:
-//   nb_step          <- run_step call sites               samples/nbody.cc:116,129
-//   nb_run_scenario  <- P1/P2 loops, t_problem_12/_3      samples/nbody.cc:114-138 ; hw5.cu:366-404,489-508
-//   nb_solve         <- main()                            samples/nbody.cc:91-146 ; hw5.cu:532-606
+// nbody_capi.cpp — the core of the C ABI in include/nbody_amd.h on top of the gfx950 kernels: contexts, state,
+// nb_step / nb_accel (the run_step call sites, samples/nbody.cc:116,129) and the raw launches on caller-owned HBM.
+// The scenario drivers, nb_solve and the state files live in nbody_scenario.cpp, nbody_solve.cpp, nbody_statefile.cpp
+// (shared declarations: nbody_internal.h).
 // There is no CPU compute path here: every entry point needs a HIP device and fails loudly without one.
-#include "../../include/nbody_amd.h"
-
-#include <hip/hip_runtime.h>
-
 #include <algorithm>
-#include <chrono>
-#include <cmath>
-#include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <functional>
-#include <future>
-#include <limits>
-#include <memory>
 #include <new>
-#include <thread>
 #include <vector>
 
-#include "nbody_kernels.h"
+#include "nbody_internal.h"
 
 using namespace nbk;
+using namespace nbi;
 
-struct nb_context {
-    nb_config cfg;
-    int n = 0;
-    int n_cus = 0;
-    hipStream_t stream = nullptr;
-    bool owns_stream = true;  // false: borrowed from another context of the same GPU (nb_solve: a stream costs ~8 ms to
-                              // create, and only the leader of a launch stream ever enqueues on it)
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool have_state = false;
-    char err[512] = {0};
+namespace nbi {
 
-    // F64: SoA planes in HBM, exactly run_step's vectors: q[3][n] (ping-pong), v[3][n], m[n], coef[n]
-    double* q[2] = {nullptr, nullptr};
-    int cur = 0;
-    double* v = nullptr;
-    double* m = nullptr;
-    double* coef = nullptr;
-    double* acc = nullptr;  // [3][n] scratch for nb_accel
-    F64Monitor* mon = nullptr;
-    F64Monitor* mon_host = nullptr;  // pinned
-    double* snap_q = nullptr;        // [NB_MAX_WATCH? n_watch][3][n]
-    double* snap_v = nullptr;
-    int snap_slots = 0;
-    int snap_arrival[NB_MAX_WATCH];  // per snapshot slot: arrival step of the last FIRST_HIT scenario, -2 = holds nothing
-    int split = 1;
-    double* gm_large = nullptr;       // K1-f64 (n > F64_LARGE_MIN): G*m_eff scratch [n]
-    double* partial_large = nullptr;  // ... and partial sums [slices][3][n]
-    int slices_large = 1;
-    double* fst_dev = nullptr;  // K3: |sin(step*dt/6000)| table, steps 0 .. fst_len-1
-    int fst_len = 0;
-    int* done_dev = nullptr;
-    int* done_host = nullptr;  // pinned
-    F64Ctl* ctl_host = nullptr;  // pinned staging copy of *ctl
-    F64Ctl* ctl = nullptr;     // graph-driven stepping: {base step, active} read by every launch of a replayed graph
-    void* arena = nullptr;       // F64: ONE device allocation behind q, v, m, coef, acc, mon, done_dev, ctl ...
-    void* host_arena = nullptr;  // ... and one pinned allocation behind mon_host, done_host (a context costs two
-                                 // allocations instead of ten: nb_solve creates 2 + D of them per program run)
-    std::vector<double> m_host;
-    std::vector<uint8_t> dev_host;
-
-    // F32 / F32_ACC64: float4 {x,y,z,G*m} ping-pong, float4 velocities, optional double4 masters
-    float4* pos[2] = {nullptr, nullptr};
-    float4* vel = nullptr;
-    double4* pos64 = nullptr;
-    double4* vel64 = nullptr;
-    void* acc32 = nullptr;
-    void* partial = nullptr;  // source-slice workspace [SLICES_PER_LAUNCH + 2][n] float4 (double4 for ACC64)
-};
-
-namespace {
-
-// text of the last failure of a call that has no context (raw launches, state files, nb_solve, nb_sharded_create):
-// per host thread, read with nb_last_error(NULL)
-thread_local char g_err[512] = {0};
+// text of the last failure of a call that has no context (raw launches, state files, nb_solve): per host thread, read
+// with nb_last_error(NULL)
+char* thread_error() {
+    static thread_local char g_err[512] = {0};
+    return g_err;
+}
 
 int set_error(int code, const char* text) {
-    snprintf(g_err, sizeof g_err, "%s", text);
+    snprintf(thread_error(), 512, "%s", text);
     return code;
 }
 
 int fail_hip(nb_context* c, hipError_t e, const char* what) {
-    snprintf(c ? c->err : g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
+    snprintf(c ? c->err : thread_error(), 512, "%s: %s", what, hipGetErrorString(e));
     return NB_ERR_HIP;
 }
-
-#define NB_HIP(ctx, call)                                        \
-    do {                                                         \
-        hipError_t e_ = (call);                                  \
-        if (e_ != hipSuccess) return fail_hip(ctx, e_, #call);   \
-    } while (0)
 
 int bind(nb_context* c) {
     if (!c) return NB_ERR_INVALID;
@@ -104,14 +39,14 @@ int bind(nb_context* c) {
     return NB_OK;
 }
 
-// |sin(step*dt/6000)| with glibc, the value samples/nbody.cc:15,63 feeds gravity_device_mass
-double fst_of(int step, double dt) { return std::fabs(std::sin(step * dt / 6000)); }
-
-template <class T>
-void free_dev(T*& p) {
-    if (p) (void)hipFree(p);
-    p = nullptr;
+bool trace_enabled() {
+    static const bool on = getenv("NB_SOLVE_TRACE") != nullptr;
+    return on;
 }
+
+}  // namespace nbi
+
+namespace {
 
 void release(nb_context* c) {
     free_dev(c->arena);  // q, v, m, coef, acc, mon, done_dev, ctl
@@ -126,7 +61,9 @@ void release(nb_context* c) {
     if (c->stream && c->owns_stream) (void)hipStreamDestroy(c->stream);
 }
 
-F64Args base_args(nb_context* c, int step) {
+}  // namespace
+
+F64Args nbi::base_args(nb_context* c, int step) {
     F64Args a{};
     a.qin = c->q[c->cur];
     a.qout = c->q[c->cur ^ 1];
@@ -144,6 +81,8 @@ F64Args base_args(nb_context* c, int step) {
     a.scn.kind = -1;
     return a;
 }
+
+namespace {
 
 F64LargeArgs large_args(nb_context* c, int step) {
     F64LargeArgs a{};
@@ -246,27 +185,19 @@ const char* nb_strerror(int code) {
     return "unknown error";
 }
 
-const char* nb_last_error(const nb_context* ctx) { return ctx ? ctx->err : g_err; }
-
-}  // extern "C"
-
-namespace {
-int create_context(nb_context** out, const nb_config* cfg, hipStream_t borrowed);
-}
-
-extern "C" {
+const char* nb_last_error(const nb_context* ctx) { return ctx ? ctx->err : thread_error(); }
 
 int nb_create(nb_context** out, const nb_config* cfg) { return create_context(out, cfg, nullptr); }
 
 }  // extern "C"
 
-namespace {
-
 // `borrowed`: use this stream (of another context on the same GPU, which must outlive this one) instead of creating one
-int create_context(nb_context** out, const nb_config* cfg, hipStream_t borrowed) {
+int nbi::create_context(nb_context** out, const nb_config* cfg, hipStream_t borrowed) {
     if (!out || !cfg || cfg->n <= 0) return NB_ERR_INVALID;
     if (cfg->precision < NB_F64 || cfg->precision > NB_F32_ACC64) return NB_ERR_INVALID;
     if (cfg->precision != NB_F64 && !(cfg->eps > 0)) return NB_ERR_INVALID;  // fp32 kernels evaluate the self pair
+    if (cfg->cu_mask < NB_CU_ALL || cfg->cu_mask > NB_CU_ODD) return NB_ERR_INVALID;
+    if (cfg->f64_split < 0 || cfg->f64_split > 64 || (cfg->f64_split & (cfg->f64_split - 1))) return NB_ERR_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return NB_ERR_NO_DEVICE;
     if (cfg->device < 0 || cfg->device >= ndev) return NB_ERR_NO_DEVICE;
@@ -280,17 +211,17 @@ int create_context(nb_context** out, const nb_config* cfg, hipStream_t borrowed)
     hipDeviceProp_t prop;
     NB_HIP(c, hipGetDeviceProperties(&prop, cfg->device));
     c->n_cus = prop.multiProcessorCount;
-    // experiment knob (bench/scenario_concurrency.py): NB_CU_MASK=lo|hi|even|odd confines this context's stream to half
-    // of the compute units, so that two scenario streams do not share CUs
+    // nb_config.cu_mask (bench/scenario_concurrency.py) confines this context's stream to half of the compute units, so
+    // that two scenario streams do not share CUs
     if (borrowed) {
         c->stream = borrowed;
         c->owns_stream = false;
-    } else if (const char* e = getenv("NB_CU_MASK")) {
+    } else if (cfg->cu_mask != NB_CU_ALL) {
         uint32_t mask[8];
-        const int cus = std::min(256, c->n_cus);
+        const int cus = std::min(256, c->n_cus), how = cfg->cu_mask;
         for (int w = 0; w < 8; ++w) mask[w] = 0;
         for (int i = 0; i < cus; ++i) {
-            const bool on = !strcmp(e, "lo") ? i < cus / 2 : !strcmp(e, "hi") ? i >= cus / 2 : !strcmp(e, "even") ? !(i & 1) : (i & 1);
+            const bool on = how == NB_CU_LOW ? i < cus / 2 : how == NB_CU_HIGH ? i >= cus / 2 : how == NB_CU_EVEN ? !(i & 1) : (i & 1);
             if (on) mask[i >> 5] |= 1u << (i & 31);
         }
         NB_HIP(c, hipExtStreamCreateWithCUMask(&c->stream, 8, mask));
@@ -315,11 +246,7 @@ int create_context(nb_context** out, const nb_config* cfg, hipStream_t borrowed)
         c->mon_host = (F64Monitor*)c->host_arena;
         c->done_host = (int*)((char*)c->host_arena + 224);
         c->ctl_host = (F64Ctl*)((char*)c->host_arena + 232);
-        c->split = auto_split_f64(c->n, c->n_cus);
-        if (const char* e = getenv("NB_F64_SPLIT")) {  // experiments: lanes per target of the fp64 step kernel (power of two)
-            const int S = atoi(e);
-            if (S >= 1 && S <= 64 && !(S & (S - 1))) c->split = S;
-        }
+        c->split = cfg->f64_split > 0 ? cfg->f64_split : auto_split_f64(c->n, c->n_cus);
         const int large_min = cfg->f64_large_min > 0 ? cfg->f64_large_min : F64_LARGE_MIN;
         if (c->n >= large_min) {  // plain steps of a large fp64 system go through K1-f64
             c->slices_large = plan_f64_large_slices(c->n, c->n_cus);
@@ -343,8 +270,6 @@ int create_context(nb_context** out, const nb_config* cfg, hipStream_t borrowed)
     }
     return NB_OK;
 }
-
-}  // namespace
 
 extern "C" {
 
@@ -521,692 +446,6 @@ static int nb_accel_impl(nb_context* c, int step, double* ax, double* ay, double
     return NB_OK;
 }
 
-// ---------------------------------------------------------------- scenario drivers
-}  // extern "C"
-
-namespace {
-
-int check_scenario(const nb_context* c, const nb_scenario* s) {
-    if (c->cfg.precision != NB_F64) return NB_ERR_INVALID;
-    if (!c->have_state) return NB_ERR_STATE;
-    if (s->kind < NB_SCN_MIN_DIST || s->kind > NB_SCN_MISSILE) return NB_ERR_INVALID;
-    if (s->n_watch < 0 || s->n_watch > NB_MAX_WATCH) return NB_ERR_INVALID;
-    // one device is destroyed per Problem-3 run (hw5.cu:289-309): the kernels keep a single dead body
-    if (s->kind == NB_SCN_MISSILE && s->n_watch > 1) return NB_ERR_INVALID;
-    if (s->planet < 0 || s->planet >= c->n || s->asteroid < 0 || s->asteroid >= c->n) return NB_ERR_INVALID;
-    if (s->last_step < s->first_step) return NB_ERR_INVALID;
-    for (int k = 0; k < s->n_watch; ++k)
-        if (s->watch[k] < 0 || s->watch[k] >= c->n) return NB_ERR_INVALID;
-    if (s->engine < 0 || s->engine > 2) return NB_ERR_INVALID;
-    if (s->engine == 2 && c->n > SMALL_N_MAX) return NB_ERR_INVALID;
-    return NB_OK;
-}
-
-F64Scenario device_scenario(const nb_context* c, const nb_scenario* s) {
-    F64Scenario sc{};
-    sc.kind = s->kind;
-    sc.planet = s->planet;
-    sc.asteroid = s->asteroid;
-    sc.n_watch = (s->kind == NB_SCN_MIN_DIST) ? 0 : s->n_watch;
-    for (int k = 0; k < sc.n_watch; ++k) sc.watch[k] = s->watch[k];
-    sc.destroy_on_arrival = (s->kind == NB_SCN_MISSILE);
-    sc.R2 = s->planet_radius * s->planet_radius;      // nbody.cc:134
-    sc.missile_dstep = s->missile_speed * c->cfg.dt;  // hw5.cu:274
-    return sc;
-}
-
-bool wants_snapshots(const nb_scenario* s) {
-    return s->kind == NB_SCN_FIRST_HIT && s->n_watch > 0 && !(s->flags & NB_SCN_NO_SNAPSHOT);
-}
-
-int ensure_snapshots(nb_context* c, int n_watch) {
-    if (c->snap_slots >= n_watch) return NB_OK;
-    const size_t n = (size_t)c->n;
-    free_dev(c->snap_q);
-    free_dev(c->snap_v);
-    c->snap_slots = 0;
-    NB_HIP(c, hipMalloc(&c->snap_q, (size_t)n_watch * 3 * n * sizeof(double)));
-    NB_HIP(c, hipMalloc(&c->snap_v, (size_t)n_watch * 3 * n * sizeof(double)));
-    c->snap_slots = n_watch;
-    return NB_OK;
-}
-
-// K3 reads |sin(step*dt/6000)| by step index from a host-computed (glibc) table and prefetches two steps ahead
-int ensure_fst_table(nb_context* c, int last_step) {
-    const int need = last_step + 3;
-    if (c->fst_len < need) {
-        free_dev(c->fst_dev);
-        c->fst_len = 0;
-        std::vector<double> tab((size_t)need);
-        for (int k = 0; k < need; ++k) tab[(size_t)k] = fst_of(k, c->cfg.dt);
-        NB_HIP(c, hipMalloc(&c->fst_dev, (size_t)need * sizeof(double)));
-        // (never the legacy stream: another host thread may be capturing a graph on its own context's stream)
-        NB_HIP(c, hipMemcpyAsync(c->fst_dev, tab.data(), (size_t)need * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        NB_HIP(c, hipStreamSynchronize(c->stream));
-        c->fst_len = need;
-    }
-    return NB_OK;
-}
-
-// K3 reports the index of the last state it computed through a device word + its pinned host copy (part of the arenas)
-int ensure_done_word(nb_context* c) { return (c->done_dev && c->done_host) ? NB_OK : NB_ERR_STATE; }
-
-void reset_monitor_host(nb_context* c) {
-    F64Monitor* mh = c->mon_host;
-    mh->min_d2 = std::numeric_limits<double>::infinity();
-    mh->hit_step = -2;
-    for (int k = 0; k < MAX_WATCH; ++k) mh->arrival_step[k] = -2;
-    for (int k = 0; k < NB_MAX_WATCH; ++k) c->snap_arrival[k] = -2;
-}
-
-// `err` = the context that reports a HIP failure (the batch leader when several contexts share a stream)
-int reset_monitor(nb_context* err, nb_context* c, hipStream_t stream) {
-    F64Monitor* mh = c->mon_host;
-    reset_monitor_host(c);
-    NB_HIP(err, hipMemcpyAsync(c->mon, mh, sizeof(F64Monitor), hipMemcpyHostToDevice, stream));
-    return NB_OK;
-}
-
-void fill_result(nb_context* c, const nb_scenario* s, const F64Scenario& sc, int steps_done, nb_scenario_result* res) {
-    const F64Monitor* mh = c->mon_host;
-    memset(res, 0, sizeof *res);
-    res->min_dist2 = mh->min_d2;
-    res->hit_step = mh->hit_step;
-    res->steps_done = steps_done;
-    for (int k = 0; k < NB_MAX_WATCH; ++k) {
-        res->arrival_step[k] = (k < sc.n_watch) ? mh->arrival_step[k] : -2;
-        res->missile_cost[k] = (res->arrival_step[k] != -2)
-                                   ? 1e5 + 1e3 * ((res->arrival_step[k] + 1) * c->cfg.dt)  // hw5.cu:305 ; nbody.cc:19
-                                   : 0.0;
-        if (wants_snapshots(s)) c->snap_arrival[k] = res->arrival_step[k];  // which snapshot slots hold a state
-    }
-}
-
-F64SmallArgs small_args(nb_context* c, const F64Scenario& sc, bool want_snap, const double* fst_table, int at, int to,
-                        int last_step) {
-    F64SmallArgs k{};
-    k.q = c->q[c->cur];
-    k.v = c->v;
-    k.m = c->m;
-    k.coef = c->coef;
-    k.fst = fst_table;
-    k.snap_q = want_snap ? c->snap_q : nullptr;
-    k.snap_v = want_snap ? c->snap_v : nullptr;
-    k.mon = c->mon;
-    k.steps_done = c->done_dev;
-    k.n = c->n;
-    k.first_step = at;
-    k.last_step = to;
-    k.final_monitor = (to == last_step);
-    k.G = c->cfg.G;
-    k.eps2 = c->cfg.eps * c->cfg.eps;
-    k.dt = c->cfg.dt;
-    k.scn = sc;
-    return k;
-}
-
-constexpr int SMALL_CHUNK = 50000;  // K3: steps per launch, so that the host can stop relaunching after a hit
-constexpr int GRAPH_CHUNK_DEFAULT = 1000;  // K2, graph-driven: steps per replay (even: the ping-pong buffers are back
-                                           // in place after a chunk)
-// NB_GRAPH_CHUNK=<even, 2..4000> overrides (rocprofv3 1.1's kernel tracing crashes inside hipGraphLaunch on a 1000-node
-// graph; 100 nodes profile fine).  Read once per process.
-int graph_chunk() {
-    static const int chunk = [] {
-        const char* e = getenv("NB_GRAPH_CHUNK");
-        const int v = e ? atoi(e) : 0;
-        return (v >= 2 && v <= 4000 && v % 2 == 0) ? v : GRAPH_CHUNK_DEFAULT;
-    }();
-    return chunk;
-}
-constexpr int GRAPH_MIN_STEPS = 4000;  // shorter ranges are launched eagerly: capture + instantiate would cost more
-
-int run_batched_impl(nb_context** ctxs, const nb_scenario* scns, nb_scenario_result* results, int count);
-
-int run_scenario_impl(nb_context* c, const nb_scenario* s, nb_scenario_result* res) {
-    if (int rc = check_scenario(c, s)) return rc;
-    if (int rc = bind(c)) return rc;
-    const F64Scenario sc = device_scenario(c, s);
-    const bool want_snap = wants_snapshots(s);
-    if (want_snap)
-        if (int rc = ensure_snapshots(c, sc.n_watch)) return rc;
-    if (int rc = reset_monitor(c, c, c->stream)) return rc;
-    NB_HIP(c, hipStreamSynchronize(c->stream));
-    F64Monitor* mh = c->mon_host;
-
-    const bool small_engine = (s->engine == 2) || (s->engine == 0 && c->n <= SMALL_N_MAX);
-    if (small_engine) {
-        // K3: the whole step loop inside one single-workgroup kernel, in chunks so the host can stop after a hit
-        if (int rc = ensure_fst_table(c, s->last_step)) return rc;
-        if (int rc = ensure_done_word(c)) return rc;
-        int at = s->first_step;
-        bool first = true;
-        while (first || at < s->last_step) {
-            first = false;
-            const F64SmallArgs k = small_args(c, sc, want_snap, c->fst_dev, at, std::min(s->last_step, at + SMALL_CHUNK),
-                                              s->last_step);
-            NB_HIP(c, (hipError_t)launch_f64_small(k, c->stream));
-            NB_HIP(c, hipMemcpyAsync(mh, c->mon, sizeof(F64Monitor), hipMemcpyDeviceToHost, c->stream));
-            NB_HIP(c, hipMemcpyAsync(c->done_host, c->done_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-            NB_HIP(c, hipStreamSynchronize(c->stream));
-            at = *c->done_host;
-            if (mh->hit_step != -2 || at < k.last_step) break;
-        }
-        fill_result(c, s, sc, at, res);
-        return NB_OK;
-    }
-
-    if (!(s->flags & NB_SCN_EAGER) && s->last_step - s->first_step >= GRAPH_MIN_STEPS)
-        return run_batched_impl(&c, s, res, 1);  // graph replay of the (batched) step kernel with one slot
-
-    const int sync_every = s->sync_every > 0 ? s->sync_every : 2000;  // hw5.cu:72
-    const bool can_stop = s->kind != NB_SCN_MIN_DIST;
-    bool stopped = false;
-    int step = s->first_step + 1;
-    for (; step <= s->last_step; ++step) {
-        F64Args a = base_args(c, step);
-        a.scn = sc;
-        a.snap_q = want_snap ? c->snap_q : nullptr;
-        a.snap_v = want_snap ? c->snap_v : nullptr;
-        NB_HIP(c, (hipError_t)launch_f64(a, c->split, c->stream));
-        c->cur ^= 1;
-        if (can_stop && (step % sync_every == sync_every - 1)) {  // hw5.cu:398-402
-            NB_HIP(c, hipMemcpyAsync(&mh->hit_step, &c->mon->hit_step, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-            NB_HIP(c, hipStreamSynchronize(c->stream));
-            if (mh->hit_step != -2) {
-                stopped = true;
-                break;
-            }
-        }
-    }
-    if (!stopped) {  // monitor of the final state (index last_step): nbody.cc's loop runs step <= n_steps
-        F64Args a = base_args(c, s->last_step + 1);
-        a.scn = sc;
-        a.do_update = 0;
-        a.snap_q = want_snap ? c->snap_q : nullptr;
-        a.snap_v = want_snap ? c->snap_v : nullptr;
-        NB_HIP(c, (hipError_t)launch_f64(a, c->split, c->stream));
-    }
-    NB_HIP(c, hipMemcpyAsync(mh, c->mon, sizeof(F64Monitor), hipMemcpyDeviceToHost, c->stream));
-    NB_HIP(c, hipStreamSynchronize(c->stream));
-    // a hit ends the scenario at the state it was seen in, whichever poll noticed it (the launches after it returned at once)
-    (void)stopped;
-    fill_result(c, s, sc, (can_stop && mh->hit_step != -2) ? mh->hit_step : s->last_step, res);
-    return NB_OK;
-}
-
-// ---------------------------------------------------------------- graph-driven stepping (the per-step engine, K2)
-// One eager launch costs the HOST 3.1-3.7 us on this platform (bench/ubench/launch_rate.hip, profiles/r02_launch_rate.txt)
-// — more than a step of a few-hundred-body system takes on the GPU — while a hipGraph of kernel nodes replays at
-// 1.5-2.0 us per node with no host work at all.  A captured launch cannot carry its step index, so the scenario keeps a
-// control word {base step, active} in HBM: the node with offset t computes step base + t, reads |sin| from the
-// host-computed table, runs the monitor-only launch at last_step + 1 and returns at once beyond it (or while the slot is
-// dormant); a one-thread node at the end of the graph advances base by the chunk length.  The host replays the graph,
-// copies the monitors back and looks at them once per chunk (where hw5.cu polls every 2000 steps, hw5.cu:398-402).
-
-struct GraphGroup;
-struct GraphSlot {
-    nb_context* c = nullptr;
-    const nb_scenario* scn = nullptr;
-    F64Scenario sc{};
-    bool snap = false;
-    int base = 0;        // index of the state the slot's buffers hold (host mirror of ctl.base_step)
-    bool active = true;  // false: dormant follower
-    int done_at = -1;    // >= 0: finished; index of the last state computed
-    int inflight = 0;    // replays enqueued with this slot active and not yet collected
-    bool cancelled = false;  // follower dropped because a device that arrived earlier turned out feasible
-    // follower: a MISSILE run that starts from the snapshot which slot `parent_slot` of `parent` (a FIRST_HIT scenario
-    // with snapshots) takes when the missile of its watched device `parent_watch` arrives (hw5.cu:265-287,482-489)
-    GraphGroup* parent = nullptr;
-    int parent_slot = -1, parent_watch = -1;
-};
-
-struct GraphGroup {  // the scenarios that share one stream and one replayed graph
-    std::vector<GraphSlot> slots;
-    nb_context* lead = nullptr;  // owns the stream and the |sin| table, reports errors
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-    hipEvent_t ev[2] = {nullptr, nullptr};  // end of the replays in flight (even / odd)
-    int launched = 0, collected = 0;
-    bool prepared = false;
-    ~GraphGroup() {
-        if (lead) (void)hipSetDevice(lead->cfg.device);
-        if (lead && lead->stream) (void)hipStreamSynchronize(lead->stream);  // error paths: nothing of ours in flight
-        if (exec) (void)hipGraphExecDestroy(exec);
-        if (graph) (void)hipGraphDestroy(graph);
-        for (hipEvent_t e : ev)
-            if (e) (void)hipEventDestroy(e);
-    }
-    bool running() const {
-        for (const GraphSlot& s : slots)
-            if (s.done_at < 0) return true;
-        return false;
-    }
-    bool anything_active() const {
-        for (const GraphSlot& s : slots)
-            if (s.done_at < 0 && s.active) return true;
-        return false;
-    }
-};
-
-int upload_ctl(nb_context* err, GraphSlot& s, hipStream_t stream) {
-    *s.c->ctl_host = F64Ctl{s.base, s.active ? 1 : 0};  // pinned; rewritten only with the same values while in flight
-    NB_HIP(err, hipMemcpyAsync(s.c->ctl, s.c->ctl_host, sizeof(F64Ctl), hipMemcpyHostToDevice, stream));
-    return NB_OK;
-}
-
-// monitors, control words, tables, and the captured graph of graph_chunk() batched launches + the advance node
-int group_prepare(GraphGroup& g) {
-    nb_context* c0 = g.lead;
-    if (int rc = bind(c0)) return rc;
-    hipStream_t stream = c0->stream;
-    int max_last = 0;
-    for (GraphSlot& s : g.slots) {
-        s.sc = device_scenario(s.c, s.scn);
-        s.snap = wants_snapshots(s.scn);
-        if (s.snap)
-            if (int rc = ensure_snapshots(s.c, s.sc.n_watch)) { snprintf(c0->err, sizeof c0->err, "%s", s.c->err); return rc; }
-        max_last = std::max(max_last, s.scn->last_step);
-        NB_HIP(c0, hipStreamSynchronize(s.c->stream));  // earlier work of this context (uploads) is complete
-        if (int rc = reset_monitor(c0, s.c, stream)) return rc;
-        if (int rc = upload_ctl(c0, s, stream)) return rc;
-    }
-    if (int rc = ensure_fst_table(c0, max_last)) return rc;  // indices up to last_step + 1 are read
-    NB_HIP(c0, hipStreamSynchronize(stream));
-
-    const int count = (int)g.slots.size();
-    const auto t_prep = std::chrono::steady_clock::now();
-    // relaxed mode: the capture restricts neither this thread's nor other host threads' HIP calls on OTHER streams
-    // (distinct contexts may be driven from distinct threads); nothing but the launches below touches `stream` meanwhile
-    NB_HIP(c0, hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed));
-    hipError_t bad = hipSuccess;
-    const int chunk = graph_chunk();
-    for (int t = 0; t < chunk && bad == hipSuccess; ++t) {
-        F64BatchArgs args{};
-        args.count = count;
-        for (int b = 0; b < count; ++b) {
-            GraphSlot& s = g.slots[(size_t)b];
-            nb_context* c = s.c;
-            F64Args a{};
-            a.qin = c->q[c->cur ^ (t & 1)];
-            a.qout = c->q[c->cur ^ (t & 1) ^ 1];
-            a.v = c->v;
-            a.m = c->m;
-            a.coef = c->coef;
-            a.snap_q = s.snap ? c->snap_q : nullptr;
-            a.snap_v = s.snap ? c->snap_v : nullptr;
-            a.mon = c->mon;
-            a.n = c->n;
-            a.do_update = 1;  // (full grid; the kernel decides from the control word)
-            a.G = c->cfg.G;
-            a.eps2 = c->cfg.eps * c->cfg.eps;
-            a.dt = c->cfg.dt;
-            a.scn = s.sc;
-            a.ctl = c->ctl;
-            a.fst_table = c0->fst_dev;
-            a.t = t + 1;  // state index base + t  ->  step base + t + 1
-            a.last_step = s.scn->last_step;
-            args.item[b] = a;
-        }
-        bad = (hipError_t)launch_f64_batched(args, c0->n, c0->split, stream);
-    }
-    if (bad == hipSuccess) {
-        F64CtlBatch cb{};
-        cb.count = count;
-        for (int b = 0; b < count; ++b) cb.ctl[b] = g.slots[(size_t)b].c->ctl;
-        bad = (hipError_t)launch_ctl_advance(cb, chunk, stream);
-    }
-    hipError_t e = hipStreamEndCapture(stream, &g.graph);
-    if (bad != hipSuccess) return fail_hip(c0, bad, "capturing the step graph");
-    if (e != hipSuccess) return fail_hip(c0, e, "hipStreamEndCapture");
-    const auto t_cap = std::chrono::steady_clock::now();
-    NB_HIP(c0, hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
-    for (hipEvent_t& e : g.ev) NB_HIP(c0, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    if (getenv("NB_SOLVE_TRACE"))
-        fprintf(stderr, "[graph] %d slots: capture %.2f ms, instantiate %.2f ms\n", count,
-                std::chrono::duration<double, std::milli>(t_cap - t_prep).count(),
-                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_cap).count());
-    g.prepared = true;
-    return NB_OK;
-}
-
-// one replay = graph_chunk() steps of every active slot, then the monitors travel to their pinned host copies
-int group_launch(GraphGroup& g) {
-    nb_context* c0 = g.lead;
-    if (int rc = bind(c0)) return rc;
-    if (!g.prepared)
-        if (int rc = group_prepare(g)) return rc;
-    NB_HIP(c0, hipGraphLaunch(g.exec, c0->stream));
-    for (GraphSlot& s : g.slots)
-        if (s.done_at < 0 && s.active) {
-            NB_HIP(c0, hipMemcpyAsync(s.c->mon_host, s.c->mon, sizeof(F64Monitor), hipMemcpyDeviceToHost, c0->stream));
-            ++s.inflight;
-        }
-    NB_HIP(c0, hipEventRecord(g.ev[g.launched & 1], c0->stream));
-    ++g.launched;
-    return NB_OK;
-}
-
-// the oldest replay in flight has finished: host mirrors of the control words, and which slots have ended.  The pinned
-// monitors may already hold what a LATER replay wrote — they only ever move forward (min, first hit, first arrival), and
-// a value that is visible here was written by a replay that is complete (the copy is stream-ordered behind it).
-int group_collect(GraphGroup& g) {
-    nb_context* c0 = g.lead;
-    if (int rc = bind(c0)) return rc;
-    NB_HIP(c0, hipEventSynchronize(g.ev[g.collected & 1]));
-    ++g.collected;
-    for (GraphSlot& s : g.slots) {
-        if (s.inflight <= 0) continue;
-        --s.inflight;
-        if (s.done_at >= 0) continue;  // ended at an earlier replay: the launches of this one returned at once
-        const int before = s.base, last = s.scn->last_step;
-        s.base += graph_chunk();  // what nbody_ctl_advance did
-        const int hit = s.c->mon_host->hit_step;
-        if (s.scn->kind != NB_SCN_MIN_DIST && hit != -2) {
-            s.done_at = hit;  // the launch after state `hit` saw it and every later one returned at once
-        } else if (s.base > last) {  // steps before+1 .. last were taken, and the monitor-only launch at last + 1 has run
-            s.done_at = last;
-            s.c->cur ^= (last - before) & 1;  // an odd number of updates leaves the state in the other buffer
-        }
-    }
-    return NB_OK;
-}
-
-// start one dormant follower from its parent's arrival snapshot (hw5.cu:482-489)
-int activate_follower(GraphGroup& g, GraphSlot& f, int arr) {
-    nb_context* c0 = g.lead;
-    GraphSlot& p = f.parent->slots[(size_t)f.parent_slot];
-    const size_t n = (size_t)f.c->n, B = 3 * n * sizeof(double);
-    const double* sq = p.c->snap_q + (size_t)f.parent_watch * 3 * n;
-    const double* sv = p.c->snap_v + (size_t)f.parent_watch * 3 * n;
-    if (p.c->cfg.device == f.c->cfg.device) {  // the parent's replay that took the snapshot is complete (see group_collect)
-        if (int rc = bind(c0)) return rc;
-        NB_HIP(c0, hipMemcpyAsync(f.c->q[f.c->cur], sq, B, hipMemcpyDeviceToDevice, c0->stream));
-        NB_HIP(c0, hipMemcpyAsync(f.c->v, sv, B, hipMemcpyDeviceToDevice, c0->stream));
-    } else {  // another GPU: through the host
-        std::vector<double> hq(3 * n), hv(3 * n);
-        if (int rc = bind(p.c)) return rc;
-        NB_HIP(c0, hipMemcpyAsync(hq.data(), sq, B, hipMemcpyDeviceToHost, p.c->stream));
-        NB_HIP(c0, hipMemcpyAsync(hv.data(), sv, B, hipMemcpyDeviceToHost, p.c->stream));
-        NB_HIP(c0, hipStreamSynchronize(p.c->stream));
-        if (int rc = bind(c0)) return rc;
-        NB_HIP(c0, hipMemcpyAsync(f.c->q[f.c->cur], hq.data(), B, hipMemcpyHostToDevice, f.c->stream));
-        NB_HIP(c0, hipMemcpyAsync(f.c->v, hv.data(), B, hipMemcpyHostToDevice, f.c->stream));
-        NB_HIP(c0, hipStreamSynchronize(f.c->stream));  // host staging buffers die here; the group's stream starts later
-    }
-    f.base = arr;
-    f.active = true;
-    if (int rc = bind(c0)) return rc;
-    return upload_ctl(c0, f, c0->stream);
-}
-
-// The Problem-3 work queue (hw5.cu:490-493,574-596) over the followers of all groups: candidates are the devices whose
-// missile has arrived on the parent (P2) trajectory, cheapest first = ascending arrival step; at most `parallel` of them
-// run at a time (the reference: one per GPU); a run that ends feasible cancels every candidate that arrived later —
-// it cannot cost less (PROBLEM3_BREAK) — and a run that ends in a hit hands its place to the next candidate.
-int schedule_followers(std::vector<GraphGroup*>& groups, int parallel) {
-    struct Cand { GraphGroup* g; GraphSlot* f; int arr; };
-    std::vector<Cand> waiting;
-    int active = 0, best = std::numeric_limits<int>::max();
-    for (GraphGroup* g : groups)
-        for (GraphSlot& f : g->slots) {
-            if (!f.parent) continue;
-            GraphSlot& p = f.parent->slots[(size_t)f.parent_slot];
-            const int arr = p.c->mon_host->arrival_step[f.parent_watch];
-            if (f.done_at >= 0) {
-                if (f.active && !f.cancelled && f.done_at == f.scn->last_step && f.c->mon_host->hit_step == -2)
-                    best = std::min(best, arr);  // ended feasible
-            } else if (f.active) {
-                ++active;
-            } else if (arr != -2) {
-                waiting.push_back(Cand{g, &f, arr});
-            } else if (p.done_at >= 0) {
-                f.done_at = f.scn->first_step;  // the parent ended before this missile arrived: never starts
-            }
-        }
-    for (GraphGroup* g : groups)  // nothing that arrived after a feasible device can beat it
-        for (GraphSlot& f : g->slots) {
-            if (!f.parent || f.done_at >= 0) continue;
-            const int arr = f.parent->slots[(size_t)f.parent_slot].c->mon_host->arrival_step[f.parent_watch];
-            if (arr != -2 && arr > best) {
-                if (f.active) --active;
-                f.cancelled = true;
-                f.done_at = f.active ? std::min(f.base, f.scn->last_step) : f.scn->first_step;
-            }
-        }
-    std::stable_sort(waiting.begin(), waiting.end(), [](const Cand& a, const Cand& b) { return a.arr < b.arr; });
-    for (const Cand& c : waiting) {
-        if (c.f->done_at >= 0) continue;  // cancelled above
-        if (active >= parallel) break;
-        if (int rc = activate_follower(*c.g, *c.f, c.arr)) return rc;
-        ++active;
-    }
-    return NB_OK;
-}
-
-// all groups to completion, one host thread: every running group keeps up to two replays in flight (the second is
-// enqueued while the first executes, so neither the host's enqueue work nor its look at the monitors idles the GPU)
-int run_groups_graph(std::vector<GraphGroup*>& groups, int follower_parallel = 1 << 30) {
-    for (;;) {
-        bool progressed = false;
-        // enqueueing a replay costs the host about a millisecond per 1000 nodes: groups enqueue side by side (graphs are
-        // captured serially, on the calling thread, the first time round)
-        std::vector<GraphGroup*> due;
-        for (GraphGroup* g : groups)
-            if (g->running() && g->anything_active() && g->launched - g->collected < 2) {
-                if (!g->prepared)
-                    if (int rc = group_prepare(*g)) return rc;
-                due.push_back(g);
-            }
-        if (!due.empty()) {
-            std::vector<std::future<int>> side;
-            for (size_t k = 1; k < due.size(); ++k) side.push_back(std::async(std::launch::async, group_launch, std::ref(*due[k])));
-            int rc = group_launch(*due[0]);
-            for (auto& f : side) {
-                const int r = f.get();
-                if (!rc) rc = r;
-            }
-            if (rc) return rc;
-            progressed = true;
-        }
-        for (GraphGroup* g : groups)
-            if (g->launched > g->collected && (g->launched - g->collected == 2 || !g->running() || !g->anything_active() ||
-                                               !progressed)) {
-                if (int rc = group_collect(*g)) return rc;
-                progressed = true;
-            }
-        bool dormant_left = false, inflight = false;
-        if (int rc = schedule_followers(groups, follower_parallel)) return rc;
-        for (GraphGroup* g : groups) {
-            for (const GraphSlot& s : g->slots) dormant_left |= (s.done_at < 0);
-            inflight |= g->launched > g->collected;
-        }
-        if (!dormant_left && !inflight) break;
-        if (!progressed && !inflight) {  // only dormant followers whose parents have all ended: cannot wake any more
-            for (GraphGroup* g : groups)
-                for (GraphSlot& s : g->slots)
-                    if (s.done_at < 0) s.done_at = s.scn->first_step;
-            break;
-        }
-    }
-    return NB_OK;
-}
-
-// Several scenarios of equally sized systems on one GPU, all driven by ONE stream (that of ctxs[0]):
-//  * small systems (K3): one launch whose workgroup k runs scenario k to its end, relaunched per SMALL_CHUNK steps
-//    for the slots still running;
-//  * otherwise (K2): lock step, ONE launch per step serves all of them (blockIdx.y), each with its own state, step
-//    index, |sin| and monitor — what hw5.cu does with one host thread + launch stream per scenario
-//    (hw5.cu:564-567,587-588), without the streams contending for the command processor.
-int run_batched_impl(nb_context** ctxs, const nb_scenario* scns, nb_scenario_result* results, int count) {
-    if (!ctxs || !scns || !results || count <= 0 || count > MAX_BATCH) return NB_ERR_INVALID;
-    nb_context* c0 = ctxs[0];
-    if (!c0) return NB_ERR_INVALID;
-    for (int b = 0; b < count; ++b) {
-        nb_context* c = ctxs[b];
-        if (!c || c->n != c0->n || c->cfg.device != c0->cfg.device) return NB_ERR_INVALID;
-        if (c->cfg.dt != c0->cfg.dt || scns[b].engine != scns[0].engine) return NB_ERR_INVALID;
-        if (int rc = check_scenario(c, &scns[b])) return rc;
-        for (int b2 = 0; b2 < b; ++b2)
-            if (ctxs[b2] == c) return NB_ERR_INVALID;
-    }
-    if (int rc = bind(c0)) return rc;
-    hipStream_t stream = c0->stream;
-
-    F64Scenario sc[MAX_BATCH];
-    bool snap[MAX_BATCH];
-    int done_at[MAX_BATCH];  // -1 while running; else the index of the last state computed
-    for (int b = 0; b < count; ++b) {
-        nb_context* c = ctxs[b];
-        sc[b] = device_scenario(c, &scns[b]);
-        snap[b] = wants_snapshots(&scns[b]);
-        if (snap[b])
-            if (int rc = ensure_snapshots(c, sc[b].n_watch)) { snprintf(c0->err, sizeof c0->err, "%s", c->err); return rc; }
-        done_at[b] = -1;
-        NB_HIP(c0, hipStreamSynchronize(c->stream));  // earlier work of this context (uploads) is complete
-        if (int rc = reset_monitor(c0, c, stream)) return rc;
-    }
-    NB_HIP(c0, hipStreamSynchronize(stream));
-
-    const bool small_engine = (scns[0].engine == 2) || (scns[0].engine == 0 && c0->n <= SMALL_N_MAX);
-    if (small_engine) {
-        int max_last = 0, at[MAX_BATCH];
-        for (int b = 0; b < count; ++b) {
-            max_last = std::max(max_last, scns[b].last_step);
-            at[b] = scns[b].first_step;
-            if (int rc = ensure_done_word(ctxs[b])) { snprintf(c0->err, sizeof c0->err, "%s", ctxs[b]->err); return rc; }
-        }
-        const bool trace = getenv("NB_SOLVE_TRACE") != nullptr;
-        const auto t_k3 = std::chrono::steady_clock::now();
-        auto lap = [&](const char* what, int a0, int a1) {
-            if (trace)
-                fprintf(stderr, "[K3 batch] %8.1f ms  %s %d %d\n",
-                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_k3).count(), what, a0, a1);
-        };
-        if (int rc = ensure_fst_table(c0, max_last)) return rc;  // same dt everywhere: one table serves the batch
-        lap("|sin| table ready, entries", max_last + 3, 0);
-        int running = count;
-        while (running > 0) {
-            F64SmallBatchArgs args{};
-            args.count = count;
-            int to[MAX_BATCH];
-            for (int b = 0; b < count; ++b) {
-                if (done_at[b] >= 0) continue;  // finished slot: item[b].n stays 0
-                // each workgroup runs to the end of its own scenario (it stops by itself at a hit): chunking the launch would
-                // make every scenario wait for the slowest one of the batch at each chunk boundary
-                to[b] = scns[b].last_step;
-                args.item[b] = small_args(ctxs[b], sc[b], snap[b], c0->fst_dev, at[b], to[b], scns[b].last_step);
-            }
-            NB_HIP(c0, (hipError_t)launch_f64_small_batched(args, c0->n, stream));
-            for (int b = 0; b < count; ++b) {
-                if (done_at[b] >= 0) continue;
-                NB_HIP(c0, hipMemcpyAsync(ctxs[b]->mon_host, ctxs[b]->mon, sizeof(F64Monitor), hipMemcpyDeviceToHost, stream));
-                NB_HIP(c0, hipMemcpyAsync(ctxs[b]->done_host, ctxs[b]->done_dev, sizeof(int), hipMemcpyDeviceToHost, stream));
-            }
-            NB_HIP(c0, hipStreamSynchronize(stream));
-            lap("launch returned, slots still running before it", running, 0);
-            for (int b = 0; b < count; ++b) {
-                if (done_at[b] >= 0) continue;
-                at[b] = *ctxs[b]->done_host;
-                lap("  slot reached state", b, at[b]);
-                if (ctxs[b]->mon_host->hit_step != -2 || at[b] < to[b] || at[b] >= scns[b].last_step) {
-                    done_at[b] = at[b];
-                    --running;
-                }
-            }
-        }
-        for (int b = 0; b < count; ++b) fill_result(ctxs[b], &scns[b], sc[b], done_at[b], &results[b]);
-        return NB_OK;
-    }
-
-    // long runs: replay a captured graph of launches instead of issuing every launch from the host
-    int longest = 0;
-    bool eager = false;
-    for (int b = 0; b < count; ++b) {
-        longest = std::max(longest, scns[b].last_step - scns[b].first_step);
-        eager |= (scns[b].flags & NB_SCN_EAGER) != 0;
-    }
-    if (!eager && longest >= GRAPH_MIN_STEPS) {
-        GraphGroup g;
-        g.lead = c0;
-        g.slots.resize((size_t)count);
-        for (int b = 0; b < count; ++b) {
-            g.slots[(size_t)b].c = ctxs[b];
-            g.slots[(size_t)b].scn = &scns[b];
-            g.slots[(size_t)b].base = scns[b].first_step;
-        }
-        std::vector<GraphGroup*> one{&g};
-        if (int rc = run_groups_graph(one)) return rc;
-        for (int b = 0; b < count; ++b) fill_result(ctxs[b], &scns[b], g.slots[(size_t)b].sc, g.slots[(size_t)b].done_at, &results[b]);
-        return NB_OK;
-    }
-
-    const int sync_every = scns[0].sync_every > 0 ? scns[0].sync_every : 2000;
-    int running = count;
-    for (int t = 1; running > 0; ++t) {  // t-th step of every scenario still running
-        F64BatchArgs args{};
-        args.count = count;
-        for (int b = 0; b < count; ++b) {
-            if (done_at[b] >= 0) continue;  // idle slot: item[b].n stays 0
-            nb_context* c = ctxs[b];
-            const int step = scns[b].first_step + t;
-            F64Args a = base_args(c, step);
-            a.scn = sc[b];
-            a.snap_q = snap[b] ? c->snap_q : nullptr;
-            a.snap_v = snap[b] ? c->snap_v : nullptr;
-            if (step > scns[b].last_step) {  // the state last_step exists: only its monitor is left
-                a.do_update = 0;
-                done_at[b] = scns[b].last_step;
-                --running;
-            }
-            args.item[b] = a;
-            if (a.do_update) c->cur ^= 1;
-        }
-        NB_HIP(c0, (hipError_t)launch_f64_batched(args, c0->n, c0->split, stream));
-        if (t % sync_every == sync_every - 1) {  // poll the hit flags (hw5.cu:398-402,503-507)
-            for (int b = 0; b < count; ++b)
-                if (done_at[b] < 0 && scns[b].kind != NB_SCN_MIN_DIST)
-                    NB_HIP(c0, hipMemcpyAsync(&ctxs[b]->mon_host->hit_step, &ctxs[b]->mon->hit_step, sizeof(int),
-                                              hipMemcpyDeviceToHost, stream));
-            NB_HIP(c0, hipStreamSynchronize(stream));
-            for (int b = 0; b < count; ++b)
-                if (done_at[b] < 0 && scns[b].kind != NB_SCN_MIN_DIST && ctxs[b]->mon_host->hit_step != -2) {
-                    done_at[b] = scns[b].first_step + t;
-                    --running;
-                }
-        }
-    }
-    for (int b = 0; b < count; ++b)
-        NB_HIP(c0, hipMemcpyAsync(ctxs[b]->mon_host, ctxs[b]->mon, sizeof(F64Monitor), hipMemcpyDeviceToHost, stream));
-    NB_HIP(c0, hipStreamSynchronize(stream));
-    for (int b = 0; b < count; ++b) {
-        const int hit = ctxs[b]->mon_host->hit_step;  // as above: a hit ends the scenario at the state it was seen in
-        if (scns[b].kind != NB_SCN_MIN_DIST && hit != -2) done_at[b] = hit;
-        fill_result(ctxs[b], &scns[b], sc[b], done_at[b], &results[b]);
-    }
-    return NB_OK;
-}
-
-}  // namespace
-
-extern "C" {
-
-int nb_run_scenario(nb_context* c, const nb_scenario* s, nb_scenario_result* res) {
-    if (!c || !s || !res) return NB_ERR_INVALID;
-    try {
-        return run_scenario_impl(c, s, res);
-    } catch (...) {  // std::bad_alloc from the host-side tables: nothing crosses the C boundary
-        return NB_ERR_NOMEM;
-    }
-}
-
-int nb_run_scenarios_batched(nb_context** ctxs, const nb_scenario* scns, nb_scenario_result* results, int count) {
-    try {
-        return run_batched_impl(ctxs, scns, results, count);
-    } catch (...) {
-        return NB_ERR_NOMEM;
-    }
-}
-
 static int nb_restore_snapshot_impl(nb_context* dst, nb_context* src, int slot) {
     if (!dst || !src || slot < 0 || slot >= src->snap_slots) return NB_ERR_INVALID;
     if (dst->n != src->n || dst->cfg.precision != NB_F64 || src->cfg.precision != NB_F64) return NB_ERR_INVALID;
@@ -1259,557 +498,7 @@ int nb_restore_snapshot(nb_context* dst, nb_context* src, int slot) {
     }
 }
 
-// ---------------------------------------------------------------- binary state files
-}  // extern "C"
-
-namespace {
-// version 1 (round 1): magic "NBODYST1", int64 n, int32 precision, int32 step, double G, eps, dt            (48 bytes)
-// version 2:           magic "NBODYST2", uint32 byte-order mark, int32 precision, int64 n, int32 step,
-//                      int32 planet, int32 asteroid, int32 reserved, double G, eps, dt                      (64 bytes)
-struct StateHeaderV1 {
-    char magic[8];
-    int64_t n;
-    int32_t precision;
-    int32_t step;
-    double G, eps, dt;
-};
-struct StateHeaderV2 {
-    char magic[8];
-    uint32_t bom;
-    int32_t precision;
-    int64_t n;
-    int32_t step;
-    int32_t planet, asteroid, reserved;
-    double G, eps, dt;
-};
-static_assert(sizeof(StateHeaderV1) == 48 && sizeof(StateHeaderV2) == 64, "on-disk layout");
-const char kMagic1[8] = {'N', 'B', 'O', 'D', 'Y', 'S', 'T', '1'};
-const char kMagic2[8] = {'N', 'B', 'O', 'D', 'Y', 'S', 'T', '2'};
-constexpr uint32_t kBom = 0x01020304u;
-
-struct FileCloser {
-    void operator()(FILE* f) const {
-        if (f) fclose(f);
-    }
-};
-using FilePtr = std::unique_ptr<FILE, FileCloser>;
-
-// header of either version; the stream is left at the first body array
-int read_header(FILE* f, nb_state_header* h) {
-    char magic[8];
-    if (fread(magic, 8, 1, f) != 1) return NB_ERR_IO;
-    memset(h, 0, sizeof *h);
-    if (memcmp(magic, kMagic1, 8) == 0) {
-        StateHeaderV1 v;
-        if (fread(&v.n, sizeof v - 8, 1, f) != 1) return NB_ERR_IO;
-        h->n = v.n; h->precision = v.precision; h->step = v.step;
-        h->planet = h->asteroid = -1;
-        h->G = v.G; h->eps = v.eps; h->dt = v.dt;
-    } else if (memcmp(magic, kMagic2, 8) == 0) {
-        StateHeaderV2 v;
-        if (fread(&v.bom, sizeof v - 8, 1, f) != 1) return NB_ERR_IO;
-        if (v.bom != kBom) return set_error(NB_ERR_IO, "state file written with another byte order");
-        h->n = v.n; h->precision = v.precision; h->step = v.step;
-        h->planet = v.planet; h->asteroid = v.asteroid;
-        h->G = v.G; h->eps = v.eps; h->dt = v.dt;
-    } else {
-        return set_error(NB_ERR_IO, "not an NBODYST1/NBODYST2 state file");
-    }
-    if (h->n <= 0 || h->precision < NB_F64 || h->precision > NB_F32_ACC64) return set_error(NB_ERR_IO, "corrupt state header");
-    return NB_OK;
-}
-
-int write_state(const char* path, const nb_state_header* h, const double* const q[6], const double* m,
-                const uint8_t* is_device) {
-    if (h->n <= 0) return NB_ERR_INVALID;
-    const size_t n = (size_t)h->n;
-    StateHeaderV2 v{};
-    memcpy(v.magic, kMagic2, 8);
-    v.bom = kBom;
-    v.precision = h->precision;
-    v.n = h->n;
-    v.step = h->step;
-    v.planet = h->planet;
-    v.asteroid = h->asteroid;
-    v.G = h->G; v.eps = h->eps; v.dt = h->dt;
-    FILE* f = fopen(path, "wb");
-    if (!f) return set_error(NB_ERR_IO, "cannot open state file for writing");
-    bool ok = fwrite(&v, sizeof v, 1, f) == 1;
-    for (int k = 0; k < 6 && ok; ++k) ok = fwrite(q[k], sizeof(double), n, f) == n;
-    ok = ok && fwrite(m, sizeof(double), n, f) == n;
-    if (ok && is_device) ok = fwrite(is_device, 1, n, f) == n;
-    else if (ok) {
-        std::vector<uint8_t> z(n, 0);
-        ok = fwrite(z.data(), 1, n, f) == n;
-    }
-    ok = (fclose(f) == 0) && ok;
-    return ok ? NB_OK : set_error(NB_ERR_IO, "short write to state file");
-}
-
-int read_state_impl(const char* path, nb_state_header* hdr, int64_t capacity, double* qx, double* qy, double* qz,
-                    double* vx, double* vy, double* vz, double* m, uint8_t* is_device) {
-    if (!path || !hdr) return NB_ERR_INVALID;
-    FilePtr f(fopen(path, "rb"));
-    if (!f) return set_error(NB_ERR_IO, "cannot open state file");
-    if (int rc = read_header(f.get(), hdr)) return rc;
-    if (!qx && !qy && !qz && !vx && !vy && !vz && !m && !is_device) return NB_OK;  // header only
-    if (!qx || !qy || !qz || !vx || !vy || !vz || !m) return NB_ERR_INVALID;
-    if (capacity < hdr->n) return set_error(NB_ERR_INVALID, "arrays too small for the bodies in the state file");
-    const size_t n = (size_t)hdr->n;
-    double* arr[7] = {qx, qy, qz, vx, vy, vz, m};
-    for (double* a : arr)
-        if (fread(a, sizeof(double), n, f.get()) != n) return set_error(NB_ERR_IO, "truncated state file");
-    if (is_device) {
-        if (fread(is_device, 1, n, f.get()) != n) return set_error(NB_ERR_IO, "truncated state file");
-    }
-    return NB_OK;
-}
-
-}  // namespace
-
-extern "C" {
-
-int nb_state_file_info(const char* path, int64_t* n, int* precision, int* step) {
-    nb_state_header h;
-    if (int rc = read_state_impl(path, &h, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr)) return rc;
-    if (n) *n = h.n;
-    if (precision) *precision = h.precision;
-    if (step) *step = h.step;
-    return NB_OK;
-}
-
-int nb_read_state_file(const char* path, nb_state_header* hdr, int64_t capacity, double* qx, double* qy, double* qz,
-                       double* vx, double* vy, double* vz, double* m, uint8_t* is_device) {
-    return read_state_impl(path, hdr, capacity, qx, qy, qz, vx, vy, vz, m, is_device);
-}
-
-int nb_write_state_file(const char* path, const nb_state_header* hdr, const double* qx, const double* qy,
-                        const double* qz, const double* vx, const double* vy, const double* vz, const double* m,
-                        const uint8_t* is_device) {
-    if (!path || !hdr || !qx || !qy || !qz || !vx || !vy || !vz || !m) return NB_ERR_INVALID;
-    if (hdr->precision < NB_F64 || hdr->precision > NB_F32_ACC64) return NB_ERR_INVALID;
-    const double* q[6] = {qx, qy, qz, vx, vy, vz};
-    try {
-        return write_state(path, hdr, q, m, is_device);
-    } catch (...) {
-        return NB_ERR_NOMEM;
-    }
-}
-
-int nb_save_state(nb_context* c, const char* path, int step) {
-    if (!c || !path) return NB_ERR_INVALID;
-    if (!c->have_state) return NB_ERR_STATE;
-    try {
-        const size_t n = (size_t)c->n;
-        std::vector<double> buf(6 * n);
-        if (int rc = nb_get_state(c, &buf[0], &buf[n], &buf[2 * n], &buf[3 * n], &buf[4 * n], &buf[5 * n])) return rc;
-        nb_state_header h{};
-        h.n = c->n;
-        h.precision = c->cfg.precision;
-        h.step = step;
-        h.planet = h.asteroid = -1;  // a context does not know the scenario's bodies (nb_write_state_file records them)
-        h.G = c->cfg.G;
-        h.eps = c->cfg.eps;
-        h.dt = c->cfg.dt;
-        const double* q[6] = {&buf[0], &buf[n], &buf[2 * n], &buf[3 * n], &buf[4 * n], &buf[5 * n]};
-        int rc = write_state(path, &h, q, c->m_host.data(), c->dev_host.data());
-        if (rc) snprintf(c->err, sizeof c->err, "%s", nb_last_error(nullptr));
-        return rc;
-    } catch (...) {
-        return NB_ERR_NOMEM;
-    }
-}
-
-int nb_load_state(nb_context* c, const char* path, int* step) {
-    if (!c || !path) return NB_ERR_INVALID;
-    try {
-        nb_state_header h;
-        if (int rc = read_state_impl(path, &h, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr)) {
-            snprintf(c->err, sizeof c->err, "%s", nb_last_error(nullptr));
-            return rc;
-        }
-        // a checkpoint resumes the run it was taken from: same system size, arithmetic and integration parameters.
-        // (nb_read_state_file + nb_set_state is the explicit route for loading a state under other parameters.)
-        if (h.n != c->n || h.precision != c->cfg.precision || h.G != c->cfg.G || h.eps != c->cfg.eps || h.dt != c->cfg.dt) {
-            snprintf(c->err, sizeof c->err,
-                     "state file (n=%lld precision=%d G=%g eps=%g dt=%g) does not match the context (n=%d precision=%d "
-                     "G=%g eps=%g dt=%g)", (long long)h.n, h.precision, h.G, h.eps, h.dt, c->n, c->cfg.precision, c->cfg.G,
-                     c->cfg.eps, c->cfg.dt);
-            return NB_ERR_INVALID;
-        }
-        const size_t n = (size_t)c->n;
-        std::vector<double> buf(7 * n);
-        std::vector<uint8_t> dev(n);
-        if (int rc = read_state_impl(path, &h, (int64_t)n, &buf[0], &buf[n], &buf[2 * n], &buf[3 * n], &buf[4 * n], &buf[5 * n],
-                                     &buf[6 * n], dev.data())) {
-            snprintf(c->err, sizeof c->err, "%s", nb_last_error(nullptr));
-            return rc;
-        }
-        if (step) *step = h.step;
-        return nb_set_state(c, &buf[0], &buf[n], &buf[2 * n], &buf[3 * n], &buf[4 * n], &buf[5 * n], &buf[6 * n], dev.data());
-    } catch (...) {
-        return NB_ERR_NOMEM;
-    }
-}
-
-// ---------------------------------------------------------------- whole program
-}  // extern "C"
-
-namespace {
-
-struct CtxDeleter {
-    void operator()(nb_context* c) const {
-        if (c) nb_destroy(c);
-    }
-};
-using CtxPtr = std::unique_ptr<nb_context, CtxDeleter>;
-
-struct CtxList {  // destroyed newest first: a context that borrows a stream dies before the context that owns it
-    std::vector<CtxPtr> v;
-    ~CtxList() {
-        while (!v.empty()) v.pop_back();
-    }
-};
-
-struct ThreadJoiner {  // no exception may leave joinable threads behind (std::terminate)
-    std::vector<std::thread>& ts;
-    ~ThreadJoiner() {
-        for (auto& t : ts)
-            if (t.joinable()) t.join();
-    }
-};
-
-struct SolveSlot {  // one scenario of the program: P1, P2 or the Problem-3 run of one device
-    nb_scenario scn{};
-    nb_scenario_result res{};
-    int device_k = -1;  // MISSILE: index into the device list
-    bool zero_devices = false;  // P1: devices massless (nbody.cc:109-113)
-    int rc = NB_OK;
-    bool ran = false;
-    char err[256] = {0};
-};
-
-struct SolveInput {
-    int n, planet, asteroid;
-    const double *qx, *qy, *qz, *vx, *vy, *vz, *m;
-    const uint8_t* is_device;
-    const std::vector<double>* m_no_devices;
-    void (*stamp)(const char*);  // NB_SOLVE_TRACE timeline, or nullptr
-};
-
-// all scenarios of `slots` on one GPU: contexts + one batched launch stream, at most `cap` scenarios at a time
-void run_group(const SolveInput& in, int gpu, const std::vector<SolveSlot*>& slots, int cap) {
-    try {
-        for (size_t at = 0; at < slots.size(); at += (size_t)cap) {
-            const int cnt = (int)std::min(slots.size() - at, (size_t)cap);
-            CtxList list;
-            std::vector<CtxPtr>& owned = list.v;
-            nb_context* ctxs[MAX_BATCH];
-            nb_scenario scns[MAX_BATCH];
-            nb_scenario_result ress[MAX_BATCH];
-            int rc = NB_OK;
-            for (int k = 0; k < cnt && !rc; ++k) {
-                SolveSlot* s = slots[at + k];
-                nb_config cfg;
-                nb_config_default(&cfg);
-                cfg.n = in.n;
-                cfg.device = gpu;
-                nb_context* c = nullptr;
-                // one launch stream serves the whole batch: only its leader creates a stream
-                rc = create_context(&c, &cfg, k > 0 && ctxs[0] ? ctxs[0]->stream : nullptr);
-                owned.emplace_back(c);
-                if (!rc)
-                    rc = nb_set_state(c, in.qx, in.qy, in.qz, in.vx, in.vy, in.vz,
-                                      s->zero_devices ? in.m_no_devices->data() : in.m, in.is_device);
-                ctxs[k] = c;
-                scns[k] = s->scn;
-            }
-            const nb_context* failed = (rc && !owned.empty()) ? owned.back().get() : nullptr;  // set-up failure
-            if (in.stamp) in.stamp("contexts created, state uploaded");
-            if (!rc) {
-                rc = nb_run_scenarios_batched(ctxs, scns, ress, cnt);
-                if (in.stamp) in.stamp("batched scenarios returned");
-                if (rc) failed = ctxs[0];  // the batch reports through its leader
-            }
-            for (int k = 0; k < cnt; ++k) {
-                if (failed) snprintf(slots[at + k]->err, sizeof slots[at + k]->err, "%s", nb_last_error(failed));
-                slots[at + k]->rc = rc;
-                slots[at + k]->res = ress[k];
-                slots[at + k]->ran = true;
-            }
-            if (rc) return;
-        }
-    } catch (...) {
-        for (SolveSlot* s : slots)
-            if (!s->ran) s->rc = NB_ERR_NOMEM;
-    }
-}
-
-// groups[g] runs on gpus[g]: inline for one GPU, one host thread per GPU otherwise (hw5.cu:564-567,587-588)
-void run_groups(const SolveInput& in, const std::vector<int>& gpus, const std::vector<std::vector<SolveSlot*>>& groups,
-                int cap) {
-    std::vector<std::thread> ts;
-    ThreadJoiner join{ts};
-    for (size_t g = 1; g < groups.size(); ++g)
-        if (!groups[g].empty()) ts.emplace_back([&, g] { run_group(in, gpus[g], groups[g], cap); });
-    if (!groups.empty() && !groups[0].empty()) run_group(in, gpus[0], groups[0], cap);
-}
-
-int solve_impl(int n, int planet, int asteroid, const double* qx, const double* qy, const double* qz, const double* vx,
-               const double* vy, const double* vz, const double* m, const uint8_t* is_device, const int* devices,
-               int n_devices, nb_answer* out) {
-    if (n <= 0 || !qx || !qy || !qz || !vx || !vy || !vz || !m || !out) return NB_ERR_INVALID;
-    if (planet < 0 || planet >= n || asteroid < 0 || asteroid >= n) return NB_ERR_INVALID;
-    int ndev_gpu = 0;
-    if (nb_device_count(&ndev_gpu) != NB_OK) return NB_ERR_NO_DEVICE;
-    std::vector<int> gpus;
-    if (devices && n_devices > 0) gpus.assign(devices, devices + n_devices);
-    else gpus.push_back(0);
-    for (int g : gpus)
-        if (g < 0 || g >= ndev_gpu) return NB_ERR_NO_DEVICE;
-    const size_t G = gpus.size();
-
-    std::vector<int> dev_idx;
-    std::vector<double> m_no_devices(m, m + n);
-    for (int i = 0; i < n; ++i)
-        if (is_device && is_device[i]) {
-            dev_idx.push_back(i);
-            m_no_devices[(size_t)i] = 0.0;
-        }
-    const size_t D = dev_idx.size();
-    if (D > NB_MAX_WATCH) return NB_ERR_INVALID;
-    const bool trace = getenv("NB_SOLVE_TRACE") != nullptr;  // stderr timeline of the driver's phases
-    static thread_local std::chrono::steady_clock::time_point t_start;
-    t_start = std::chrono::steady_clock::now();
-    auto stamp_fn = +[](const char* what) {
-        fprintf(stderr, "[nb_solve] %8.1f ms  %s\n",
-                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(), what);
-    };
-    auto stamp = [&](const char* what) {
-        if (trace) stamp_fn(what);
-    };
-    const SolveInput in{n, planet, asteroid, qx, qy, qz, vx, vy, vz, m, is_device, &m_no_devices, trace ? stamp_fn : nullptr};
-    stamp("HIP runtime up, input checked");
-
-    int cap = MAX_BATCH;  // scenarios per launch stream; NB_SOLVE_MAX_BATCH (2..8) lowers it (tests of the queueing path)
-    if (const char* e = getenv("NB_SOLVE_MAX_BATCH")) cap = std::min(MAX_BATCH, std::max(2, atoi(e)));
-
-    const int n_steps = 200000;  // nbody.cc:10
-    auto base_scn = [&](int kind) {
-        nb_scenario s{};
-        s.kind = kind;
-        s.first_step = 0;
-        s.last_step = n_steps;
-        s.planet = planet;
-        s.asteroid = asteroid;
-        s.sync_every = 2000;    // hw5.cu:72
-        s.planet_radius = 1e7;  // nbody.cc:17
-        s.missile_speed = 1e6;  // nbody.cc:18
-        return s;
-    };
-
-    // The scenarios of the program: P1 (devices massless, nbody.cc:109-122), P2 (nbody.cc:124-138) and one Problem-3 run per
-    // gravity device (hw5.cu:289-309).  Two engines, chosen by system size below:
-    //  * persistent (n <= 128): every scenario starts at step 0 in ONE launch with a workgroup per scenario — until its
-    //    missile arrives a device's run IS the P2 trajectory, so nothing waits for P2's snapshots (hw5.cu:265-287,482-489)
-    //    and the critical path of the whole program is one 200 000-step scenario;
-    //  * per-step (n > 128): replayed graphs of launches, a stream per scenario, Problem-3 runs started from P2's arrival
-    //    snapshots in arrival order.
-    // Several GPUs each take a share of the scenarios (the reference's task parallelism, hw5.cu:564-567,587-588).
-    std::vector<SolveSlot> slots(2 + D);
-    slots[0].scn = base_scn(NB_SCN_MIN_DIST);
-    slots[0].zero_devices = true;
-    slots[1].scn = base_scn(NB_SCN_FIRST_HIT);
-    slots[1].scn.n_watch = (int)D;  // arrival steps order the devices that do not fit the first wave (hw5.cu:574-585)
-    for (size_t k = 0; k < D; ++k) slots[1].scn.watch[k] = dev_idx[k];
-    slots[1].scn.flags = NB_SCN_NO_SNAPSHOT;
-    for (size_t k = 0; k < D; ++k) {
-        SolveSlot& s = slots[2 + k];
-        s.scn = base_scn(NB_SCN_MISSILE);
-        s.scn.n_watch = 1;
-        s.scn.watch[0] = dev_idx[k];
-        s.device_k = (int)k;
-    }
-    // NB_SOLVE_ENGINE=steps|persistent overrides the choice by system size (tests run small systems through both)
-    bool per_step = n > SMALL_N_MAX;
-    if (const char* e = getenv("NB_SOLVE_ENGINE")) {
-        if (!strcmp(e, "steps")) per_step = true;
-        else if (!strcmp(e, "persistent") && n <= SMALL_N_MAX) per_step = false;
-    }
-    if (per_step) {
-        for (SolveSlot& sl : slots) sl.scn.engine = 1;
-        // Per-step engine: one stream + replayed graph each for P1, for P2, and for the Problem-3 runs (at most two
-        // streams of those per GPU: four hardware queues).  A Problem-3 run is dormant until P2's monitor reports the
-        // missile's arrival at its device; it then starts from the snapshot P2 took at that step (hw5.cu:265-287,
-        // 482-489) at most one replay (1000 steps) behind, so the whole program ends one replay after P1 does.
-        // Independent streams keep the scenarios out of phase — one's latency-bound launch prologue overlaps another's
-        // pair loop — which a lock-step batch of large systems cannot (profiles/r02_scenario_batch_timing.txt).
-        CtxList list;
-        std::vector<CtxPtr>& owned = list.v;
-        auto make = [&](int gpu, bool zero_devices, nb_context** c, hipStream_t borrowed) -> int {
-            nb_config cfg;
-            nb_config_default(&cfg);
-            cfg.n = n;
-            cfg.device = gpu;
-            int rc = create_context(c, &cfg, borrowed);
-            owned.emplace_back(*c);
-            if (rc) return set_error(rc, *c ? nb_last_error(*c) : "nb_create");
-            rc = nb_set_state(*c, qx, qy, qz, vx, vy, vz, zero_devices ? m_no_devices.data() : m, is_device);
-            if (rc) return set_error(rc, nb_last_error(*c));
-            reset_monitor_host(*c);
-            return NB_OK;
-        };
-        slots[1].scn.flags = 0;  // P2 keeps the arrival snapshots its followers start from
-        // Streams: systems of a few hundred bodies leave most of the chip idle and their launch chain does not lengthen
-        // when several scenarios share a launch (measured flat up to 5 at n = 200), so everything on a GPU goes into ONE
-        // graph; from ~256 bodies on a lock-step batch pays for every member (n = 1024: 5.8 / 6.9 / 8.1 / 9.2 us per step
-        // for 1 / 2 / 3 / 4 scenarios) and P1, P2 and the Problem-3 runs get a stream each instead
-        // (profiles/r02_scenario_batch_timing.txt).  NB_SOLVE_STREAMS=merged|split overrides.
-        bool merged = n <= 256;
-        if (const char* e = getenv("NB_SOLVE_STREAMS")) merged = !strcmp(e, "merged");
-        std::vector<GraphGroup> groups(merged ? 3 * G : 2 + 2 * G);
-        std::vector<nb_context*> cs(slots.size(), nullptr);
-        // a launch stream's leader creates the stream (~8 ms each); the other scenarios of that stream borrow it
-        if (int rc = make(gpus[0], true, &cs[0], nullptr)) return rc;
-        if (int rc = make(gpus[1 % G], false, &cs[1], (merged && G == 1) ? cs[0]->stream : nullptr)) return rc;
-        GraphGroup* p2_group = nullptr;
-        int p2_slot = 0;
-        for (size_t i = 0; i < 2; ++i) {
-            GraphGroup& g = merged ? groups[3 * (i % G)] : groups[i];
-            if (!g.lead) g.lead = cs[i];
-            GraphSlot sl;
-            sl.c = cs[i];
-            sl.scn = &slots[i].scn;
-            if (i == 1) { p2_group = &g; p2_slot = (int)g.slots.size(); }
-            g.slots.push_back(sl);
-        }
-        for (size_t k = 0; k < D; ++k) {
-            const size_t gi = (2 + k) % G;  // GPU of this device's run
-            GraphGroup* g = nullptr;
-            if (merged) {  // the GPU's shared graph while it has room (8 scenarios per launch), then two overflow graphs
-                for (size_t j = 0; j < 3 && !g; ++j)
-                    if (groups[3 * gi + j].slots.size() < (size_t)MAX_BATCH) g = &groups[3 * gi + j];
-            } else {
-                g = &groups[2 + 2 * gi + (k / G) % 2];  // one of the GPU's two follower streams
-                if (g->slots.size() >= (size_t)MAX_BATCH) g = nullptr;
-            }
-            if (!g) return set_error(NB_ERR_INVALID, "too many gravity devices per stream");
-            if (int rc = make(gpus[gi], false, &cs[2 + k], g->lead ? g->lead->stream : nullptr)) return rc;
-            if (!g->lead) g->lead = cs[2 + k];
-            GraphSlot f;
-            f.c = cs[2 + k];
-            f.scn = &slots[2 + k].scn;
-            f.active = false;
-            f.parent = p2_group;
-            f.parent_slot = p2_slot;
-            f.parent_watch = (int)k;
-            g->slots.push_back(f);
-        }
-        stamp("contexts created, state uploaded");
-        std::vector<GraphGroup*> live;
-        for (GraphGroup& g : groups)
-            if (g.lead) live.push_back(&g);
-        // Problem-3 runs at a time: one per GPU, like the reference's one worker thread per GPU (hw5.cu:587-588); the
-        // others wait their turn in arrival order.  NB_SOLVE_P3_PARALLEL overrides (e.g. 16 = all at once).
-        int p3_parallel = (int)G;
-        if (const char* e = getenv("NB_SOLVE_P3_PARALLEL")) p3_parallel = std::max(1, atoi(e));
-        if (int rc = run_groups_graph(live, p3_parallel)) return set_error(rc, nb_last_error(live[0]->lead));
-        stamp(merged ? "graph-driven scenarios done (one stream per GPU)" : "graph-driven scenarios done (stream per scenario)");
-        for (GraphGroup* g : live)
-            for (GraphSlot& gs : g->slots) {
-                SolveSlot& sl = slots[(size_t)(std::find(cs.begin(), cs.end(), gs.c) - cs.begin())];
-                fill_result(gs.c, gs.scn, device_scenario(gs.c, gs.scn), gs.done_at, &sl.res);
-                sl.ran = true;
-            }
-        out->min_dist = std::sqrt(slots[0].res.min_dist2);  // nbody.cc:121 takes min of sqrt; sqrt is monotone
-        out->hit_time_step = slots[1].res.hit_step;
-        out->gravity_device_id = -1;
-        out->missile_cost = 0;
-        if (slots[1].res.hit_step == -2) return NB_OK;  // no collision: nothing to prevent (hw5.cu:547-548,568)
-        int best_arrival = std::numeric_limits<int>::max();
-        for (size_t k = 0; k < D; ++k) {
-            const nb_scenario_result& r = slots[2 + k].res;
-            // feasible: the missile arrived (before the P2 hit, else the run never started) and no hit followed
-            // (hw5.cu:512: strict <; cost is monotone in the arrival step)
-            if (r.hit_step == -2 && r.arrival_step[0] != -2 && r.steps_done == n_steps && r.arrival_step[0] < best_arrival) {
-                best_arrival = r.arrival_step[0];
-                out->gravity_device_id = dev_idx[k];
-                out->missile_cost = r.missile_cost[0];
-            }
-        }
-        return NB_OK;
-    }
-
-    const size_t first_wave = std::min(slots.size(), G * (size_t)cap);
-    {
-        std::vector<std::vector<SolveSlot*>> groups(G);
-        for (size_t i = 0; i < first_wave; ++i) groups[i % G].push_back(&slots[i]);
-        run_groups(in, gpus, groups, cap);
-    }
-    stamp("first wave of scenarios done");
-    if (slots[0].rc) return set_error(slots[0].rc, slots[0].err);
-    if (slots[1].rc) return set_error(slots[1].rc, slots[1].err);
-    out->min_dist = std::sqrt(slots[0].res.min_dist2);  // nbody.cc:121 takes min of sqrt; sqrt is monotone
-    out->hit_time_step = slots[1].res.hit_step;
-    out->gravity_device_id = -1;
-    out->missile_cost = 0;
-    if (slots[1].res.hit_step == -2) return NB_OK;  // no collision: nothing to prevent (hw5.cu:547-548,568)
-
-    // Problem 3 (hw5.cu:568-602): answer = feasible device of least cost (strict <, hw5.cu:512); cost is monotone in
-    // the arrival step, so a device can only improve on a feasible one by arriving earlier
-    int best_arrival = std::numeric_limits<int>::max();
-    int rc3 = NB_OK;
-    auto account = [&](const SolveSlot& s) {
-        if (s.rc) { rc3 = set_error(s.rc, s.err); return; }
-        if (!s.ran) return;
-        // feasible: the missile arrived (before the P2 hit, hence before any hit of this run) and no hit followed
-        if (s.res.hit_step == -2 && s.res.arrival_step[0] != -2 && s.res.arrival_step[0] < best_arrival) {
-            best_arrival = s.res.arrival_step[0];
-            out->gravity_device_id = dev_idx[(size_t)s.device_k];
-            out->missile_cost = s.res.missile_cost[0];
-        }
-    };
-    for (size_t i = 2; i < first_wave; ++i) account(slots[i]);
-
-    // devices beyond the first wave: cheapest first — ascending arrival step on the P2 trajectory (hw5.cu:574-585) —
-    // and stop as soon as no remaining device can beat a feasible one (PROBLEM3_BREAK, hw5.cu:490-493)
-    std::vector<size_t> rest;
-    for (size_t i = first_wave; i < slots.size(); ++i)
-        if (slots[1].res.arrival_step[slots[i].device_k] != -2) rest.push_back(i);  // never arrives before the hit: fails
-    std::sort(rest.begin(), rest.end(), [&](size_t a, size_t b) {
-        return slots[1].res.arrival_step[slots[a].device_k] < slots[1].res.arrival_step[slots[b].device_k];
-    });
-    size_t at = 0;
-    while (at < rest.size() && !rc3) {
-        std::vector<std::vector<SolveSlot*>> groups(G);
-        size_t taken = 0;
-        for (; at < rest.size() && taken < G * (size_t)cap; ++at) {
-            if (slots[1].res.arrival_step[slots[rest[at]].device_k] >= best_arrival) { at = rest.size(); break; }
-            groups[taken % G].push_back(&slots[rest[at]]);
-            ++taken;
-        }
-        if (!taken) break;
-        run_groups(in, gpus, groups, cap);
-        for (auto& g : groups)
-            for (SolveSlot* s : g) account(*s);
-    }
-    return rc3;
-}
-
-}  // namespace
-
-extern "C" {
-
-int nb_solve(int n, int planet, int asteroid, const double* qx, const double* qy, const double* qz,
-             const double* vx, const double* vy, const double* vz, const double* m, const uint8_t* is_device,
-             const int* devices, int n_devices, nb_answer* out) {
-    try {
-        return solve_impl(n, planet, asteroid, qx, qy, qz, vx, vy, vz, m, is_device, devices, n_devices, out);
-    } catch (...) {  // bad_alloc / system_error from the host-side containers and threads
-        return NB_ERR_NOMEM;
-    }
-}
-
+// ---------------------------------------------------------------- raw launches on caller-owned HBM
 // ---------------------------------------------------------------- raw launches on caller-owned HBM
 static int check_launch(const nb_launch_f32* a, bool accel_only) {
     if (!a || !a->src || a->n_src <= 0 || a->n_tgt <= 0 || a->tgt_off < 0) return NB_ERR_INVALID;

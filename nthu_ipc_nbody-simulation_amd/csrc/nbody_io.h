@@ -22,6 +22,7 @@ bool read_input(const char* filename, Input& in);
 // read_state_input needs planet/asteroid recorded in the header (version 2) and links against libnbody_amd.
 bool is_state_file(const char* filename);
 bool read_state_input(const char* filename, Input& in);
+const char* state_input_error();  // why the last read_state_input returned false
 
 // three lines, scientific with 16 digits after the point (digits10 + 1): nbody.cc:43-48 == hw5.cu:135-140
 bool write_output(const char* filename, double min_dist, int hit_time_step, int gravity_device_id,

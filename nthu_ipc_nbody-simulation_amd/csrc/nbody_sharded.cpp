@@ -14,6 +14,14 @@
 // RCCL is loaded with dlopen when the first sharded system is created, so bin/hw5 and single-GPU users of libnbody_amd
 // never pay for (or depend on) librccl.  nbody_amd.distributed is the second host of the same scheme: one process per
 // GPU with torch.distributed.
+//
+// Two exchanges implement the all-gather behind the same stream/event protocol (`exchange_rccl`, `exchange_copy`):
+//   RCCL (default)            ncclAllGather in a group call — a kernel per GPU that occupies CUs while it runs;
+//   NB_SHARDED_COPY_EXCHANGE  P-1 peer copies per GPU (hipMemcpyPeerAsync: the SDMA engines push the shards over xGMI,
+//                             no CU is taken from the force kernel, nothing to load).  Each destination PULLS the other
+//                             ranks' slots on its own exchange stream once the owner's `stepped` event has fired.  It is
+//                             also the only exchange that accepts the same ordinal more than once in `devices` (ranks
+//                             that share a GPU), which is how a one-GPU box runs every P > 1 line of step_once.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -93,7 +101,8 @@ struct nb_sharded {
     int cur = 0;
     bool have_state = false;
     bool gather_pending = false;  // overlap: the all-gather of pos[cur] is still in flight on the comm streams
-    const RcclApi* api = nullptr;
+    bool ready = false;  // creation went through: streams, buffers and (RCCL) communicators exist
+    const RcclApi* api = nullptr;  // null with NB_SHARDED_COPY_EXCHANGE
     char err[512] = {0};
 };
 
@@ -119,6 +128,7 @@ int fail(nb_sharded* s, int code, const char* what, const char* detail) {
 
 bool acc64(const nb_sharded* s) { return s->precision == NB_F32_ACC64; }
 bool overlapped(const nb_sharded* s) { return (s->flags & NB_SHARDED_OVERLAP) && s->P > 1; }
+bool copy_exchange(const nb_sharded* s) { return (s->flags & NB_SHARDED_COPY_EXCHANGE) != 0; }
 
 int64_t workspace_bytes(const nb_sharded* s) { return nb_workspace_bytes_f32(s->per, acc64(s)); }
 
@@ -145,25 +155,12 @@ int launch_phase(nb_sharded* s, Rank& k, int64_t src_begin, int64_t src_end, int
     return NB_OK;
 }
 
-int step_once(nb_sharded* s) {
-    const bool ov = overlapped(s);
-    for (Rank& k : s->rank) {
-        SH_HIP(s, hipSetDevice(k.device));
-        if (!ov) {
-            if (int rc = launch_phase(s, k, 0, 0, F32_PHASE_WHOLE)) return rc;
-            continue;
-        }
-        // own shard first: final since this GPU's previous launch (or the initial upload); no exchange needed
-        const int64_t lo = k.lo, hi = k.lo + s->per;
-        if (int rc = launch_phase(s, k, lo, hi, F32_PHASE_FIRST)) return rc;
-        if (s->gather_pending) SH_HIP(s, hipStreamWaitEvent(k.stream, k.gathered, 0));  // the other shards have landed
-        if (lo > 0)
-            if (int rc = launch_phase(s, k, 0, lo, hi < s->n ? F32_PHASE_MIDDLE : F32_PHASE_LAST)) return rc;
-        if (hi < s->n)
-            if (int rc = launch_phase(s, k, hi, s->n, F32_PHASE_LAST)) return rc;
-    }
-    // exchange: every GPU contributes its own slot of the array its kernels have just written
-    const int nxt = s->cur ^ 1;
+// ---- the exchange step: all-gather of pos[nxt], every rank's own slot into every other rank's copy of the array.
+// Protocol shared by both implementations (ov = overlapped step): the gather runs on the rank's exchange stream — its
+// compute stream, or with ov its comm_stream, which first waits for the rank's `stepped` event (own slot written) and
+// afterwards records `gathered` (remote slots landed) for the next step's remote-source phases to wait on.
+
+int exchange_rccl(nb_sharded* s, int nxt, bool ov) {
     if (ov)
         for (Rank& k : s->rank) {
             SH_HIP(s, hipSetDevice(k.device));
@@ -186,6 +183,56 @@ int step_once(nb_sharded* s) {
             SH_HIP(s, hipSetDevice(k.device));
             SH_HIP(s, hipEventRecord(k.gathered, k.comm_stream));
         }
+    return NB_OK;
+}
+
+// Copy-engine all-gather: destination rank q pulls slot r from rank r's array once r's step kernels have finished.
+// Buffer reuse needs no further event: rank r next writes this slot of this array two steps later, behind an exchange
+// that waited for q's `stepped` of the step in between, which q's stream reaches only after these copies (stream order,
+// or with ov through q's `gathered`).
+int exchange_copy(nb_sharded* s, int nxt, bool ov) {
+    for (Rank& k : s->rank) {
+        SH_HIP(s, hipSetDevice(k.device));
+        SH_HIP(s, hipEventRecord(k.stepped, k.stream));
+    }
+    const size_t bytes = (size_t)s->per * sizeof(float4);
+    for (Rank& q : s->rank) {
+        SH_HIP(s, hipSetDevice(q.device));
+        hipStream_t xs = ov ? q.comm_stream : q.stream;
+        if (ov) SH_HIP(s, hipStreamWaitEvent(xs, q.stepped, 0));
+        for (Rank& r : s->rank) {
+            if (&r == &q) continue;
+            SH_HIP(s, hipStreamWaitEvent(xs, r.stepped, 0));
+            if (r.device == q.device)
+                SH_HIP(s, hipMemcpyAsync(q.pos[nxt] + r.lo, r.pos[nxt] + r.lo, bytes, hipMemcpyDeviceToDevice, xs));
+            else
+                SH_HIP(s, hipMemcpyPeerAsync(q.pos[nxt] + r.lo, q.device, r.pos[nxt] + r.lo, r.device, bytes, xs));
+        }
+        if (ov) SH_HIP(s, hipEventRecord(q.gathered, xs));
+    }
+    return NB_OK;
+}
+
+int step_once(nb_sharded* s) {
+    const bool ov = overlapped(s);
+    for (Rank& k : s->rank) {
+        SH_HIP(s, hipSetDevice(k.device));
+        if (!ov) {
+            if (int rc = launch_phase(s, k, 0, 0, F32_PHASE_WHOLE)) return rc;
+            continue;
+        }
+        // own shard first: final since this GPU's previous launch (or the initial upload); no exchange needed
+        const int64_t lo = k.lo, hi = k.lo + s->per;
+        if (int rc = launch_phase(s, k, lo, hi, F32_PHASE_FIRST)) return rc;
+        if (s->gather_pending) SH_HIP(s, hipStreamWaitEvent(k.stream, k.gathered, 0));  // the other shards have landed
+        if (lo > 0)
+            if (int rc = launch_phase(s, k, 0, lo, hi < s->n ? F32_PHASE_MIDDLE : F32_PHASE_LAST)) return rc;
+        if (hi < s->n)
+            if (int rc = launch_phase(s, k, hi, s->n, F32_PHASE_LAST)) return rc;
+    }
+    // exchange: every GPU contributes its own slot of the array its kernels have just written
+    const int nxt = s->cur ^ 1;
+    if (int rc = copy_exchange(s) ? exchange_copy(s, nxt, ov) : exchange_rccl(s, nxt, ov)) return rc;
     s->gather_pending = ov;
     s->cur = nxt;
     return NB_OK;
@@ -232,7 +279,8 @@ int create_impl(nb_sharded** out, const int* devices, int n_devices, int64_t n, 
     for (int i = 0; i < n_devices; ++i) {
         if (devices[i] < 0 || devices[i] >= ndev) return NB_ERR_NO_DEVICE;
         for (int j = 0; j < i; ++j)
-            if (devices[j] == devices[i]) return fail(nullptr, NB_ERR_INVALID, "nb_sharded_create", "a device is listed twice (RCCL: one rank per GPU)");
+            if (devices[j] == devices[i] && !(flags & NB_SHARDED_COPY_EXCHANGE))
+                return fail(nullptr, NB_ERR_INVALID, "nb_sharded_create", "a device is listed twice (RCCL: one rank per GPU; NB_SHARDED_COPY_EXCHANGE lets ranks share a GPU)");
     }
     nb_sharded* s = new (std::nothrow) nb_sharded();
     if (!s) return NB_ERR_NOMEM;
@@ -245,8 +293,10 @@ int create_impl(nb_sharded** out, const int* devices, int n_devices, int64_t n, 
     s->G = G;
     s->eps = eps;
     s->dt = dt;
-    s->api = rccl(s->err, sizeof s->err);
-    if (!s->api) return NB_ERR_HIP;
+    if (!copy_exchange(s)) {
+        s->api = rccl(s->err, sizeof s->err);
+        if (!s->api) return NB_ERR_HIP;
+    }
     s->rank.resize((size_t)n_devices);
     const size_t N = (size_t)n, per = (size_t)s->per;
     for (int r = 0; r < n_devices; ++r) {
@@ -258,9 +308,9 @@ int create_impl(nb_sharded** out, const int* devices, int n_devices, int64_t n, 
         SH_HIP(s, hipStreamCreateWithFlags(&k.stream, hipStreamNonBlocking));
         if (overlapped(s)) {
             SH_HIP(s, hipStreamCreateWithFlags(&k.comm_stream, hipStreamNonBlocking));
-            SH_HIP(s, hipEventCreateWithFlags(&k.stepped, hipEventDisableTiming));
             SH_HIP(s, hipEventCreateWithFlags(&k.gathered, hipEventDisableTiming));
         }
+        if (overlapped(s) || copy_exchange(s)) SH_HIP(s, hipEventCreateWithFlags(&k.stepped, hipEventDisableTiming));
         SH_HIP(s, hipMalloc(&k.pos[0], N * sizeof(float4)));
         SH_HIP(s, hipMalloc(&k.pos[1], N * sizeof(float4)));
         SH_HIP(s, hipMalloc(&k.vel, per * sizeof(float4)));
@@ -273,9 +323,22 @@ int create_impl(nb_sharded** out, const int* devices, int n_devices, int64_t n, 
         if (overlapped(s) || plan_f32(s->per, s->n, k.n_cus, 0, 0, true).j_split > 1)
             SH_HIP(s, hipMalloc(&k.ws, (size_t)workspace_bytes(s)));
     }
-    std::vector<ncclComm_t> comms((size_t)n_devices);
-    SH_NCCL(s, s->api->CommInitAll(comms.data(), n_devices, devices));
-    for (int r = 0; r < n_devices; ++r) s->rank[(size_t)r].comm = comms[(size_t)r];
+    if (copy_exchange(s)) {
+        // direct xGMI copies between distinct GPUs; without peer access the runtime stages through the host, which is
+        // slower but still correct, so a refusal here is not an error
+        for (Rank& q : s->rank)
+            for (Rank& r : s->rank)
+                if (q.device != r.device) {
+                    SH_HIP(s, hipSetDevice(q.device));
+                    hipError_t e = hipDeviceEnablePeerAccess(r.device, 0);
+                    if (e != hipSuccess) (void)hipGetLastError();  // already enabled / not supported
+                }
+    } else {
+        std::vector<ncclComm_t> comms((size_t)n_devices);
+        SH_NCCL(s, s->api->CommInitAll(comms.data(), n_devices, devices));
+        for (int r = 0; r < n_devices; ++r) s->rank[(size_t)r].comm = comms[(size_t)r];
+    }
+    s->ready = true;
     return NB_OK;
 }
 
@@ -375,7 +438,7 @@ const char* nb_sharded_last_error(const nb_sharded* s) { return s ? s->err : g_e
 int nb_sharded_set_state(nb_sharded* s, const double* qx, const double* qy, const double* qz, const double* vx,
                          const double* vy, const double* vz, const double* m) {
     if (!s || !qx || !qy || !qz || !vx || !vy || !vz || !m) return NB_ERR_INVALID;
-    if (s->rank.empty() || !s->rank.back().comm) return NB_ERR_STATE;  // creation failed half way
+    if (!s->ready) return NB_ERR_STATE;  // creation failed half way
     try {
         return set_state_impl(s, qx, qy, qz, vx, vy, vz, m);
     } catch (...) {

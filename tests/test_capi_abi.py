@@ -20,14 +20,15 @@ def test_header_and_binding_agree(nb):
     L = nb.capi.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.nb_abi_version() == 2
+    assert L.nb_abi_version() == 3
 
 
 def test_struct_layouts_match_header(nb):
     import ctypes as C
     c = nb.capi
-    assert C.sizeof(c.NbConfig) == 40
-    assert C.sizeof(c.NbScenario) == 6 * 4 + 16 * 4 + 4 * 4 + 16  # ints, watch[], sync_every/engine/flags/reserved, 2 doubles
+    assert C.sizeof(c.NbConfig) == 6 * 4 + 3 * 8
+    assert C.sizeof(c.NbScenario) == 6 * 4 + 16 * 4 + 4 * 4 + 16  # ints, watch[], sync_every/engine/flags/graph_chunk, 2 doubles
+    assert C.sizeof(c.NbSolveOptions) == 8 * 4
     assert C.sizeof(c.NbStateHeader) == 8 + 4 * 4 + 3 * 8
     assert C.sizeof(c.NbAnswer) == 24
     assert C.sizeof(c.NbLaunchF32) == 7 * 8 + 4 * 8 + 8 * 4 + 3 * 8
@@ -70,8 +71,17 @@ def test_state_file_header_errors(nb, tmp_path):
         nb.capi.state_file_info(str(bad))
     import struct
     good = tmp_path / "hdr.nbst"
-    good.write_bytes(b"NBODYST1" + struct.pack("<qiiddd", 7, 0, 123, 6.674e-11, 1e-3, 60.0))
+    hdr = b"NBODYST1" + struct.pack("<qiiddd", 7, 0, 123, 6.674e-11, 1e-3, 60.0)
+    good.write_bytes(hdr + bytes(7 * 57))
     assert nb.capi.state_file_info(str(good)) == (7, 0, 123)
+    # a header that announces more bodies than the file holds is refused before anyone sizes a buffer from it
+    good.write_bytes(hdr + bytes(7 * 57 - 1))
+    with pytest.raises(nb.capi.NBodyError, match="truncated"):
+        nb.capi.state_file_info(str(good))
+    huge = tmp_path / "huge.nbst"
+    huge.write_bytes(b"NBODYST1" + struct.pack("<qiiddd", 1 << 40, 0, 0, 6.674e-11, 1e-3, 60.0) + bytes(1000))
+    with pytest.raises(nb.capi.NBodyError, match="truncated"):
+        nb.capi.read_state_file(str(huge))
     # context-free failures leave their text in the calling thread's nb_last_error(NULL)
     with pytest.raises(nb.capi.NBodyError, match="not an NBODYST"):
         nb.capi.read_state_file(str(bad))
@@ -125,8 +135,9 @@ def test_header_is_plain_c_and_links_from_c(nb, tmp_path):
 #include "nbody_amd.h"
 int main(void) {
     nb_config cfg;
-    nb_scenario scn; nb_scenario_result res; nb_answer ans; nb_launch_f32 l; nb_state_header h;
-    (void)scn; (void)res; (void)ans; (void)l;
+    nb_scenario scn; nb_scenario_result res; nb_answer ans; nb_launch_f32 l; nb_state_header h; nb_solve_options o;
+    (void)scn; (void)res; (void)ans; (void)l; (void)o;
+    if (sizeof(nb_config) != 48 || sizeof(nb_solve_options) != 32) return 7;
     if (nb_read_state_file("/nonexistent/x.nbst", &h, 0, 0, 0, 0, 0, 0, 0, 0, 0) != NB_ERR_IO) return 5;
     if (nb_last_error(0)[0] == 0) return 6;
     if (nb_abi_version() != NB_ABI_VERSION) return 1;

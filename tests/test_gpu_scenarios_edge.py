@@ -60,28 +60,40 @@ CASES = {
 
 @pytest.mark.parametrize("engine", ["persistent", "steps", "steps-all-at-once"])
 @pytest.mark.parametrize("name", list(CASES))
-def test_solve_matches_oracle(nb, oracle, name, engine, tmp_path, monkeypatch):
+def test_solve_matches_oracle(nb, oracle, name, engine, tmp_path):
     """engine: the whole program through the persistent engine (what these small systems get by default), through the
     per-step engine (graph replay, a stream per scenario, Problem-3 runs queued cheapest-first), and through it with every
     Problem-3 run started as soon as its missile arrives."""
-    monkeypatch.setenv("NB_SOLVE_ENGINE", engine.split("-")[0])
-    if engine.endswith("all-at-once"):
-        monkeypatch.setenv("NB_SOLVE_P3_PARALLEL", "16")
+    opts = dict(engine=engine.split("-")[0], p3_parallel=16 if engine.endswith("all-at-once") else 0)
     s = _system(oracle, CASES[name])
     ref_min = oracle.problem1(s)
     ref, details = oracle.problem23(s)
-    got = nb.capi.solve(s.n, s.planet, s.asteroid, s.q, s.v, s.m, s.is_device)
+    got = nb.capi.solve(s.n, s.planet, s.asteroid, s.q, s.v, s.m, s.is_device, **opts)
     assert got[1] == ref.hit_time_step and got[2] == ref.gravity_device_id, (name, got, details)
     assert got[3] == ref.missile_cost
     assert abs(got[0] - ref_min) <= 1e-9 * ref_min
     # and through the CLI, against the oracle's CLI
     inp, out, out_ref = tmp_path / "c.in", tmp_path / "c.out", tmp_path / "c.ref"
     _write_in(s, inp)
-    subprocess.run([os.path.join(ROOT, "bin", "hw5"), str(inp), str(out)], check=True, timeout=300)
+    env = dict(os.environ, NB_SOLVE_ENGINE=opts["engine"], NB_SOLVE_P3_PARALLEL=str(opts["p3_parallel"]))  # hw5 maps them
+    subprocess.run([os.path.join(ROOT, "bin", "hw5"), str(inp), str(out)], check=True, timeout=300, env=env)
     oracle.solve_file(str(inp), str(out_ref))
     a, b = out.read_text().split("\n"), out_ref.read_text().split("\n")
     assert a[1:] == b[1:], (name, a, b)            # hit step, device id and cost: exactly
     assert abs(float(a[0]) - float(b[0])) <= 1e-9 * float(b[0])
+
+
+@pytest.mark.parametrize("cap", [2, 3, 4])
+def test_arrival_tie_in_the_queued_wave(nb, oracle, cap):
+    """six_devices_with_a_tie through the persistent engine with max_batch below 2 + D: the devices beyond the first
+    wave are queued by arrival step, and the two that arrive at step 4 (one useless, one feasible) must resolve exactly
+    as in the oracle and in the per-step engine — ties keep index order (stable sort, strict < in the selection)."""
+    s = _system(oracle, CASES["six_devices_with_a_tie"])
+    ref, _ = oracle.problem23(s)
+    got = nb.capi.solve(s.n, s.planet, s.asteroid, s.q, s.v, s.m, s.is_device, engine="persistent", max_batch=cap)
+    assert (got[1], got[2], got[3]) == (ref.hit_time_step, ref.gravity_device_id, ref.missile_cost)
+    steps = nb.capi.solve(s.n, s.planet, s.asteroid, s.q, s.v, s.m, s.is_device, engine="steps")
+    assert steps[1:] == got[1:]
 
 
 def test_expected_shapes_of_the_edge_cases(oracle):

@@ -1,6 +1,9 @@
-"""nb_sharded_*: the index-sharded stepper behind the C ABI (one process, P GPUs, in-place ncclAllGather per GPU per
-step).  A one-GPU box can run P = 1 through exactly that code — RCCL communicator, all-gather call and all — where the
-trajectory must equal nb_step's bit for bit; P > 1 is the driver's multi-GPU run (bin/nbody_bench N steps warmup f32 P)."""
+"""nb_sharded_*: the index-sharded stepper behind the C ABI (one process, P GPUs, in-place all-gather per GPU per
+step).  A one-GPU box runs P = 1 through the RCCL code (communicator, all-gather call and all), where the trajectory
+must equal nb_step's bit for bit, and P = 2, 4 through NB_SHARDED_COPY_EXCHANGE with every rank on device 0: the same
+step_once — per-rank streams, stepped/gathered events, the FIRST/MIDDLE/LAST phase order of the overlapped step, the
+ping-pong and the all-gather protocol — against nb_step AND against the oracle.  RCCL with P > 1 is the driver's
+multi-GPU run (bin/nbody_bench N steps warmup f32 P)."""
 import json
 import os
 import subprocess
@@ -36,6 +39,93 @@ def test_one_device_equals_nb_step_bitwise(nb, precision, n):
     assert np.abs(q1 - q).max() > 1e-6
 
 
+def _oracle_one_step(oracle, syn, q, v, m, dt, rows, f32_start):
+    """q,v of `rows` after ONE run_step from the oracle's fp64 accelerations (samples/nbody.cc:56-88)."""
+    gm = (syn.G * m).astype(np.float32).astype(np.float64) / syn.G  # the kernels round G*m once to fp32
+    q0 = q.astype(np.float32).astype(np.float64) if f32_start else q
+    v0 = v.astype(np.float32).astype(np.float64) if f32_start else v
+    # sources are always the fp32-rounded positions (also in NB_F32_ACC64: the pair loop reads the float4 copies)
+    a = np.concatenate([oracle.accel_rows(q.astype(np.float32).astype(np.float64), gm, syn.G, syn.EPS, lo, lo + cnt)
+                        for lo, cnt in rows], axis=1)
+    idx = np.concatenate([np.arange(lo, lo + cnt) for lo, cnt in rows])
+    v1 = v0[:, idx] + a * dt
+    return idx, q0[:, idx] + v1 * dt, v1
+
+
+@pytest.mark.parametrize("precision", ["NB_F32", "NB_F32_ACC64"])
+@pytest.mark.parametrize("overlap", [False, True])
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_ranks_sharing_one_gpu_follow_nb_step_and_the_oracle(nb, oracle, ranks, overlap, precision):
+    """Every P > 1 line of the native host on one GPU (copy exchange, all ranks on device 0), N = 16384:
+    3 steps vs the unsharded nb_step (same arithmetic, sums cut at other places: fp32 rounding), and the first step
+    vs oracle rows taken from every rank's shard."""
+    c, syn = nb.capi, nb.synthetic
+    prec = getattr(c, precision)
+    n, dt = 16384, 1e-2
+    q, v, m = syn.bodies(n)
+    with c.Context(n, prec, 0, G=syn.G, eps=syn.EPS, dt=dt) as ctx:
+        ctx.set_state(q, v, m)
+        ctx.step(1, 3)
+        q_ref, v_ref = ctx.get_state()
+    with c.Sharded(n, [0] * ranks, prec, G=syn.G, eps=syn.EPS, dt=dt, overlap=overlap, exchange="copy") as sh:
+        info = sh.info()
+        assert info["devices"] == ranks and info["targets_per_device"] == n // ranks
+        sh.set_state(q, v, m)
+        sh.step(1)
+        q1, v1 = sh.get_state()
+        sh.step(2)
+        q3, v3 = sh.get_state()
+    per = n // ranks
+    rows = [(r * per + off, 8) for r in range(ranks) for off in (0, per // 2 + 3, per - 8)]
+    idx, qo, vo = _oracle_one_step(oracle, syn, q, v, m, dt, rows, f32_start=(precision == "NB_F32"))
+    # |a| = O(1), dt = 1e-2: a force error of 1e-5 * sum|a_ij| would move v by 1e-7 * O(10); fp32 state rounds at 6e-8
+    tol_v, tol_q = (2e-6, 2e-7) if precision == "NB_F32" else (2e-6, 3e-8)
+    assert np.abs(v1[:, idx] - vo).max() < tol_v, np.abs(v1[:, idx] - vo).max()
+    assert np.abs(q1[:, idx] - qo).max() < tol_q, np.abs(q1[:, idx] - qo).max()
+    assert np.abs(q3 - q_ref).max() < (5e-7 if precision == "NB_F32" else 1e-7), np.abs(q3 - q_ref).max()
+    assert np.abs(v3 - v_ref).max() < 1e-5, np.abs(v3 - v_ref).max()
+    assert np.abs(q3 - q).max() > 1e-6  # it moved
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_overlap_flag_changes_nothing_but_the_schedule(nb, overlap):
+    """Two ranks on one GPU, whole step vs own-shard-first phases: the same sums cut at another place."""
+    c, syn = nb.capi, nb.synthetic
+    n = 2 * 8192
+    q, v, m = syn.bodies(n)
+    out = []
+    for ov in (False, overlap):
+        with c.Sharded(n, [0, 0], c.NB_F32_ACC64, G=syn.G, eps=syn.EPS, dt=1e-2, overlap=ov, exchange="copy") as sh:
+            sh.set_state(q, v, m)
+            sh.step(4)
+            out.append(sh.get_state())
+    if not overlap:  # the same schedule twice: bit for bit (stream/event protocol is deterministic in its results)
+        assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    else:
+        assert np.abs(out[0][0] - out[1][0]).max() < 1e-9 and np.abs(out[0][1] - out[1][1]).max() < 1e-7
+
+
+def test_ragged_shards(nb, oracle):
+    """n/P not a multiple of the 256-body tile: the plain step takes it (tail lanes, ragged last source tile), the
+    overlapped step — which cuts the sources at shard boundaries — refuses it at creation."""
+    c, syn = nb.capi, nb.synthetic
+    per = 4096 + 37
+    n = 2 * per
+    q, v, m = syn.bodies(n)
+    with c.Sharded(n, [0, 0], c.NB_F32, G=syn.G, eps=syn.EPS, dt=1e-2, exchange="copy") as sh:
+        sh.set_state(q, v, m)
+        sh.step(1)
+        q1, v1 = sh.get_state()
+    idx, qo, vo = _oracle_one_step(oracle, syn, q, v, m, 1e-2, [(0, 8), (per - 8, 16), (n - 8, 8)], f32_start=True)
+    assert np.abs(v1[:, idx] - vo).max() < 2e-6 and np.abs(q1[:, idx] - qo).max() < 2e-7
+    with pytest.raises(c.NBodyError) as e:
+        c.Sharded(n, [0, 0], c.NB_F32, eps=syn.EPS, overlap=True, exchange="copy")
+    assert e.value.code == c.NB_ERR_INVALID and "multiple of 256" in str(e.value)
+    with pytest.raises(c.NBodyError) as e:
+        c.Sharded(n + 1, [0, 0], c.NB_F32, eps=syn.EPS, exchange="copy")
+    assert e.value.code == c.NB_ERR_INVALID and "divisible" in str(e.value)
+
+
 def test_refusals(nb):
     c = nb.capi
     for kw, text in ((dict(devices=[0, 0]), "listed twice"), (dict(devices=[0], precision=c.NB_F64), "precision"),
@@ -60,3 +150,10 @@ def test_compiled_host_runs_the_sharded_path(nb):
     assert p.returncode == 0, p.stderr
     r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])  # (libdrm may print a notice first)
     assert r["gpus"] == 1 and r["n"] == 32768 and r["pairs_per_s"] > 1e11 and r["targets_per_gpu"] == 32768
+    # four ranks on the one GPU, overlapped, copy exchange
+    p = subprocess.run([os.path.join(ROOT, "bin", "nbody_bench"), "65536", "3", "1", "f32", "4", "1", "copy-one-gpu"],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert r["gpus"] == 4 and r["exchange"] == "copy-one-gpu" and r["overlap"] == 1 and r["targets_per_gpu"] == 16384
+    assert r["pairs_per_s"] > 1e11

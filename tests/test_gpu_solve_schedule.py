@@ -19,32 +19,68 @@ def _solve_case(nb, oracle, case, **kw):
     return ("%.16e\n%d\n%d %.16e\n" % got), gold[4]
 
 
-@pytest.mark.parametrize("case", ["b30", "b90", "b200"])
+@pytest.mark.parametrize("case", ["b30", "b90", "b200", "b512", "b1024"])
 def test_solve_spread_over_two_device_slots(nb, oracle, case):
     """devices=[0,0]: the multi-GPU code path (one host thread and launch stream per listed device, scenarios dealt
-    round-robin: P1 -> first, P2 -> second, ...) on the one GPU of the box.  Answers byte-identical to the goldens."""
+    round-robin: P1 -> first, P2 -> second, ...) on the one GPU of the box.  b512 / b1024 take the split layout (n > 256:
+    a stream per scenario, two follower streams per device slot).  Answers byte-identical to the goldens."""
     text, gold = _solve_case(nb, oracle, case, devices=[0, 0])
     assert text == gold
 
 
+@pytest.mark.parametrize("case,streams", [("b200", "merged"), ("b200", "split"), ("b512", "split"), ("b1024", "split")])
+def test_cross_gpu_handoff_of_the_arrival_snapshot(nb, case, streams, tmp_path):
+    """hw5.cu:482-484 uploads P2's arrival snapshot on the OTHER GPU before a Problem-3 run starts there.  Here that is
+    activate_follower's host-staged branch; with devices = 0,0 both slots are one physical GPU, so the hand-off is forced
+    through host memory for runs that sit on another device slot than P2 (nb_solve_options.handoff, NB_SOLVE_HANDOFF=host
+    in the CLI).  The trace must show the branch was taken, and the three lines must still be the golden ones."""
+    out = str(tmp_path / "out")
+    env = dict(os.environ, NB_DEVICES="0,0", NB_SOLVE_HANDOFF="host", NB_SOLVE_TRACE="1", NB_SOLVE_STREAMS=streams,
+               NB_SOLVE_P3_PARALLEL="16")  # every device's run starts, whatever its rank in the queue
+    p = subprocess.run([os.path.join(ROOT, "bin", "hw5"), case_path(case, "in"), out], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert p.returncode == 0, p.stderr
+    starts = [ln for ln in p.stderr.splitlines() if ln.startswith("[followers]")]
+    assert any("host-staged" in ln for ln in starts), p.stderr   # P2 is on slot 1; devices 0, 2, ... run on slot 0
+    assert any("device copy" in ln for ln in starts) or len(starts) == 1, p.stderr
+    assert open(out).read() == read_golden(case)[4]
+    # and without the hook nothing is staged on a one-GPU box
+    env.pop("NB_SOLVE_HANDOFF")
+    p = subprocess.run([os.path.join(ROOT, "bin", "hw5"), case_path(case, "in"), out], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert p.returncode == 0 and "host-staged" not in p.stderr and "[followers]" in p.stderr
+    assert open(out).read() == read_golden(case)[4]
+
+
+def test_solve_options_are_validated(nb, oracle):
+    c = nb.capi
+    s = oracle.read_input(case_path("b20", "in"))
+    for kw in (dict(max_batch=1), dict(max_batch=9), dict(graph_chunk=3), dict(graph_chunk=5000), dict(p3_parallel=-1),
+               dict(handoff=7)):
+        with pytest.raises(c.NBodyError) as e:
+            c.solve(s.n, s.planet, s.asteroid, s.q, s.v, s.m, s.is_device, **kw)
+        assert e.value.code == c.NB_ERR_INVALID and "nb_solve_options" in str(e.value)
+    big = oracle.read_input(case_path("b200", "in"))
+    with pytest.raises(c.NBodyError) as e:
+        c.solve(big.n, big.planet, big.asteroid, big.q, big.v, big.m, big.is_device, engine="persistent")
+    assert e.value.code == c.NB_ERR_INVALID
+
+
 @pytest.mark.parametrize("streams,p3", [("merged", "1"), ("split", "1"), ("split", "16")])
 @pytest.mark.parametrize("case", ["b200", "b512"])
-def test_solve_stream_layouts_agree(nb, oracle, case, streams, p3, monkeypatch):
+def test_solve_stream_layouts_agree(nb, oracle, case, streams, p3):
     """The per-step engine's two stream layouts (one shared graph per GPU / a stream per scenario) and both Problem-3
     policies (queued cheapest-first / all at once) give the golden answers."""
-    monkeypatch.setenv("NB_SOLVE_STREAMS", streams)
-    monkeypatch.setenv("NB_SOLVE_P3_PARALLEL", p3)
-    text, gold = _solve_case(nb, oracle, case)
+    text, gold = _solve_case(nb, oracle, case, streams=streams, p3_parallel=int(p3))
     assert text == gold
 
 
 @pytest.mark.parametrize("case,cap", [("b30", 2), ("b80", 3), ("b200", 4)])
-def test_solve_queue_beyond_one_stream(nb, oracle, case, cap, monkeypatch):
-    """NB_SOLVE_MAX_BATCH < 2 + D: the devices that do not fit the first wave are queued in ascending arrival step
+def test_solve_queue_beyond_one_stream(nb, oracle, case, cap):
+    """nb_solve_options.max_batch < 2 + D: the devices that do not fit the first wave are queued in ascending arrival step
     (hw5.cu:574-585) and skipped once they cannot beat a feasible one (hw5.cu:490-493); the answer does not change.
     b80: device 76 (arrival 151213) is the answer; 77-79 arrive later."""
-    monkeypatch.setenv("NB_SOLVE_MAX_BATCH", str(cap))
-    text, gold = _solve_case(nb, oracle, case)
+    text, gold = _solve_case(nb, oracle, case, max_batch=cap)
     assert text == gold
 
 
@@ -164,7 +200,16 @@ def test_cli_binary_input(nb, case, tmp_path):
     plain = str(tmp_path / "plain.nbst")
     c.write_state_file(plain, q, v, m, dev)
     p = subprocess.run([os.path.join(ROOT, "bin", "hw5"), plain, out], capture_output=True)
-    assert p.returncode == 1 and b"cannot read state file" in p.stderr
+    assert p.returncode == 1 and b"cannot read state file" in p.stderr and b"planet/asteroid" in p.stderr
+    # nor is a mid-run state, an fp32 one, or one written under other constants: solved as a step-0 fp64 input under
+    # param::'s values its three lines would be wrong without a word
+    h = c.read_state_file(st)[0]
+    for kw, word in ((dict(step=7), b"step != 0"), (dict(precision=c.NB_F32), b"precision"), (dict(dt=30.0), b"dt differs"),
+                     (dict(eps=1e-2), b"eps differs"), (dict(G=1.0), b"G differs")):
+        odd = str(tmp_path / "odd.nbst")
+        c.write_state_file(odd, q, v, m, dev, planet=h["planet"], asteroid=h["asteroid"], **kw)
+        p = subprocess.run([os.path.join(ROOT, "bin", "hw5"), odd, out], capture_output=True)
+        assert p.returncode == 1 and word in p.stderr, (kw, p.stderr)
 
 
 @pytest.mark.parametrize("case,last", [("b200", 9013), ("b200", 24000), ("b512", 5001)])
@@ -230,8 +275,47 @@ def test_graph_replay_stops_at_the_hit(nb, oracle):
 
 
 def test_cli_with_a_shorter_graph_chunk(nb, tmp_path):
-    """NB_GRAPH_CHUNK=100: ten times as many, shorter replays (what profiling under rocprofv3 needs) — same three lines."""
+    """NB_GRAPH_CHUNK=100: ten times as many, shorter replays (what profiling under rocprofv3 needs) — same three lines.
+    NB_HW5_CLEAN_EXIT=1 makes hw5 return from main instead of _Exit, so this run also exercises the process teardown
+    (HIP exit handlers after graphs, borrowed streams, destruction order of the contexts)."""
     out = str(tmp_path / "out")
-    env = dict(os.environ, NB_GRAPH_CHUNK="100")
-    subprocess.run([os.path.join(ROOT, "bin", "hw5"), case_path("b200", "in"), out], check=True, timeout=300, env=env)
+    env = dict(os.environ, NB_GRAPH_CHUNK="100", NB_HW5_CLEAN_EXIT="1", NB_SOLVE_TRACE="1")
+    p = subprocess.run([os.path.join(ROOT, "bin", "hw5"), case_path("b200", "in"), out], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert p.returncode == 0, p.stderr
+    assert "x 100 launches" in p.stderr  # the option reached the graph capture
     assert open(out).read() == read_golden("b200")[4]
+
+
+@pytest.mark.parametrize("case", ["b20", "b1024"])
+def test_cli_clean_exit_runs_the_teardown(nb, case, tmp_path):
+    """Both engines (persistent for b20, replayed graphs on a stream per scenario for b1024) with a normal return from
+    main: a fault in the teardown path would show as a non-zero exit status."""
+    out = str(tmp_path / "out")
+    p = subprocess.run([os.path.join(ROOT, "bin", "hw5"), case_path(case, "in"), out], capture_output=True, text=True,
+                       timeout=300, env=dict(os.environ, NB_HW5_CLEAN_EXIT="1"))
+    assert p.returncode == 0, (p.returncode, p.stderr)
+    assert open(out).read() == read_golden(case)[4]
+
+
+def test_graph_chunk_of_a_single_scenario(nb, oracle):
+    """nb_scenario.graph_chunk: the same run through graphs of 1000 (default), 100 and 2 launches — identical results
+    and final state bits; an odd or oversized chunk is refused."""
+    c = nb.capi
+    s = oracle.read_input(case_path("b200", "in"))
+    devs = [int(i) for i in np.flatnonzero(s.is_device)]
+    outs = []
+    for chunk in (0, 100, 2):
+        with c.Context(s.n) as x:
+            x.set_state(s.q, s.v, s.m, s.is_device)
+            r = x.run_scenario(c.NB_SCN_FIRST_HIT, s.planet, s.asteroid, watch=devs, last_step=4321 if chunk != 2 else 4001,
+                               engine=1, graph_chunk=chunk)
+            outs.append((r, x.get_state()))
+    assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1][0], outs[1][1][0])
+    assert outs[2][0]["steps_done"] == 4001
+    with c.Context(s.n) as x:
+        x.set_state(s.q, s.v, s.m, s.is_device)
+        for bad in (3, 4002, -2):
+            with pytest.raises(c.NBodyError) as e:
+                x.run_scenario(c.NB_SCN_MIN_DIST, s.planet, s.asteroid, last_step=5000, engine=1, graph_chunk=bad)
+            assert e.value.code == c.NB_ERR_INVALID
