@@ -7,8 +7,9 @@ HIPCC    ?= /opt/rocm/bin/hipcc
 ARCH     ?= gfx950
 PKG      := nthu_ipc_nbody-simulation_amd
 SRC      := $(PKG)/csrc
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-result
-LIB      := $(PKG)/libnbody_amd.so
+EXTRA    ?=
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-result $(EXTRA)
+LIB      ?= $(PKG)/libnbody_amd.so
 
 KSRC := $(SRC)/nbody_kernels_f32.hip $(SRC)/nbody_kernels_f64.hip
 HDR  := $(SRC)/nbody_kernels.h include/nbody_amd.h

@@ -87,19 +87,54 @@ def cpu_baseline_all_cores(n_total, rows=2048):
 
 
 def load_traffic(n_bodies, world, kernel, j_split):
-    """HBM bytes per step of the force + reducer launches from the committed rocprofv3 PMC passes
-    (profiles/pmc_traffic.json, written by bench/parse_profile.py) — only when that profile was taken on THIS kernel,
-    body count, rank count and source split; any other configuration reports null (and the reducer's share likewise)."""
+    """HBM bytes per step of the force + reducer launches, and the VALU-busy fraction, from the committed rocprofv3 PMC
+    passes (profiles/pmc_traffic.json, written by bench/parse_profile.py on the builder's box — NOT measured by this
+    run) — only when that profile was taken on THIS kernel, body count, rank count and source split; any other
+    configuration reports null (and the reducer's share likewise)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
             t = json.load(f)
     except Exception:
-        return None, None
+        return None, None, None, None
     e = t.get(f"n{n_bodies}_p{world}", {})
     if e.get("kernel") != kernel or e.get("j_split") != j_split:
-        return None, None
-    return e.get("hbm_bytes_per_launch"), e.get("reduce_share_of_span")
+        return None, None, None, None
+    return e.get("hbm_bytes_per_launch"), e.get("reduce_share_of_span"), e.get("valu_busy"), e.get("tag")
+
+
+def parity_spot(torch, sysm, n, acc64, compute_kw, rows=64):
+    """The published number carries its own proof (SURVEY §8(d) "Parity on synthetic"): after the timed region, the
+    accelerations of ALL targets on the positions the run ended on — one accel-only launch of the same kernel family with
+    the same plan (register blocking, source slices, workgroup size) — and `rows` strided rows of it against the fp64
+    oracle (reference arithmetic, samples/nbody.cc:56-74).  Error relative to sum_j |a_ij| (the net force on a uniform
+    cloud cancels heavily); bound 1e-5 for fp32 sums, 1e-6 for fp64-accumulated ones."""
+    import numpy as np
+    from nbody_amd import capi, synthetic
+    from oracle import oracle as O
+    pos = sysm.positions
+    rec = 32 if acc64 else 16
+    acc = torch.empty((n, 4), dtype=torch.float64 if acc64 else torch.float32, device=pos.device)
+    ws = torch.empty(capi.workspace_bytes_f32(n, acc64), dtype=torch.uint8, device=pos.device)
+    capi.launch_f32(pos.data_ptr(), 0, n, 0, n, synthetic.EPS ** 2, synthetic.DT,
+                    torch.cuda.current_stream(pos.device).cuda_stream, accel_only=True, acc_ptr=acc.data_ptr(),
+                    acc64=acc64, workspace_ptr=ws.data_ptr(), workspace_bytes=ws.numel(), **compute_kw)
+    torch.cuda.synchronize()
+    assert acc.element_size() * 4 == rec
+    idx = [(k * (n // rows) + (k * 37) % (n // rows)) % n for k in range(rows)]
+    idx[0], idx[-1] = 0, n - 1
+    a_gpu = acc[idx, :3].cpu().numpy().astype(np.float64).T
+    p = pos.cpu().numpy().astype(np.float64)
+    q, m = np.ascontiguousarray(p[:, :3].T), np.ascontiguousarray(p[:, 3] / synthetic.G)
+    worst = 0.0
+    t0 = time.perf_counter()
+    for k, i in enumerate(idx):
+        a, ab = O.accel_rows(q, m, synthetic.G, synthetic.EPS, i, i + 1, want_abs=True, omp=True)
+        worst = max(worst, float(np.abs(a_gpu[:, k] - a[:, 0]).max() / ab[0]))
+    tol = 1e-6 if acc64 else 1e-5
+    return {"rows": rows, "pairs_checked": rows * (n - 1), "max_err_over_sum_abs": worst, "tol": tol,
+            "ok": bool(worst < tol), "oracle_s": round(time.perf_counter() - t0, 2),
+            "what": "accel-only launch (same plan as the timed step) on the final positions vs oracle/ fp64 rows"}
 
 
 def sharded_check(torch, dist, world, rank, device, dev_index, backend):
@@ -138,6 +173,36 @@ def sharded_check(torch, dist, world, rank, device, dev_index, backend):
     return out
 
 
+def conservation(torch, sysm, n, sample=1024):
+    """Integrals of motion of the state the system holds now (single rank): total momentum sum G m v exactly, kinetic
+    energy exactly, potential energy from `sample` strided targets against ALL sources in fp64 (scaled by n/sample; the
+    same sample before and after, so its change tracks the true change up to sampling noise).  Units: G*m (what the
+    records carry), Plummer-softened potential as the force law (samples/nbody.cc:66-72)."""
+    from nbody_amd import synthetic
+    if sysm.acc64:
+        pos, vel = sysm.pos64, sysm.vel64
+    else:
+        pos, vel = sysm.positions.double(), sysm.vel.double()
+    gm = pos[:, 3]
+    mom = (gm[:, None] * vel[:, :3]).sum(dim=0)
+    scale = (gm[:, None] * vel[:, :3].abs()).sum(dim=0)
+    kin = 0.5 * (gm * (vel[:, :3] ** 2).sum(dim=1)).sum()
+    idx = torch.arange(sample, device=pos.device) * (n // sample)
+    tq, tg = pos[idx, :3], gm[idx]
+    phi = torch.zeros(sample, dtype=torch.float64, device=pos.device)
+    chunk = 1 << 16
+    eps2 = synthetic.EPS ** 2
+    for j0 in range(0, n, chunk):
+        sq, sg = pos[j0:j0 + chunk, :3], gm[j0:j0 + chunk]
+        d2 = ((tq[:, None, :] - sq[None, :, :]) ** 2).sum(dim=2) + eps2
+        w = sg[None, :] * torch.rsqrt(d2)
+        w[(idx[:, None] == (torch.arange(j0, j0 + sq.shape[0], device=pos.device))[None, :])] = 0.0  # no self pair
+        phi -= w.sum(dim=1)
+    pot = 0.5 * (tg * phi).sum() * (n / sample)
+    return {"momentum": [float(x) for x in mom], "momentum_scale": [float(x) for x in scale],
+            "kinetic": float(kin), "potential_sampled": float(pot), "sample": sample}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,6 +219,7 @@ def main():
     ap.add_argument("--exchange", choices=["in_place", "staged", "ring"], default="in_place", help="multi-GPU: in-place "
                     "all-gather (default), all-gather from a cloned shard, or the ring pass (no rank holds all positions)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-spot", action="store_true", help="skip the oracle spot check of the final state (N=1)")
     ap.add_argument("--report-every", type=int, default=0, help="sustained runs (configs[4]): every R steps synchronise "
                     "and print steps done + running pairs/s to stderr")
     ap.add_argument("--time-box", type=float, default=0.0, help="sustained runs: stop at a report point once this many "
@@ -162,6 +228,12 @@ def main():
                     "rank 0 every --checkpoint-every steps (a collective; costs wall time inside the timed region)")
     ap.add_argument("--checkpoint-every", type=int, default=0)
     ap.add_argument("--resume", default="", help="start from this checkpoint instead of the synthetic initial state")
+    ap.add_argument("--conservation", action="store_true", help="single rank: momentum, kinetic and sampled potential "
+                    "energy before and after the run (their drift goes into the JSON)")
+    ap.add_argument("--dump-rows", default="", help="single rank: save 64 strided rows of the final q, v (npz) — resumed "
+                    "and uninterrupted runs are compared bit for bit with it")
+    ap.add_argument("--lib", default="", help="experiments: load this build of libnbody_amd.so instead of the in-tree one "
+                    "(same-device A/B of two kernel builds, e.g. make LIB=/tmp/x.so EXTRA=-DNB_K1_PAIR_GROUP=1)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; gloo + --single-device rehearses "
                     "the multi-rank path on a one-GPU box (RCCL refuses two ranks on one device)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
@@ -173,6 +245,8 @@ def main():
     import nbody_amd  # noqa: F401
     from nbody_amd import capi, synthetic
     from nbody_amd.distributed import ShardedSystem, hip_compute, shard_range
+    if args.lib:
+        capi.library_path = lambda: os.path.abspath(args.lib)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -225,17 +299,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    cons0 = conservation(torch, sysm, n) if (args.conservation and world == 1) else None
     for _ in range(args.warmup):
         sysm.step()
     barrier()
     kern_ms.clear()
     t0 = time.perf_counter()
     steps_done = 0
+    ckpt_s = []
     for k in range(args.steps):
         sysm.step()
         steps_done += 1
         if args.checkpoint and args.checkpoint_every and steps_done % args.checkpoint_every == 0:
+            tc = time.perf_counter()
             sysm.save_checkpoint(args.checkpoint, first_step + args.warmup + steps_done, synthetic.G)
+            ckpt_s.append(time.perf_counter() - tc)
         if args.report_every and steps_done % args.report_every == 0 and steps_done < args.steps:
             torch.cuda.synchronize()
             el = time.perf_counter() - t0
@@ -257,6 +335,13 @@ def main():
         wall = float(t.item())
     k_ms = sum(a.elapsed_time(b) for a, b in kern_ms) / len(kern_ms)
     assert torch.isfinite(sysm.positions).all(), "non-finite positions"
+    cons1 = conservation(torch, sysm, n) if cons0 is not None else None
+    if args.dump_rows and world == 1:
+        import numpy as np
+        idx = torch.arange(64, device=device) * (n // 64) + 17
+        qd = (sysm.pos64 if acc64 else sysm.positions)[idx].cpu().numpy()
+        vd = (sysm.vel64 if acc64 else sysm.vel)[idx].cpu().numpy()
+        np.savez(args.dump_rows, idx=idx.cpu().numpy(), q=qd, v=vd, step=first_step + args.warmup + steps_done)
 
     # --- untimed diagnostics of the multi-GPU path (after the timed region; not part of `value`)
     exchange_ms = check = overlap_ab = None
@@ -321,7 +406,7 @@ def main():
         tpl, jsp, wgs = capi.plan_f32(n_cover, sysm.n_tgt, acc64, args.targets_per_lane, args.j_split, ws_bytes,
                                       args.source_path, args.wg_size)
         reducer = f"nbody_reduce_update_f32<{'true' if acc64 else 'false'}, false>"
-        traffic, reduce_share = load_traffic(n, world, kname, jsp)
+        traffic, reduce_share, valu_busy, pmc_tag = load_traffic(n, world, kname, jsp)
         out = {
             "metric": "body-pair interactions/sec",
             "value": value,
@@ -341,8 +426,11 @@ def main():
                                        f"index-sharded x{world}, 1 RCCL all-gather of float4 positions/step")
                        if world > 1 else "single GPU"},
             "exchange": sysm.exchange_mode,
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+            "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
+                         "traffic_source": (f"profiles/pmc_traffic.json ({pmc_tag}: builder's rocprofv3 PMC passes on this "
+                                            f"kernel, N and source split; not measured by this run)") if traffic else None,
+                         "valu_busy": valu_busy,
                          "kernel": kname, "kernel_ms": k_ms,
                          "kernel_ms_spans": [kname] + ([reducer] if jsp > 1 else []),
                          "reduce_share_of_span": reduce_share,
@@ -353,9 +441,11 @@ def main():
                                                  "+ 1 v_rsq_f32 (8 cycles, does not overlap VALU) = 32 cycles -> 1024 SIMDs "
                                                  "x 2.4 GHz x 64/32 = 4.9e12 pairs/s = 0.62 of peak at 20 flop/pair "
                                                  "(profiles/r01_ubench_valu_rate.txt)",
-                         "bound_detail": "the contract's enum is hbm|mfma: the compute roofline used is the fp32 "
-                                         "vector-FMA (VALU) peak 157.3 TFLOP/s (numerically the dense f32 MFMA peak); the "
-                                         "kernel is VALU + v_rsq_f32 issue-bound, MFMA deliberately unused"},
+                         "bound_detail": "compute-bound on the fp32 vector-FMA (VALU) pipe: peak 157.3 TFLOP/s (numerically "
+                                         "the dense f32 MFMA peak, which is why the contract's hbm|mfma enum would say "
+                                         "'mfma'); the kernel issues v_pk_*_f32 + v_rsq_f32 and no MFMA instruction",
+                         "valu_busy_detail": "SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), "
+                                             "same committed PMC profile as `traffic`"},
         }
         if exchange_ms is not None:
             out["exchange_ms"] = exchange_ms  # one all-gather of float4[N] by itself, mean of 20
@@ -367,6 +457,24 @@ def main():
             out["overlap"] = bool(args.overlap)
             out["overlap_ab"] = {"ms_per_step": overlap_ab, "note": "two-phase step (own-shard sources during the "
                                  "all-gather) on vs off, same system, untimed diagnostic after the timed region"}
+        if first_step:
+            out["resumed_from_step"] = first_step
+        if ckpt_s:
+            out["checkpoints"] = {"count": len(ckpt_s), "seconds_each": [round(x, 2) for x in ckpt_s],
+                                  "bytes": os.path.getsize(args.checkpoint), "inside_timed_region": True}
+        if cons0 is not None:
+            e0, e1 = cons0["kinetic"] + cons0["potential_sampled"], cons1["kinetic"] + cons1["potential_sampled"]
+            out["conservation"] = {
+                "steps": args.warmup + args.steps, "before": cons0, "after": cons1,
+                "momentum_drift_over_scale": max(abs(a - b) / sc for a, b, sc in
+                                                 zip(cons0["momentum"], cons1["momentum"], cons0["momentum_scale"])),
+                "energy_rel_change_sampled": (e1 - e0) / abs(e0),
+                "note": "momentum and kinetic energy exact (fp64 sums over all bodies); potential from 1024 strided targets "
+                        "x all sources in fp64, same sample before and after"}
+        if world == 1 and not sysm.ring and not args.no_parity_spot:
+            out["parity_spot"] = parity_spot(torch, sysm, n, acc64, dict(
+                targets_per_lane=args.targets_per_lane, j_split=args.j_split, source_path=args.source_path,
+                wg_size=args.wg_size))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(n)

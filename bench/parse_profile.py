@@ -74,6 +74,13 @@ def main():
         lines.append(f"* VALU-active share of wave cycles = {sq['SQ_ACTIVE_INST_VALU'] / sq['SQ_WAVE_CYCLES']:.3f}")
     if "SQ_ACTIVE_INST_VALU" in sq and "SQ_BUSY_CYCLES" in sq and sq["SQ_BUSY_CYCLES"]:
         lines.append(f"* SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES = {sq['SQ_ACTIVE_INST_VALU'] / sq['SQ_BUSY_CYCLES']:.3f}")
+    valu_busy = None
+    if "SQ_ACTIVE_INST_VALU" in sq and sq.get("GRBM_GUI_ACTIVE"):
+        # SQ_ACTIVE_INST_* count quad-cycles summed over the SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        valu_busy = sq["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * sq["GRBM_GUI_ACTIVE"] / 8)
+        lines.append(f"* VALU busy = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) = **{valu_busy:.3f}**")
+        if avg_ms:
+            lines.append(f"* effective clock = GRBM_GUI_ACTIVE / 8 / kernel time = {sq['GRBM_GUI_ACTIVE'] / 8 / (avg_ms * 1e-3) / 1e9:.3f} GHz")
     if avg_ms:
         lines += ["", f"force kernel average duration (stats pass): **{avg_ms:.3f} ms**"]
     os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
@@ -93,7 +100,8 @@ def main():
         # bench.py only quotes these numbers for the configuration they were measured on
         t[key] = {"hbm_bytes_per_launch": traffic, "fetch_kib_raw": f_kib, "write_kib": w_kib, "tag": tag,
                   "kernel_avg_ms": avg_ms, "kernel": kernel, "j_split": int(os.environ.get("NB_TRAFFIC_JSPLIT", "8")),
-                  "reduce_share_of_span": reduce_total / (reduce_total + force_total) if force_total else None}
+                  "reduce_share_of_span": reduce_total / (reduce_total + force_total) if force_total else None,
+                  "valu_busy": valu_busy}
         json.dump(t, open(tpath, "w"), indent=1)
     print("\n".join(lines))
 

@@ -1,11 +1,14 @@
 // launch_rate.hip — what one dependent kernel launch costs on this box as a function of the kernarg size and of how the
 // launches are issued (eager back-to-back vs a hipGraph of N kernel nodes replayed).  Decides how the per-step scenario
 // engine (K2, csrc/nbody_kernels_f64.hip) should be driven: it is bound by this, not by arithmetic.
-//   hipcc --offload-arch=gfx950 -O3 -o launch_rate launch_rate.hip && ./launch_rate
+//   hipcc --offload-arch=gfx950 -O3 -o launch_rate launch_rate.hip && ./launch_rate [graph_nodes=2000 [quick]]
+// `quick` runs one configuration only (64-byte kernarg, one workgroup): the repro used to bracket the node count from which
+// rocprofv3's kernel tracing crashes inside hipGraphLaunch (profiles/r03_graph_trace_limit.txt).
 #include <hip/hip_runtime.h>
 
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 template <int BYTES>
@@ -31,6 +34,8 @@ __global__ __launch_bounds__(256) void touch(Args<BYTES> a) {
         }                                                                     \
     } while (0)
 
+static int g_nodes = 2000;
+
 template <int BYTES>
 int run(hipStream_t s, double* buf, int blocks, int n) {
     Args<BYTES> a{};
@@ -48,7 +53,7 @@ int run(hipStream_t s, double* buf, int blocks, int n) {
     const double issue = std::chrono::duration<double, std::micro>(t1 - t0).count() / n;
     const double total = std::chrono::duration<double, std::micro>(t2 - t0).count() / n;
     // graph: 2000 kernel nodes captured once, replayed n/2000 times
-    const int G = 2000;
+    const int G = g_nodes;
     hipGraph_t graph;
     hipGraphExec_t exec;
     CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -65,20 +70,23 @@ int run(hipStream_t s, double* buf, int blocks, int n) {
     CK(hipStreamSynchronize(s));
     auto g1 = std::chrono::steady_clock::now();
     const double graph_us = std::chrono::duration<double, std::micro>(g1 - g0).count() / (n / G * G);
-    printf("kernarg %4d B, %3d workgroups: eager issue %.2f us/launch, eager total %.2f us/launch, graph(2000 nodes) %.2f us/launch\n",
-           BYTES, blocks, issue, total, graph_us);
+    printf("kernarg %4d B, %3d workgroups: eager issue %.2f us/launch, eager total %.2f us/launch, graph(%d nodes) %.2f us/launch\n",
+           BYTES, blocks, issue, total, G, graph_us);
     (void)hipGraphExecDestroy(exec);
     (void)hipGraphDestroy(graph);
     return 0;
 }
 
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1) g_nodes = atoi(argv[1]);
+    if (g_nodes < 1 || g_nodes > 40000) return 2;
     hipStream_t s;
     CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     double* buf;
     CK(hipMalloc(&buf, 1024 * 256 * sizeof(double)));
     CK(hipMemset(buf, 0, 1024 * 256 * sizeof(double)));
     const int n = 40000;
+    if (argc > 2) return run<64>(s, buf, 1, n);
     for (int blocks : {1, 64, 256, 1024}) {
         if (run<64>(s, buf, blocks, n)) return 1;
         if (run<256>(s, buf, blocks, n)) return 1;

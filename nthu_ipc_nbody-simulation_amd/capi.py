@@ -73,6 +73,8 @@ SYMBOLS = {
     "nb_step": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "nb_accel": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp]),
     "nb_step_timed": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "nb_enable_step_stamps": (C.c_int, [C.c_void_p, C.c_int]),
+    "nb_read_step_stamps": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]),
     "nb_run_scenario": (C.c_int, [C.c_void_p, C.POINTER(NbScenario), C.POINTER(NbScenarioResult)]),
     "nb_run_scenarios_batched": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(NbScenario), C.POINTER(NbScenarioResult),
                                           C.c_int]),
@@ -262,6 +264,16 @@ class Context:
         a = np.empty((3, self.n))
         _check(lib().nb_accel(self._h, step, *[a[k].ctypes.data_as(_dp) for k in range(3)]), "nb_accel", self._h)
         return a
+
+    def enable_step_stamps(self, slots):
+        _check(lib().nb_enable_step_stamps(self._h, slots), "nb_enable_step_stamps", self._h)
+
+    def read_step_stamps(self, slots):
+        """-> (slots, 2) uint64: GPU wall clock (100 MHz ticks) at entry / after the last store of each step launch."""
+        out = np.zeros((slots, 2), dtype=np.uint64)
+        _check(lib().nb_read_step_stamps(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64)), slots), "nb_read_step_stamps",
+               self._h)
+        return out
 
     def run_scenario(self, kind, planet, asteroid, first_step=0, last_step=200000, watch=(), sync_every=2000,
                      planet_radius=1e7, missile_speed=1e6, engine=0, flags=0, graph_chunk=0):

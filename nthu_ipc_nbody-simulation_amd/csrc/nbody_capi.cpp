@@ -50,7 +50,7 @@ namespace {
 
 void release(nb_context* c) {
     free_dev(c->arena);  // q, v, m, coef, acc, mon, done_dev, ctl
-    free_dev(c->snap_q); free_dev(c->snap_v); free_dev(c->fst_dev);
+    free_dev(c->snap_q); free_dev(c->snap_v); free_dev(c->fst_dev); free_dev(c->stamps);
     free_dev(c->gm_large); free_dev(c->partial_large);
     if (c->host_arena) (void)hipHostFree(c->host_arena);  // mon_host, done_host
     free_dev(c->pos[0]); free_dev(c->pos[1]); free_dev(c->vel); free_dev(c->pos64); free_dev(c->vel64);
@@ -79,6 +79,8 @@ F64Args nbi::base_args(nb_context* c, int step) {
     a.eps2 = c->cfg.eps * c->cfg.eps;
     a.dt = c->cfg.dt;
     a.scn.kind = -1;
+    a.stamps = c->stamps;
+    a.stamp_slots = c->stamp_slots;
     return a;
 }
 
@@ -377,6 +379,29 @@ int nb_set_mass(nb_context* c, int index, double m) {
     if (int rc = bind(c)) return rc;
     c->m_host[index] = m;
     NB_HIP(c, hipMemcpyAsync(c->m + index, &c->m_host[index], sizeof(double), hipMemcpyHostToDevice, c->stream));
+    NB_HIP(c, hipStreamSynchronize(c->stream));
+    return NB_OK;
+}
+
+int nb_enable_step_stamps(nb_context* c, int slots) {
+    if (!c || slots < 0 || slots > (1 << 20) || c->cfg.precision != NB_F64) return NB_ERR_INVALID;
+    if (int rc = bind(c)) return rc;
+    NB_HIP(c, hipStreamSynchronize(c->stream));
+    free_dev(c->stamps);
+    c->stamp_slots = 0;
+    if (slots) {
+        NB_HIP(c, hipMalloc(&c->stamps, (size_t)slots * 2 * sizeof(unsigned long long)));
+        NB_HIP(c, hipMemsetAsync(c->stamps, 0, (size_t)slots * 2 * sizeof(unsigned long long), c->stream));
+        NB_HIP(c, hipStreamSynchronize(c->stream));
+        c->stamp_slots = slots;
+    }
+    return NB_OK;
+}
+
+int nb_read_step_stamps(nb_context* c, uint64_t* out, int slots) {
+    if (!c || !out || slots <= 0 || slots > c->stamp_slots) return NB_ERR_INVALID;
+    if (int rc = bind(c)) return rc;
+    NB_HIP(c, hipMemcpyAsync(out, c->stamps, (size_t)slots * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     NB_HIP(c, hipStreamSynchronize(c->stream));
     return NB_OK;
 }

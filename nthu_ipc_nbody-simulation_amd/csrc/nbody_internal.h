@@ -51,6 +51,8 @@ struct nb_context {
     int* done_host = nullptr;         // pinned
     nbk::F64Ctl* ctl_host = nullptr;  // pinned staging copy of *ctl
     nbk::F64Ctl* ctl = nullptr;  // graph-driven stepping: {base step, active} read by every launch of a replayed graph
+    unsigned long long* stamps = nullptr;  // nb_enable_step_stamps: [2 * stamp_slots] device words, else null
+    int stamp_slots = 0;
     void* arena = nullptr;       // F64: ONE device allocation behind q, v, m, coef, acc, mon, done_dev, ctl ...
     void* host_arena = nullptr;  // ... and one pinned allocation behind mon_host, done_host (a context costs two
                                  // allocations instead of ten: nb_solve creates 2 + D of them per program run)

@@ -95,6 +95,11 @@ struct F64Args {
     const F64Ctl* ctl;
     const double* fst_table;
     int t, last_step;
+    // measurement hook (nb_enable_step_stamps; null in normal runs: one scalar branch): thread 0 of workgroup 0 writes the
+    // 100 MHz wall clock at kernel entry and after its last store into stamps[2k], stamps[2k+1], k = (t-1 for a graph node,
+    // step for an eager launch) mod stamp_slots — per-launch duration and launch-to-launch gap of the replayed chain
+    unsigned long long* stamps;
+    int stamp_slots;
 };
 int launch_f64(const F64Args& a, int S, hipStream_t stream);  // S = lanes sharing one target (1..64, pow2)
 constexpr int MAX_BATCH = 8;

@@ -16,8 +16,9 @@
 //    - SGPR (default): a source is the same for all 64 lanes, so it never needs a vector register or LDS at
 //      all: batches of 16 bodies are fetched with scalar loads (s_load_dwordx16, through the scalar cache and
 //      L2) into SGPRs and used directly as the broadcast operand of the packed VALU ops
-//      (v_pk_add_f32 v, s[n:n+1], v op_sel_hi:[0,1]).  No ds_read, no v_mov, no barrier, no s_nop in the
-//      loop: exactly 12 packed VALU + 2 v_rsq_f32 per 2 pairs.  Measured (bench/ubench/force_variants.hip,
+//      (v_pk_add_f32 v, s[n:n+1], v op_sel_hi:[0,1]).  No ds_read and no barrier inside a batch: exactly 12 packed
+//      VALU + 2 v_rsq_f32 per 2 pairs (hot block of the bench kernel in the gfx950 dump: 384 v_pk_*, 64 v_rsq_f32,
+//      1 v_mov, ~12 SALU, and since round 3 no s_nop — see `interact`).  Measured (bench/ubench/force_variants.hip,
 //      profiles/r01_force_variants.txt; bench.py --source-path): 55.5 % of peak vs 52 % for the LDS path.
 //  * targets are held two-per-register-pair (ext_vector float2) so the loop is PACKED fp32:
 //    per source and target pair 3 v_pk_add, 3 v_pk_fma, 2 v_rsq_f32, 3 v_pk_mul, 3 v_pk_fma
@@ -48,6 +49,15 @@
 //    other workgroups still read the old positions — the barrier the reference gets from its kernel boundary
 //    between hw5.cu:371 and :375.
 #include "nbody_kernels.h"
+
+#ifndef NB_K1_PAIR_GROUP
+#define NB_K1_PAIR_GROUP 2  // pairs taken two at a time, stage by stage (see `interact`); 1 = pair after pair
+#endif
+#ifndef NB_K1_WAVES_512
+#define NB_K1_WAVES_512 4   // waves per SIMD the sliced 512-thread kernels are compiled for: 4 = two workgroups per CU =
+                            // at most 128 VGPRs.  The pair-grouped loop needs 148 when left alone (ONE workgroup per CU,
+                            // measured 257 vs 237 ms/step); held to 128 it compiles without scratch and without s_nop.
+#endif
 
 namespace nbk {
 
@@ -94,7 +104,7 @@ constexpr int SGPR_BATCH = 8;  // bodies per scalar-load batch (32 SGPRs; two ba
 // r01_force_variants_wgsize_traffic.txt: 140 MB per step = 8 XCDs x 16.8 MB, the floor; two independent 256-thread
 // workgroups per CU drift apart — oldest-wave-first issue arbitration — and fetch it twice, four fetch it 4x).
 template <int P, bool ACC64, bool ACCEL_ONLY, bool SPLIT, bool SGPR, int WGS>
-__global__ __launch_bounds__(WGS, (WGS == 1024 ? 4 : WGS == 512 ? 2 : (P >= 4 ? 2 : 4))) void nbody_force_f32(F32Args a) {
+__global__ __launch_bounds__(WGS, (WGS == 1024 ? 4 : WGS == 512 ? (SPLIT ? NB_K1_WAVES_512 : 2) : (P >= 4 ? 2 : 4))) void nbody_force_f32(F32Args a) {
     static_assert(SGPR || WGS == TILE, "the LDS path stages one source per thread");
     __shared__ float4 tile[SGPR ? 1 : 2][SGPR ? 1 : TILE];
     constexpr int WG = WGS;  // shadows nbk::WG inside this kernel
@@ -127,24 +137,34 @@ __global__ __launch_bounds__(WGS, (WGS == 1024 ? 4 : WGS == 512 ? 2 : (P >= 4 ? 
 
     const v2f eps2 = splat(a.eps2);
 
-    // one source body against this lane's P target pairs: 12 packed VALU + 2 v_rsq_f32 per pair of targets
+    // one source body against this lane's P target pairs: 12 packed VALU + 2 v_rsq_f32 per pair of targets.
+    // The pairs are taken in groups of G = 2, stage by stage (both subtractions, both r2 chains, both rsq, ...): a packed
+    // result is then never consumed by the very next VALU instruction.  Pair after pair (rounds 1-2) the compiler left
+    // `sc = gm*rinv ; sc *= rinv2` adjacent and padded the gfx950 forwarding hazard with one s_nop per (source, pair) —
+    // 32 per 8-source batch; grouped, the hot block has none.  Same-device A/B (bench/ubench/force_variants.hip ORDER 0/2,
+    // profiles/r03_pair_order_ab.txt): 31.6 -> 30.65 ms (+3.1 %); groups of 4 (40 live temporaries) and the
+    // rinv2*rinv*gm chain order measured slower than the original.  NB_K1_PAIR_GROUP=1 rebuilds the old order.
     auto interact = [&](const float4 s) {
         const v2f qx = splat(s.x), qy = splat(s.y), qz = splat(s.z), gm = splat(s.w);
+        constexpr int G = (NB_K1_PAIR_GROUP > 1 && P % 2 == 0) ? 2 : 1;
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
-            v2f dx = qx - xi[p];
-            v2f dy = qy - yi[p];
-            v2f dz = qz - zi[p];
-            v2f r2 = pk_fma(dx, dx, eps2);
-            r2 = pk_fma(dy, dy, r2);
-            r2 = pk_fma(dz, dz, r2);
-            v2f rinv = (v2f){__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};  // v_rsq_f32 x2
-            v2f rinv2 = rinv * rinv;
-            v2f sc = gm * rinv;
-            sc = sc * rinv2;  // G*m_j / (r2+eps2)^(3/2) ; the self pair gives sc*0 = +0
-            ax[p] = pk_fma(dx, sc, ax[p]);
-            ay[p] = pk_fma(dy, sc, ay[p]);
-            az[p] = pk_fma(dz, sc, az[p]);
+        for (int p0 = 0; p0 < P; p0 += G) {
+            v2f dx[G], dy[G], dz[G], r2[G], rinv[G], sc[G];
+#define NB_STAGE(stmt) _Pragma("unroll") for (int g = 0; g < G; ++g) { const int p = p0 + g; (void)p; stmt; }
+            NB_STAGE(dx[g] = qx - xi[p])
+            NB_STAGE(dy[g] = qy - yi[p])
+            NB_STAGE(dz[g] = qz - zi[p])
+            NB_STAGE(r2[g] = pk_fma(dx[g], dx[g], eps2))
+            NB_STAGE(r2[g] = pk_fma(dy[g], dy[g], r2[g]))
+            NB_STAGE(r2[g] = pk_fma(dz[g], dz[g], r2[g]))
+            NB_STAGE(rinv[g] = ((v2f){__builtin_amdgcn_rsqf(r2[g].x), __builtin_amdgcn_rsqf(r2[g].y)}))  // v_rsq_f32 x2
+            NB_STAGE(sc[g] = gm * rinv[g])
+            NB_STAGE(rinv[g] = rinv[g] * rinv[g])
+            NB_STAGE(sc[g] = sc[g] * rinv[g])  // G*m_j / (r2+eps2)^(3/2) ; the self pair gives sc*0 = +0
+            NB_STAGE(ax[p] = pk_fma(dx[g], sc[g], ax[p]))
+            NB_STAGE(ay[p] = pk_fma(dy[g], sc[g], ay[p]))
+            NB_STAGE(az[p] = pk_fma(dz[g], sc[g], az[p]))
+#undef NB_STAGE
         }
     };
     // second summation level: fold the partial of the last <= 256 sources into the running sum
@@ -395,10 +415,14 @@ F32Plan plan_f32(long n_tgt, long n_src, int n_cus, int force_tpl, int force_js,
             // for 256-thread ones — N = 2^18: 4 slices 55.3 %, 16 slices 58.2 %; N = 2^20: 2 -> 57.4 %, 8 -> 58.7 %
             const long want = 8 * (wg >= 512 ? 1L : 2L) * n_cus;
             while (bx * js < want && js < MAX_JSPLIT && js * 2 * 8 <= ntiles) js <<= 1;  // keep >= 8 tiles per slice
-            // small systems (a few thousand bodies: too few workgroups either way): 16 slices of >= 2 tiles measured
-            // best — N = 8192: 0.158 -> 0.048 ms/step, N = 16384: 0.161 -> 0.086 ms/step (r01_jsplit_search.txt)
-            if (n_tgt < 4096L * 32)
-                while (js < 16 && js * 2 * 2 <= ntiles) js <<= 1;
+            // small systems (up to 2^16 bodies: too few workgroups either way): ONE launch of 16 slices + one reducer
+            // measured best at every size — N = 4096 (one tile per slice): 0.0388 ms/step vs 0.0516 at 8 slices; 8192: 0.062
+            // vs 0.071 at 32; 16384: 0.102 / 0.116; 65536: 1.008 / 1.025 (profiles/r02_small_n_jsplit.txt).  Below 16 tiles
+            // a slice keeps at least two of them.
+            if (n_tgt < 4096L * 32) {
+                while (js < 16 && js * 2 <= ntiles && (ntiles >= 16 || js * 2 * 2 <= ntiles)) js <<= 1;
+                if (n_src < 4096L * 32 && js > SLICES_PER_LAUNCH) js = SLICES_PER_LAUNCH;  // (measured for n_src = n_tgt)
+            }
         }
     }
     if (js > MAX_JSPLIT) js = MAX_JSPLIT;

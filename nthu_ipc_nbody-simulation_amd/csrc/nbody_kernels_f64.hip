@@ -92,6 +92,12 @@ __device__ __forceinline__ void step_f64_body(const F64Args& a) {
         }
     };
     issue_loads(0);
+    unsigned long long* stamp = nullptr;
+    if (a.stamps && blockIdx.x == 0 && t == 0) {  // (scalar condition + one lane: nothing on the other lanes' path)
+        stamp = a.stamps + 2 * (size_t)((a.ctl ? a.t - 1 : a.step) % a.stamp_slots);
+        stamp[0] = wall_clock64();
+        stamp[1] = 0;
+    }
 
     constexpr int TPB = WG / S;  // targets per workgroup
     const int ls = t % S;        // this lane's slice of the source range
@@ -270,6 +276,7 @@ __device__ __forceinline__ void step_f64_body(const F64Args& a) {
             a.qout[2 * n + i] = __dadd_rn(zi, __dmul_rn(vz, a.dt));
         }
     }
+    if (stamp) stamp[1] = wall_clock64();
 }
 
 template <int S, bool SELFCHECK>

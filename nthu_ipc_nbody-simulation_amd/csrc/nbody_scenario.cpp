@@ -323,6 +323,8 @@ int group_prepare(GraphGroup& g) {
             a.ctl = c->ctl;
             a.fst_table = c0->fst_dev;
             a.t = t + 1;  // state index base + t  ->  step base + t + 1
+            a.stamps = c->stamps;  // measurement hook, null unless nb_enable_step_stamps
+            a.stamp_slots = c->stamp_slots;
             a.last_step = s.scn->last_step;
             args.item[b] = a;
         }

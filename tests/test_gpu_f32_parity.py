@@ -359,3 +359,64 @@ def test_phased_step_equals_whole_step(nb, oracle, acc64):
         with pytest.raises(c.NBodyError) as e:
             c.launch_f32(src.data_ptr(), src.data_ptr(), n, off, cnt, syn.EPS ** 2, dt, stream, **base, **bad)
         assert e.value.code == c.NB_ERR_INVALID
+
+
+@pytest.mark.parametrize("acc64", [False, True])
+def test_travelling_source_blocks_against_the_oracle(nb, oracle, acc64):
+    """The ring pass's launch mode (nb_launch_f32.tgt != NULL): the sources of a launch are a block that is NOT the
+    targets' own array, `tgt` is a separate float4[n_tgt], tgt_off (> n_src) only places the result in `out`, and a step
+    is NB_PHASE_FIRST / MIDDLE / LAST over three such blocks with the running sums in the workspace.  Accelerations and
+    one fused kick-drift against oracle rows (samples/nbody.cc:56-88): the oracle sees targets + the three blocks as one
+    system in which the targets are massless, so exactly the block bodies attract them."""
+    import torch
+    c, syn = nb.capi, nb.synthetic
+    blk, n_tgt, tgt_off, dt = 4096, 1000 + 37, 4096 + 1000, 1e-2
+    pos, vel = syn.body4_f32(3 * blk + n_tgt)
+    tgt_np, vel_np = pos[3 * blk:].copy(), vel[3 * blk:].copy()
+    blocks = [torch.from_numpy(pos[k * blk:(k + 1) * blk].copy()).cuda() for k in range(3)]
+    tgt = torch.from_numpy(tgt_np).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    ws = torch.empty(c.workspace_bytes_f32(n_tgt, acc64), dtype=torch.uint8, device="cuda")
+    phases = (c.NB_PHASE_FIRST, c.NB_PHASE_MIDDLE, c.NB_PHASE_LAST)
+    common = dict(workspace_ptr=ws.data_ptr(), workspace_bytes=ws.numel(), acc64=acc64, tgt_ptr=tgt.data_ptr())
+    # (1) accelerations
+    acc = torch.zeros((n_tgt, 4), dtype=torch.float64 if acc64 else torch.float32, device="cuda")
+    for b, ph in zip(blocks, phases):
+        c.launch_f32(b.data_ptr(), 0, blk, tgt_off, n_tgt, syn.EPS ** 2, dt, stream, accel_only=True,
+                     acc_ptr=acc.data_ptr(), phase=ph, **common)
+    torch.cuda.synchronize()
+    # oracle: one system [block0, block1, block2, targets], the targets massless
+    q = pos[:, :3].T.astype(np.float64).copy()
+    m = pos[:, 3].astype(np.float64) / syn.G
+    m[3 * blk:] = 0.0
+    ref, s = oracle.accel_rows(q, m, syn.G, syn.EPS, 3 * blk, 3 * blk + n_tgt, want_abs=True)
+    a = acc.cpu().numpy()[:, :3].T.astype(np.float64)
+    tol = TOL_ACC64 if acc64 else TOL_F32
+    assert (np.abs(a - ref).max(axis=0) / s).max() < tol
+    # (2) one fused step written at tgt_off of an `out` array that is larger than any source block
+    out = torch.zeros((tgt_off + n_tgt + 5, 4), dtype=torch.float32, device="cuda")
+    kw = dict(common)
+    if acc64:
+        p64 = torch.from_numpy(tgt_np.astype(np.float64)).cuda()
+        v64 = torch.from_numpy(vel_np.astype(np.float64)).cuda()
+        kw.update(pos64_ptr=p64.data_ptr(), vel64_ptr=v64.data_ptr())
+    else:
+        v32 = torch.from_numpy(vel_np).cuda()
+        kw.update(vel_ptr=v32.data_ptr())
+    for b, ph in zip(blocks, phases):
+        c.launch_f32(b.data_ptr(), out.data_ptr(), blk, tgt_off, n_tgt, syn.EPS ** 2, dt, stream, phase=ph, **kw)
+    torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    assert not o[:tgt_off].any() and not o[tgt_off + n_tgt:].any()         # only the window is written
+    assert np.array_equal(o[tgt_off:tgt_off + n_tgt, 3], tgt_np[:, 3])      # G*m travels with the record
+    dt32 = np.float64(np.float32(dt))
+    v0 = vel_np[:, :3].astype(np.float64)
+    v_ref = v0 + ref.T * dt32
+    q_ref = tgt_np[:, :3].astype(np.float64) + v_ref * dt32
+    v_gpu = (v64 if acc64 else v32).cpu().numpy()[:, :3].astype(np.float64)
+    q_gpu = (p64.cpu().numpy()[:, :3] if acc64 else o[tgt_off:tgt_off + n_tgt, :3].astype(np.float64))
+    ulp_v = 0 if acc64 else 2.0 ** -23 * np.abs(v_ref).max()
+    assert np.all(np.abs(v_gpu - v_ref) <= tol * s[:, None] * dt32 + ulp_v)
+    assert np.abs(q_gpu - q_ref).max() <= (1e-9 if acc64 else 1.2e-7)       # fp32 drift rounds at ulp(1)/2 = 6e-8
+    if acc64:  # the fp32 copy that travels on is the rounded master
+        assert np.array_equal(o[tgt_off:tgt_off + n_tgt, :3], p64.cpu().numpy()[:, :3].astype(np.float32))

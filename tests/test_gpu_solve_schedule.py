@@ -319,3 +319,40 @@ def test_graph_chunk_of_a_single_scenario(nb, oracle):
             with pytest.raises(c.NBodyError) as e:
                 x.run_scenario(c.NB_SCN_MIN_DIST, s.planet, s.asteroid, last_step=5000, engine=1, graph_chunk=bad)
             assert e.value.code == c.NB_ERR_INVALID
+
+
+def test_step_stamps_measure_without_changing_results(nb, oracle):
+    """nb_enable_step_stamps: every step launch of the per-step engine records the GPU wall clock at entry and after its
+    last store — entry < exit, launches in order — and the trajectory is bit for bit that of the unstamped run, for eager
+    launches and for a replayed graph."""
+    c = nb.capi
+    s = oracle.read_input(case_path("b200", "in"))
+    for flags, last in ((c.NB_SCN_EAGER, 64), (0, 64 * 65 - 2)):  # the last replay: 62 steps, the final monitor, one idle node
+        out = []
+        for slots in (0, 64):
+            with c.Context(s.n) as x:
+                x.set_state(s.q, s.v, s.m, s.is_device)
+                if slots:
+                    x.enable_step_stamps(slots)
+                r = x.run_scenario(c.NB_SCN_MIN_DIST, s.planet, s.asteroid, last_step=last, engine=1, flags=flags,
+                                   graph_chunk=64)
+                st = x.read_step_stamps(slots) if slots else None
+                out.append((r, x.get_state(), st))
+                if slots:
+                    with pytest.raises(c.NBodyError):
+                        x.read_step_stamps(slots + 1)
+                    x.enable_step_stamps(0)  # off again
+                    with pytest.raises(c.NBodyError):
+                        x.read_step_stamps(1)
+        (r0, (q0, v0), _), (r1, (q1, v1), st) = out
+        assert r0 == r1 and np.array_equal(q0, q1) and np.array_equal(v0, v1)
+        st = st.astype(np.int64)
+        done = st[:, 1] > 0
+        assert done.sum() >= 60                       # (the monitor-only launch after the last step leaves no exit stamp)
+        dur = (st[:, 1] - st[:, 0])[done]
+        assert np.all(dur > 0) and np.all(dur < 100000)   # 0 < duration < 1 ms in 10 ns ticks
+        k = np.flatnonzero(done[:-1] & done[1:])
+        if not flags:  # slots of one replay are consecutive nodes of the graph
+            assert np.all(st[k + 1, 0] >= st[k, 1])       # a node starts after its predecessor's last store
+    with c.Context(1024, c.NB_F32) as x, pytest.raises(c.NBodyError):
+        x.enable_step_stamps(8)  # fp64 engine only
