@@ -14,13 +14,19 @@ LIB      ?= $(PKG)/libnbody_amd.so
 KSRC := $(SRC)/nbody_kernels_f32.hip $(SRC)/nbody_kernels_f64.hip
 HDR  := $(SRC)/nbody_kernels.h include/nbody_amd.h
 
-.PHONY: all lib hw5 nbody_bench nbconv oracle ubench asan clean
-all: lib hw5 nbody_bench nbconv
+.PHONY: all lib hw5 nbody_bench nbconv oracle ubench asan clean stamps
+all: lib hw5 nbody_bench nbconv stamps
 
 lib: $(LIB)
 HOSTSRC := $(SRC)/nbody_capi.cpp $(SRC)/nbody_scenario.cpp $(SRC)/nbody_solve.cpp $(SRC)/nbody_statefile.cpp $(SRC)/nbody_sharded.cpp
 $(LIB): $(KSRC) $(HOSTSRC) $(HDR) $(SRC)/nbody_internal.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(KSRC) -x hip $(HOSTSRC) -lpthread -ldl
+
+# instrumented build of the same sources: the per-step fp64 kernel records clock stamps (bench/replay_stamps.py, tests)
+STAMPLIB := $(PKG)/libnbody_amd_stamps.so
+stamps: $(STAMPLIB)
+$(STAMPLIB): $(KSRC) $(HOSTSRC) $(HDR) $(SRC)/nbody_internal.h
+	$(HIPCC) $(HIPFLAGS) -DNB_STEP_STAMPS=1 -shared -o $@ $(KSRC) -x hip $(HOSTSRC) -lpthread -ldl
 
 hw5: bin/hw5
 bin/hw5: $(SRC)/main_hw5.cpp $(SRC)/nbody_io.cpp $(SRC)/nbody_io_state.cpp $(SRC)/nbody_io.h $(LIB)
@@ -59,4 +65,4 @@ bench/ubench/valu_rate: bench/ubench/valu_rate.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
 
 clean:
-	rm -f $(LIB) bin/hw5 bin/nbody_bench bin/nbconv hw5 bench/ubench/valu_rate bench/ubench/force_variants bench/ubench/launch_rate bench/debug/startup_probe
+	rm -f $(LIB) $(STAMPLIB) bin/hw5 bin/nbody_bench bin/nbconv hw5 bench/ubench/valu_rate bench/ubench/force_variants bench/ubench/launch_rate bench/debug/startup_probe

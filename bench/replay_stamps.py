@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-launch timing of the per-step fp64 engine INSIDE a replayed hipGraph, from the kernel's own clock stamps
-(nb_enable_step_stamps: 100 MHz GPU wall clock at kernel entry and after the last store of workgroup 0).  rocprofv3's
+(the instrumented build libnbody_amd_stamps.so, nb_enable_step_stamps: 100 MHz GPU wall clock at kernel entry and after
+the last store of workgroup 0; the hook itself lengthens the step by 7-13 %, so read the SPLIT, not the absolute period).  rocprofv3's
 kernel tracing crashes inside hipGraphLaunch on this image (profiles/r03_graph_trace_limit.txt), so this is how the replay
 path is measured: duration of one step launch, gap to the next node of the graph (the dependent-kernel boundary), and the
 period — against the same launches issued eagerly from the host.
@@ -25,6 +26,8 @@ def stats(x):
     return f"median {np.median(x):6.2f}  mean {x.mean():6.2f}  p5 {np.percentile(x, 5):6.2f}  p95 {np.percentile(x, 95):6.2f}"
 
 
+c.use_library(c.stamps_library_path()).__enter__()  # the instrumented build for the whole run of this tool
+
 for case in sys.argv[1:] or ["b200", "b512", "b1024"]:
     s = O.read_input(os.path.join(ROOT, "tests/golden/testcases", case + ".in"))
     for mode, flags in (("graph replay", 0), ("eager launches", c.NB_SCN_EAGER)):
@@ -38,6 +41,9 @@ for case in sys.argv[1:] or ["b200", "b512", "b1024"]:
             wall = (time.perf_counter() - t0) / STEPS * 1e6
             st = x.read_step_stamps(CHUNK).astype(np.int64)
         assert r["steps_done"] == 200 + STEPS
+        if not (st[1:, 1] > 0).any():
+            print(f"{case} {mode}: no exit stamps; first rows of the buffer:\n{st[:6]}", flush=True)
+            continue
         ok = st[1:, 1] > 0                      # slot 0 was overwritten by the monitor-only launch after the last step
         ent, ext = st[1:, 0][ok], st[1:, 1][ok]
         dur = (ext - ent) * TICK_US

@@ -130,10 +130,11 @@ int nb_accel(nb_context* ctx, int step, double* ax, double* ay, double* az);
  * recorded on the context's own stream around the `count` steps */
 int nb_step_timed(nb_context* ctx, int first_step, int count, float* ms_per_step);
 
-/* measurement hook of the per-step fp64 engine (NB_F64; off by default, one scalar branch in the kernel): with
- * slots > 0 every step launch of this context records the GPU's 100 MHz wall clock at kernel entry and after its last
+/* measurement hook of the per-step fp64 engine — INSTRUMENTED BUILD ONLY (libnbody_amd_stamps.so, `make stamps`; the
+ * product library answers NB_ERR_STATE: its latency-bound step kernel carries no instrumentation).  With slots > 0 every
+ * step launch of this context that does work records the GPU's 100 MHz wall clock at kernel entry and after its last
  * store (workgroup 0) into slot k = (node index within a replayed graph, or the step index for eager launches) mod slots;
- * nb_read_step_stamps copies {entry, exit} pairs out (exit = 0: the launch returned early).  Gives the per-launch duration
+ * nb_read_step_stamps copies {entry, exit} pairs out (exit = 0: a monitor-only launch).  Gives the per-launch duration
  * and the launch-to-launch gap of a replayed hipGraph where tracing tools cannot (bench/replay_stamps.py).  slots = 0
  * switches it off again. */
 int nb_enable_step_stamps(nb_context* ctx, int slots);

@@ -124,6 +124,11 @@ def library_path():
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libnbody_amd.so")
 
 
+def stamps_library_path():
+    """The instrumented build (make stamps): the per-step fp64 kernel records clock stamps (nb_enable_step_stamps)."""
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libnbody_amd_stamps.so")
+
+
 _lib = None
 
 
@@ -151,20 +156,40 @@ def _share_hip_runtime_with_torch():
             pass
 
 
+def _load(path):
+    if not os.path.exists(path):
+        raise ImportError(f"{path} not built — run `make` (there is no CPU fallback)")
+    _share_hip_runtime_with_torch()
+    L = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        f = getattr(L, name)  # AttributeError if the ABI lost a symbol
+        f.restype, f.argtypes = res, args
+    return L
+
+
 def lib():
     """Load libnbody_amd.so.  Raises if it has not been built (`make` / __graft_entry__.build())."""
     global _lib
     if _lib is None:
-        path = library_path()
-        if not os.path.exists(path):
-            raise ImportError(f"{path} not built — run `make` (there is no CPU fallback)")
-        _share_hip_runtime_with_torch()
-        L = C.CDLL(path)
-        for name, (res, args) in SYMBOLS.items():
-            f = getattr(L, name)  # AttributeError if the ABI lost a symbol
-            f.restype, f.argtypes = res, args
-        _lib = L
+        _lib = _load(library_path())
     return _lib
+
+
+class use_library:
+    """`with capi.use_library(path):` — everything inside goes through another build of the library (measurement tools:
+    the instrumented stamps build, same-device A/B of two kernel builds).  Contexts must not outlive the block."""
+
+    def __init__(self, path):
+        self.path = path
+
+    def __enter__(self):
+        global _lib
+        self.saved, _lib = _lib, _load(self.path)
+        return _lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.saved
 
 
 def _strerror(code):

@@ -79,8 +79,10 @@ F64Args nbi::base_args(nb_context* c, int step) {
     a.eps2 = c->cfg.eps * c->cfg.eps;
     a.dt = c->cfg.dt;
     a.scn.kind = -1;
+#if NB_STEP_STAMPS
     a.stamps = c->stamps;
     a.stamp_slots = c->stamp_slots;
+#endif
     return a;
 }
 
@@ -385,6 +387,10 @@ int nb_set_mass(nb_context* c, int index, double m) {
 
 int nb_enable_step_stamps(nb_context* c, int slots) {
     if (!c || slots < 0 || slots > (1 << 20) || c->cfg.precision != NB_F64) return NB_ERR_INVALID;
+#if !NB_STEP_STAMPS
+    snprintf(c->err, sizeof c->err, "this build of the library carries no stamp hook: use libnbody_amd_stamps.so (make stamps)");
+    return NB_ERR_STATE;
+#endif
     if (int rc = bind(c)) return rc;
     NB_HIP(c, hipStreamSynchronize(c->stream));
     free_dev(c->stamps);

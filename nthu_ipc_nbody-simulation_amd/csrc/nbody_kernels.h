@@ -5,6 +5,10 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#ifndef NB_STEP_STAMPS
+#define NB_STEP_STAMPS 0  // 1: the per-step fp64 kernel records clock stamps (instrumented build, `make stamps`)
+#endif
+
 namespace nbk {
 
 constexpr int WG = 256;    // threads per workgroup: 4 wave64, one per SIMD of a CU
@@ -95,11 +99,15 @@ struct F64Args {
     const F64Ctl* ctl;
     const double* fst_table;
     int t, last_step;
-    // measurement hook (nb_enable_step_stamps; null in normal runs: one scalar branch): thread 0 of workgroup 0 writes the
-    // 100 MHz wall clock at kernel entry and after its last store into stamps[2k], stamps[2k+1], k = (t-1 for a graph node,
-    // step for an eager launch) mod stamp_slots — per-launch duration and launch-to-launch gap of the replayed chain
+#if NB_STEP_STAMPS
+    // measurement hook of the instrumented build (libnbody_amd_stamps.so, nb_enable_step_stamps): thread 0 of workgroup 0
+    // writes the 100 MHz wall clock at kernel entry and after its last store into stamps[2k], stamps[2k+1], k = (t-1 for a
+    // graph node, step for an eager launch) mod stamp_slots — per-launch duration and launch-to-launch gap of the replayed
+    // chain.  Not in the product build: the extra kernarg words and the branch cost the latency-bound step 7-13 %
+    // (profiles/r03_step_stamps_cost.txt).
     unsigned long long* stamps;
     int stamp_slots;
+#endif
 };
 int launch_f64(const F64Args& a, int S, hipStream_t stream);  // S = lanes sharing one target (1..64, pow2)
 constexpr int MAX_BATCH = 8;

@@ -141,9 +141,13 @@ __global__ __launch_bounds__(WGS, (WGS == 1024 ? 4 : WGS == 512 ? (SPLIT ? NB_K1
     // The pairs are taken in groups of G = 2, stage by stage (both subtractions, both r2 chains, both rsq, ...): a packed
     // result is then never consumed by the very next VALU instruction.  Pair after pair (rounds 1-2) the compiler left
     // `sc = gm*rinv ; sc *= rinv2` adjacent and padded the gfx950 forwarding hazard with one s_nop per (source, pair) —
-    // 32 per 8-source batch; grouped, the hot block has none.  Same-device A/B (bench/ubench/force_variants.hip ORDER 0/2,
-    // profiles/r03_pair_order_ab.txt): 31.6 -> 30.65 ms (+3.1 %); groups of 4 (40 live temporaries) and the
-    // rinv2*rinv*gm chain order measured slower than the original.  NB_K1_PAIR_GROUP=1 rebuilds the old order.
+    // 32 per 8-source batch; grouped, the hot block has none (hipcc -S: 384 v_pk_*, 64 v_rsq_f32, 0 s_nop).  The grouped
+    // loop holds 8 more temporaries: left alone it takes 148 VGPRs, which costs the second workgroup per CU and 8 % of
+    // the rate (257 vs 237 ms/step); compiled for 4 waves per SIMD (NB_K1_WAVES_512) it fits 128 without scratch.
+    // Same-device A/B of the four combinations (profiles/r03_k1_ab.txt): grouped + 4 waves 237.9 ms/step, pair-after-pair
+    // 241.0 (either bound), grouped at 148 VGPRs 256.0 — adopted: +1.3 %.  In the stand-alone harness at equal occupancy
+    // (bench/ubench/force_variants.hip ORDER 0/2, profiles/r03_pair_order_ab.txt) the grouping alone is worth +3.1 %;
+    // groups of 4 (40 live temporaries) and the rinv2*rinv*gm chain order measured slower than the original.
     auto interact = [&](const float4 s) {
         const v2f qx = splat(s.x), qy = splat(s.y), qz = splat(s.z), gm = splat(s.w);
         constexpr int G = (NB_K1_PAIR_GROUP > 1 && P % 2 == 0) ? 2 : 1;

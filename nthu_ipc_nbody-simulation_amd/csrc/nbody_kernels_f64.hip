@@ -92,12 +92,11 @@ __device__ __forceinline__ void step_f64_body(const F64Args& a) {
         }
     };
     issue_loads(0);
+#if NB_STEP_STAMPS
+    const bool stamping = a.stamps && blockIdx.x == 0 && t == 0;
+    const unsigned long long t_entry = stamping ? wall_clock64() : 0;
     unsigned long long* stamp = nullptr;
-    if (a.stamps && blockIdx.x == 0 && t == 0) {  // (scalar condition + one lane: nothing on the other lanes' path)
-        stamp = a.stamps + 2 * (size_t)((a.ctl ? a.t - 1 : a.step) % a.stamp_slots);
-        stamp[0] = wall_clock64();
-        stamp[1] = 0;
-    }
+#endif
 
     constexpr int TPB = WG / S;  // targets per workgroup
     const int ls = t % S;        // this lane's slice of the source range
@@ -121,6 +120,13 @@ __device__ __forceinline__ void step_f64_body(const F64Args& a) {
         do_update = step <= a.last_step;
         fst = a.fst_table[step];
     }
+#if NB_STEP_STAMPS
+    if (stamping) {  // only launches that do work leave a record (idle nodes past the end of a run returned above)
+        stamp = a.stamps + 2 * (size_t)((a.ctl ? a.t - 1 : a.step) % a.stamp_slots);
+        stamp[0] = t_entry;
+        stamp[1] = 0;
+    }
+#endif
 
     // ---- monitor on the state after step-1 (index step-1), evaluated identically by every workgroup;
     //      only workgroup 0 records it.  A value another workgroup of THIS launch may already have written
@@ -276,7 +282,9 @@ __device__ __forceinline__ void step_f64_body(const F64Args& a) {
             a.qout[2 * n + i] = __dadd_rn(zi, __dmul_rn(vz, a.dt));
         }
     }
+#if NB_STEP_STAMPS
     if (stamp) stamp[1] = wall_clock64();
+#endif
 }
 
 template <int S, bool SELFCHECK>

@@ -323,8 +323,10 @@ int group_prepare(GraphGroup& g) {
             a.ctl = c->ctl;
             a.fst_table = c0->fst_dev;
             a.t = t + 1;  // state index base + t  ->  step base + t + 1
-            a.stamps = c->stamps;  // measurement hook, null unless nb_enable_step_stamps
+#if NB_STEP_STAMPS
+            a.stamps = c->stamps;  // measurement hook of the instrumented build, null unless nb_enable_step_stamps
             a.stamp_slots = c->stamp_slots;
+#endif
             a.last_step = s.scn->last_step;
             args.item[b] = a;
         }

@@ -327,6 +327,14 @@ def test_step_stamps_measure_without_changing_results(nb, oracle):
     launches and for a replayed graph."""
     c = nb.capi
     s = oracle.read_input(case_path("b200", "in"))
+    with c.Context(s.n) as x, pytest.raises(c.NBodyError) as e:  # the product build carries no instrumentation
+        x.enable_step_stamps(8)
+    assert e.value.code == c.NB_ERR_STATE and "libnbody_amd_stamps.so" in str(e.value)
+    with c.use_library(c.stamps_library_path()):
+        _stamps_checks(c, s)
+
+
+def _stamps_checks(c, s):
     for flags, last in ((c.NB_SCN_EAGER, 64), (0, 64 * 65 - 2)):  # the last replay: 62 steps, the final monitor, one idle node
         out = []
         for slots in (0, 64):
@@ -354,5 +362,5 @@ def test_step_stamps_measure_without_changing_results(nb, oracle):
         k = np.flatnonzero(done[:-1] & done[1:])
         if not flags:  # slots of one replay are consecutive nodes of the graph
             assert np.all(st[k + 1, 0] >= st[k, 1])       # a node starts after its predecessor's last store
-    with c.Context(1024, c.NB_F32) as x, pytest.raises(c.NBodyError):
+    with c.Context(1024, c.NB_F32, eps=1e-3) as x, pytest.raises(c.NBodyError):
         x.enable_step_stamps(8)  # fp64 engine only
