@@ -311,6 +311,7 @@ def main():
         sysm.step()
         steps_done += 1
         if args.checkpoint and args.checkpoint_every and steps_done % args.checkpoint_every == 0:
+            torch.cuda.synchronize()  # the step in flight is not part of the checkpoint's time
             tc = time.perf_counter()
             sysm.save_checkpoint(args.checkpoint, first_step + args.warmup + steps_done, synthetic.G)
             ckpt_s.append(time.perf_counter() - tc)

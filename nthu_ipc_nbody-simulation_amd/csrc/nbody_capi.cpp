@@ -50,7 +50,7 @@ namespace {
 
 void release(nb_context* c) {
     free_dev(c->arena);  // q, v, m, coef, acc, mon, done_dev, ctl
-    free_dev(c->snap_q); free_dev(c->snap_v); free_dev(c->fst_dev); free_dev(c->stamps);
+    free_dev(c->snap_q); free_dev(c->snap_v); free_dev(c->fst_dev); free_dev(c->fst_chunk); free_dev(c->stamps);
     free_dev(c->gm_large); free_dev(c->partial_large);
     if (c->host_arena) (void)hipHostFree(c->host_arena);  // mon_host, done_host
     free_dev(c->pos[0]); free_dev(c->pos[1]); free_dev(c->vel); free_dev(c->pos64); free_dev(c->vel64);

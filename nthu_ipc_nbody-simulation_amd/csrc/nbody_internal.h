@@ -45,8 +45,10 @@ struct nb_context {
     double* gm_large = nullptr;       // K1-f64 (n > F64_LARGE_MIN): G*m_eff scratch [n]
     double* partial_large = nullptr;  // ... and partial sums [slices][3][n]
     int slices_large = 1;
-    double* fst_dev = nullptr;  // K3: |sin(step*dt/6000)| table, steps 0 .. fst_len-1
+    double* fst_dev = nullptr;  // |sin(step*dt/6000)| table, steps 0 .. fst_len-1, host-computed (glibc)
     int fst_len = 0;
+    double* fst_chunk = nullptr;  // graph-driven stepping: |sin| of steps base .. base + chunk + 1, refilled per replay
+    int fst_chunk_len = 0;
     int* done_dev = nullptr;
     int* done_host = nullptr;         // pinned
     nbk::F64Ctl* ctl_host = nullptr;  // pinned staging copy of *ctl
@@ -132,6 +134,7 @@ struct GraphGroup {  // the scenarios that share one stream and one replayed gra
     hipEvent_t ev[2] = {nullptr, nullptr};  // end of the replays in flight (even / odd)
     int launched = 0, collected = 0;
     int chunk = 0;  // steps per replay (even: the ping-pong buffers are back in place after a chunk); 0 = default
+    nbk::F64CtlBatch cb{};  // control words and per-replay |sin| arrays of the slots (valid once prepared)
     bool prepared = false;
     ~GraphGroup();
     bool running() const;

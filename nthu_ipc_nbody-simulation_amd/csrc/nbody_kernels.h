@@ -93,11 +93,13 @@ struct F64Args {
     double fst;     // |sin(step*dt/6000)| computed on the host (glibc, as the CPU reference does)
     double G, eps2, dt;
     F64Scenario scn;
-    // graph-driven stepping (ctl != nullptr): step = ctl->base_step + t instead of `step`, |sin| from the host-computed
-    // table `fst_table[step]` instead of `fst`; the update runs while step <= last_step, step == last_step + 1 is the
-    // monitor-only launch for the final state, later launches (and dormant slots) return at once
+    // graph-driven stepping (ctl != nullptr): step = ctl->base_step + t instead of `step`, |sin| of that step from
+    // `fst_chunk[t]` instead of `fst` — a per-scenario array the graph's own fill node rewrites for the next replay from the
+    // host-computed (glibc) table, so that the value sits at an address known at capture time and its load does not wait
+    // for the control word; the update runs while step <= last_step, step == last_step + 1 is the monitor-only launch for
+    // the final state, later launches (and dormant slots) return at once
     const F64Ctl* ctl;
-    const double* fst_table;
+    const double* fst_chunk;
     int t, last_step;
 #if NB_STEP_STAMPS
     // measurement hook of the instrumented build (libnbody_amd_stamps.so, nb_enable_step_stamps): thread 0 of workgroup 0
@@ -118,9 +120,13 @@ struct F64BatchArgs {  // up to MAX_BATCH independent systems of the same n, one
 int launch_f64_batched(const F64BatchArgs& b, int n, int S, hipStream_t stream);
 struct F64CtlBatch {
     F64Ctl* ctl[MAX_BATCH];
+    double* fst_chunk[MAX_BATCH];  // [chunk + 2] per slot: fst_chunk[t] = |sin| of step base_step + t
     int count;
 };
 int launch_ctl_advance(const F64CtlBatch& b, int by, hipStream_t stream);  // base_step += by for the active slots
+// fst_chunk[k][t] = table[base_step_k + (active_k ? by : 0) + t] for t = 0 .. chunk + 1 (index clamped to the table):
+// with by = chunk the values of the NEXT replay (the node runs before launch_ctl_advance), with by = 0 a (re)fill
+int launch_fst_fill(const F64CtlBatch& b, int by, int chunk, const double* table, int table_len, hipStream_t stream);
 int auto_split_f64(int n, int n_cus);
 
 // K1-f64: fp64 force + kick-drift for LARGE n (plain nb_step / nb_accel from F64_LARGE_MIN bodies up): sources broadcast

@@ -114,11 +114,11 @@ __device__ __forceinline__ void step_f64_body(const F64Args& a) {
     int step = a.step, do_update = a.do_update;
     double fst = a.fst;
     if (a.ctl) {
+        fst = a.fst_chunk[a.t];  // address known at capture time: in flight together with the control word, not behind it
         const F64Ctl ctl = *a.ctl;
         step = ctl.base_step + a.t;
         if (!ctl.active || step > a.last_step + 1) return;  // dormant slot / past the end: workgroup-uniform
         do_update = step <= a.last_step;
-        fst = a.fst_table[step];
     }
 #if NB_STEP_STAMPS
     if (stamping) {  // only launches that do work leave a record (idle nodes past the end of a run returned above)
@@ -701,6 +701,23 @@ int launch_f64_batched(const F64BatchArgs& b, int n, int S, hipStream_t stream) 
 __global__ void nbody_ctl_advance(F64CtlBatch b, int by) {
     const int k = threadIdx.x;
     if (k < b.count && b.ctl[k] && b.ctl[k]->active) b.ctl[k]->base_step += by;
+}
+
+__global__ __launch_bounds__(WG) void nbody_fst_fill(F64CtlBatch b, int by, int chunk, const double* __restrict__ table,
+                                                      int table_len) {
+    const int k = blockIdx.y, t = blockIdx.x * WG + threadIdx.x;
+    if (k >= b.count || !b.ctl[k] || !b.fst_chunk[k] || t > chunk + 1) return;
+    const F64Ctl c = *b.ctl[k];
+    int at = c.base_step + (c.active ? by : 0) + t;
+    at = at < 0 ? 0 : (at < table_len ? at : table_len - 1);  // past the end of every run: never used
+    b.fst_chunk[k][t] = table[at];
+}
+
+int launch_fst_fill(const F64CtlBatch& b, int by, int chunk, const double* table, int table_len, hipStream_t stream) {
+    if (b.count <= 0 || chunk < 0 || !table || table_len <= 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(nbody_fst_fill, dim3((unsigned)((chunk + 2 + WG - 1) / WG), (unsigned)b.count), dim3(WG), 0, stream, b, by,
+                       chunk, table, table_len);
+    return (int)hipGetLastError();
 }
 
 int launch_ctl_advance(const F64CtlBatch& b, int by, hipStream_t stream) {

@@ -85,6 +85,18 @@ int ensure_fst_table(nb_context* c, int last_step) {
     return NB_OK;
 }
 
+// graph-driven stepping: the per-scenario array a replay's launches read their |sin| from (see F64Args.fst_chunk)
+int ensure_fst_chunk(nb_context* err, nb_context* c, int chunk) {
+    const int need = chunk + 2;
+    if (c->fst_chunk_len < need) {
+        free_dev(c->fst_chunk);
+        c->fst_chunk_len = 0;
+        NB_HIP(err, hipMalloc(&c->fst_chunk, (size_t)need * sizeof(double)));
+        c->fst_chunk_len = need;
+    }
+    return NB_OK;
+}
+
 // K3 reports the index of the last state it computed through a device word + its pinned host copy (part of the arenas)
 int ensure_done_word(nb_context* c) { return (c->done_dev && c->done_host) ? NB_OK : NB_ERR_STATE; }
 
@@ -289,10 +301,20 @@ int group_prepare(GraphGroup& g) {
         if (int rc = upload_ctl(c0, s, stream)) return rc;
     }
     if (int rc = ensure_fst_table(c0, max_last)) return rc;  // indices up to last_step + 1 are read
-    NB_HIP(c0, hipStreamSynchronize(stream));
-
     if (!g.chunk) g.chunk = GRAPH_CHUNK_DEFAULT;
     const int count = (int)g.slots.size();
+    g.cb = F64CtlBatch{};
+    g.cb.count = count;
+    for (int b = 0; b < count; ++b) {
+        nb_context* c = g.slots[(size_t)b].c;
+        if (int rc = ensure_fst_chunk(c0, c, g.chunk)) return rc;
+        g.cb.ctl[b] = c->ctl;
+        g.cb.fst_chunk[b] = c->fst_chunk;
+    }
+    // the first replay's |sin| values, from the control words uploaded above (stream order)
+    NB_HIP(c0, (hipError_t)launch_fst_fill(g.cb, 0, g.chunk, c0->fst_dev, c0->fst_len, stream));
+    NB_HIP(c0, hipStreamSynchronize(stream));
+
     const auto t_prep = std::chrono::steady_clock::now();
     // relaxed mode: the capture restricts neither this thread's nor other host threads' HIP calls on OTHER streams
     // (distinct contexts may be driven from distinct threads); nothing but the launches below touches `stream` meanwhile
@@ -321,7 +343,7 @@ int group_prepare(GraphGroup& g) {
             a.dt = c->cfg.dt;
             a.scn = s.sc;
             a.ctl = c->ctl;
-            a.fst_table = c0->fst_dev;
+            a.fst_chunk = c->fst_chunk;
             a.t = t + 1;  // state index base + t  ->  step base + t + 1
 #if NB_STEP_STAMPS
             a.stamps = c->stamps;  // measurement hook of the instrumented build, null unless nb_enable_step_stamps
@@ -332,12 +354,9 @@ int group_prepare(GraphGroup& g) {
         }
         bad = (hipError_t)launch_f64_batched(args, c0->n, c0->split, stream);
     }
-    if (bad == hipSuccess) {
-        F64CtlBatch cb{};
-        cb.count = count;
-        for (int b = 0; b < count; ++b) cb.ctl[b] = g.slots[(size_t)b].c->ctl;
-        bad = (hipError_t)launch_ctl_advance(cb, chunk, stream);
-    }
+    // end of a replay: the next replay's |sin| values (read against the OLD base step), then the base steps move on
+    if (bad == hipSuccess) bad = (hipError_t)launch_fst_fill(g.cb, chunk, chunk, c0->fst_dev, c0->fst_len, stream);
+    if (bad == hipSuccess) bad = (hipError_t)launch_ctl_advance(g.cb, chunk, stream);
     hipError_t e = hipStreamEndCapture(stream, &g.graph);
     if (bad != hipSuccess) return fail_hip(c0, bad, "capturing the step graph");
     if (e != hipSuccess) return fail_hip(c0, e, "hipStreamEndCapture");
@@ -425,7 +444,10 @@ int activate_follower(GraphGroup& g, GraphSlot& f, int arr, const FollowerPolicy
     f.base = arr;
     f.active = true;
     if (int rc = bind(c0)) return rc;
-    return upload_ctl(c0, f, c0->stream);
+    if (int rc = upload_ctl(c0, f, c0->stream)) return rc;
+    // its |sin| values for the next replay start at the arrival step (a group not yet prepared fills all slots when it is)
+    if (g.prepared) NB_HIP(c0, (hipError_t)launch_fst_fill(g.cb, 0, g.chunk, c0->fst_dev, c0->fst_len, c0->stream));
+    return NB_OK;
 }
 
 // The Problem-3 work queue (hw5.cu:490-493,574-596) over the followers of all groups: candidates are the devices whose
