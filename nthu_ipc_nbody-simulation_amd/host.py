@@ -55,14 +55,27 @@ def _is_device(types):
     return np.array([t == "device" for t in types], dtype=np.uint8)
 
 
+_contexts = {}  # (n, device) -> Context: the reference's run_step is stateless, its GPU stand-in keeps the allocation
+
+
 def run_step(step, n, qx, qy, qz, vx, vy, vz, m, type, device=0):  # noqa: A002
-    """One step on the GPU, updating the six state vectors in place (nbody.cc:51-89)."""
-    with capi.Context(n, capi.NB_F64, device) as ctx:
-        ctx.set_state(np.stack([qx, qy, qz]), np.stack([vx, vy, vz]), m, _is_device(type))
-        ctx.step(step, 1)
-        q, v = ctx.get_state()
+    """One step on the GPU, updating the six state vectors in place (nbody.cc:51-89).  The signature is the
+    reference's, so the state crosses PCIe both ways on every call (like the minimal binding of INTEGRATION.md §2);
+    the context (streams, HBM) is created once per system size and reused by later calls."""
+    ctx = _contexts.get((n, device))
+    if ctx is None:
+        ctx = _contexts[(n, device)] = capi.Context(n, capi.NB_F64, device)
+    ctx.set_state(np.stack([qx, qy, qz]), np.stack([vx, vy, vz]), m, _is_device(type))
+    ctx.step(step, 1)
+    q, v = ctx.get_state()
     qx[:], qy[:], qz[:] = q
     vx[:], vy[:], vz[:] = v
+
+
+def release_contexts():
+    """Free the contexts run_step keeps."""
+    while _contexts:
+        _contexts.popitem()[1].close()
 
 
 def solve_file(in_path, out_path, devices=None):

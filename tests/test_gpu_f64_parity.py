@@ -55,10 +55,14 @@ def test_run_step_mirror(nb, oracle):
     """host.run_step has the reference's signature and semantics (nbody.cc:51)."""
     n, planet, asteroid, qx, qy, qz, vx, vy, vz, m, types = nb.host.read_input(case_path("b30", "in"))
     s = oracle.read_input(case_path("b30", "in"))
-    nb.host.run_step(1, n, qx, qy, qz, vx, vy, vz, m, types)
-    oracle.run_steps(s, 1, 1)
+    for step in (1, 2, 3):  # the context behind run_step is created once and reused by the later calls
+        nb.host.run_step(step, n, qx, qy, qz, vx, vy, vz, m, types)
+    oracle.run_steps(s, 1, 3)
     assert _close(np.stack([qx, qy, qz]), s.q, RTOL_1)
     assert _close(np.stack([vx, vy, vz]), s.v, RTOL_1)
+    assert len(nb.host._contexts) == 1
+    nb.host.release_contexts()
+    assert not nb.host._contexts
 
 
 def test_ragged_and_tiny_sizes(nb, oracle):
