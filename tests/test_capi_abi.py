@@ -155,3 +155,15 @@ int main(void) {
     p = subprocess.run([str(exe)], capture_output=True, text=True)
     assert p.returncode == 0, (p.returncode, p.stderr)
     assert p.stdout.startswith("ok|no usable HIP device")
+
+
+def test_instrumented_build_exports_the_same_abi(nb):
+    """libnbody_amd_stamps.so (make stamps: the per-step kernel records clock stamps) is the same ABI, symbol for symbol."""
+    import ctypes as C
+    path = nb.capi.stamps_library_path()
+    assert os.path.exists(path), "make stamps"
+    L = C.CDLL(path)
+    for name in nb.capi.SYMBOLS:
+        assert hasattr(L, name), name
+    L.nb_abi_version.restype = C.c_int
+    assert L.nb_abi_version() == 3

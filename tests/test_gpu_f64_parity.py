@@ -4,7 +4,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import ALL_CASES, GOLDEN, case_path, read_golden
+from conftest import ALL_CASES, GOLDEN, ROOT, case_path, read_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -293,3 +293,20 @@ def test_batched_scenarios_equal_individual_runs(nb, oracle):
         assert np.array_equal(qa, qb) and np.array_equal(va, vb)
     assert [r["steps_done"] for r, _ in batched] == [last] * len(arrived) + [5000]
     assert all(r["hit_step"] == -2 and r["arrival_step"][0] == a for (r, _), (a, _, _) in zip(batched, arrived))
+
+
+def test_reference_main_drives_the_gpu_step(nb, tmp_path):
+    """INTEGRATION.md §2 executed: oracle/_ref/nbody_gpu is the REFERENCE'S OWN main() (samples/nbody.cc:91-146, compiled
+    where it lies by oracle/Makefile) whose run_step calls (nbody.cc:116,129) bind, at link time, to the C-ABI binding of
+    oracle/ref_gpu_binding.cc — same signature, arithmetic on the GPU, state over PCIe on every call.  Lines 1 and 2 of its
+    output must be the golden ones; line 3 is the sample's TODO (nbody.cc:140-143)."""
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "nbody_gpu")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/nbody_gpu not built (needs /root/reference at build time)")
+    out = tmp_path / "b20.out"
+    p = subprocess.run([exe, case_path("b20", "in"), str(out)], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr
+    got, gold = out.read_text().split("\n"), open(case_path("b20", "out")).read().split("\n")
+    assert got[0] == gold[0] and got[1] == gold[1], (got, gold)
+    assert got[2].split()[0] == "-999"
