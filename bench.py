@@ -103,6 +103,52 @@ def load_traffic(n_bodies, world, kernel, j_split):
     return e.get("hbm_bytes_per_launch"), e.get("reduce_share_of_span"), e.get("valu_busy"), e.get("tag")
 
 
+def live_pmc(argv_tail, kernel_prefix="nbody_force_f32", timeout=150):
+    """HBM traffic and VALU-busy of the force kernel measured BY THIS RUN: three short child runs of this same program
+    (2 steps each) under `rocprofv3 --pmc`, one counter group per pass as the guide prescribes — FETCH_SIZE, WRITE_SIZE,
+    then SQ_ACTIVE_INST_VALU + GRBM_GUI_ACTIVE — with the program directly after `--`.  FETCH_SIZE / WRITE_SIZE are KiB;
+    on gfx950 FETCH_SIZE reports half of a streaming read and is doubled (MI355X_MICROARCH.md, HBM section).  Returns a
+    dict, or None when the tool is missing or a pass fails (the committed profile is quoted then, and said to be)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    tool = shutil.which("rocprofv3")
+    if not tool:
+        return None
+    out = tempfile.mkdtemp(prefix="nb_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+             "--no-parity-spot", "--no-live-pmc"] + list(argv_tail)
+
+    def one_pass(tag, counters):
+        d = os.path.join(out, tag)
+        cmd = [tool, "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", d, "-o", tag, "--"] + child
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, env=env, cwd="/tmp")
+        if p.returncode != 0:
+            raise RuntimeError(f"rocprofv3 pass {tag}: rc={p.returncode}")
+        vals = {}
+        for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            with open(path, newline="") as f:
+                for r in csv.DictReader(f):
+                    if kernel_prefix in r.get("Kernel_Name", ""):
+                        vals.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        return {k: sum(v) / len(v) for k, v in vals.items()}
+
+    try:
+        f = one_pass("fetch", ["FETCH_SIZE"])
+        w = one_pass("write", ["WRITE_SIZE"])
+        q = one_pass("sq", ["SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"])
+        res = {"hbm_bytes_per_launch": (2.0 * f["FETCH_SIZE"] + w["WRITE_SIZE"]) * 1024.0,
+               "fetch_kib_raw": f["FETCH_SIZE"], "write_kib": w["WRITE_SIZE"],
+               "valu_busy": q["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * q["GRBM_GUI_ACTIVE"] / 8)}
+    except Exception as e:  # noqa: BLE001  (tool crash, timeout, missing counter: fall back to the committed profile)
+        res = {"error": f"{type(e).__name__}: {e}"}
+    shutil.rmtree(out, ignore_errors=True)
+    return res
+
+
 def parity_spot(torch, sysm, n, acc64, compute_kw, rows=64):
     """The published number carries its own proof (SURVEY §8(d) "Parity on synthetic"): after the timed region, the
     accelerations of ALL targets on the positions the run ended on — one accel-only launch of the same kernel family with
@@ -220,6 +266,8 @@ def main():
                     "all-gather (default), all-gather from a cloned shard, or the ring pass (no rank holds all positions)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-spot", action="store_true", help="skip the oracle spot check of the final state (N=1)")
+    ap.add_argument("--no-live-pmc", action="store_true", help="N=1: do not re-run 2 steps three times under rocprofv3 --pmc "
+                    "for this run's own HBM traffic / VALU-busy (the committed PMC profile is quoted instead)")
     ap.add_argument("--report-every", type=int, default=0, help="sustained runs (configs[4]): every R steps synchronise "
                     "and print steps done + running pairs/s to stderr")
     ap.add_argument("--time-box", type=float, default=0.0, help="sustained runs: stop at a report point once this many "
@@ -408,6 +456,17 @@ def main():
                                       args.source_path, args.wg_size)
         reducer = f"nbody_reduce_update_f32<{'true' if acc64 else 'false'}, false>"
         traffic, reduce_share, valu_busy, pmc_tag = load_traffic(n, world, kname, jsp)
+        traffic_source = (f"profiles/pmc_traffic.json ({pmc_tag}: builder's rocprofv3 PMC passes on this kernel, N and source "
+                          f"split; not measured by this run)") if traffic else None
+        live = None
+        if world == 1 and not args.no_live_pmc and not args.lib:
+            tail = ["--bodies", str(n), "--precision", args.precision, "--targets-per-lane", str(args.targets_per_lane),
+                    "--j-split", str(args.j_split), "--source-path", str(args.source_path), "--wg-size", str(args.wg_size)]
+            live = live_pmc(tail)
+            if live and "error" not in live:
+                traffic, valu_busy = live["hbm_bytes_per_launch"], live["valu_busy"]
+                traffic_source = ("measured by this run: three 2-step child runs under rocprofv3 --pmc (FETCH_SIZE x2 gfx950 "
+                                  "correction + WRITE_SIZE; SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE), mean over the force launches")
         out = {
             "metric": "body-pair interactions/sec",
             "value": value,
@@ -429,8 +488,8 @@ def main():
             "exchange": sysm.exchange_mode,
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
-                         "traffic_source": (f"profiles/pmc_traffic.json ({pmc_tag}: builder's rocprofv3 PMC passes on this "
-                                            f"kernel, N and source split; not measured by this run)") if traffic else None,
+                         "traffic_source": traffic_source,
+                         "live_pmc": live,
                          "valu_busy": valu_busy,
                          "kernel": kname, "kernel_ms": k_ms,
                          "kernel_ms_spans": [kname] + ([reducer] if jsp > 1 else []),
@@ -446,7 +505,7 @@ def main():
                                          "the dense f32 MFMA peak, which is why the contract's hbm|mfma enum would say "
                                          "'mfma'); the kernel issues v_pk_*_f32 + v_rsq_f32 and no MFMA instruction",
                          "valu_busy_detail": "SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), "
-                                             "same committed PMC profile as `traffic`"},
+                                             "same source as `traffic` (see traffic_source)"},
         }
         if exchange_ms is not None:
             out["exchange_ms"] = exchange_ms  # one all-gather of float4[N] by itself, mean of 20
