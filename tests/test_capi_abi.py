@@ -167,3 +167,65 @@ def test_instrumented_build_exports_the_same_abi(nb):
         assert hasattr(L, name), name
     L.nb_abi_version.restype = C.c_int
     assert L.nb_abi_version() == 3
+
+
+def test_text_input_parses_like_the_reference_reads_it(nb, oracle, tmp_path):
+    """Property test of the input format (samples/nbody.cc:22-39: `fin >> double`): random systems — huge, tiny, negative,
+    subnormal-adjacent and integer-valued numbers, several whitespace layouts, arbitrary type words — written as text with
+    17 significant digits must come out of the product's parser (bin/nbconv -> NBODYST2 -> nb_read_state_file, no GPU
+    involved) as exactly the doubles that were written, with the `device` predicate and the header indices intact; and
+    the oracle's reader (the reference's operator>> restated) must agree."""
+    import subprocess
+
+    import numpy as np
+    from hypothesis import HealthCheck, given, settings
+    from hypothesis import strategies as st
+
+    finite = st.floats(allow_nan=False, allow_infinity=False, width=64)
+    body = st.tuples(*([finite] * 7), st.sampled_from(["device", "planet", "asteroid", "body", "Device", "devices", "x"]))
+    layout = st.sampled_from([" ", "  ", "\t", "\n"])
+
+    @settings(max_examples=25, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+    @given(st.lists(body, min_size=1, max_size=12), layout, st.data())
+    def check(bodies, sep, data):
+        n = len(bodies)
+        planet, asteroid = data.draw(st.integers(0, n - 1)), data.draw(st.integers(0, n - 1))
+        txt = tmp_path / "in.txt"
+        with open(txt, "w") as f:
+            f.write(f"{n}{sep}{planet}{sep}{asteroid}\n")
+            for b in bodies:
+                f.write(sep.join("%.17g" % x for x in b[:7]) + sep + b[7] + "\n")
+        st_path = tmp_path / "in.nbst"
+        subprocess.run([os.path.join(ROOT, "bin", "nbconv"), str(txt), str(st_path)], check=True)
+        h, q, v, m, dev = nb.capi.read_state_file(str(st_path))
+        want = np.array([b[:7] for b in bodies], dtype=np.float64)
+        assert (h["n"], h["planet"], h["asteroid"], h["step"]) == (n, planet, asteroid, 0)
+        got = np.concatenate([q, v, m[None, :]], axis=0).T
+        assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), (got, want)   # bit for bit, -0.0 included
+        assert list(dev) == [int(b[7] == "device") for b in bodies]
+        s = oracle.read_input(str(txt))
+        assert np.array_equal(np.concatenate([s.q, s.v, s.m[None, :]], axis=0).T.view(np.uint64), want.view(np.uint64))
+        assert list(s.is_device) == list(dev) and (s.planet, s.asteroid) == (planet, asteroid)
+
+    check()
+
+
+def test_output_format_matches_the_reference_stream_formatting(tmp_path):
+    """write_output (samples/nbody.cc:41-49: std::scientific << setprecision(digits10 + 1)): the product's writer, driven by
+    the sanitizer build of its I/O code, prints random answers — tiny, huge, negative, zero, three-digit exponents — exactly as
+    `%.16e` does, which is what the iostream manipulators produce and what the goldens contain."""
+    import random
+    import subprocess
+    subprocess.run(["make", "-C", ROOT, "asan"], check=True, stdout=subprocess.DEVNULL)
+    io = os.path.join(ROOT, "bin", "io_check_asan")
+    rng = random.Random(7)
+    inp = os.path.join(ROOT, "tests", "golden", "testcases", "b20.in")
+    for k in range(24):
+        d = rng.choice([0.0, 1.0, -1.5, 1e-300, 9.999999999999999e307, 1.1283183768746125e+07]) if k < 6 else \
+            rng.uniform(-1, 1) * 10.0 ** rng.randint(-120, 120)
+        cost = rng.choice([0.0, 1e5 + 1e3 * 60 * rng.randint(1, 200001)])
+        hit, dev = rng.choice([-2, 0, 5, 199999, 200000]), rng.choice([-1, 0, 7, 1023])
+        out = tmp_path / "o.out"
+        p = subprocess.run([io, inp, str(out), repr(d), str(hit), str(dev), repr(cost)], capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+        assert out.read_text() == "%.16e\n%d\n%d %.16e\n" % (d, hit, dev, cost)
