@@ -296,141 +296,8 @@ __device__ __forceinline__ void step_f64_body(const F64Args& a) {
 #endif
 }
 
-#ifndef NB_K2_DIRECT
-#define NB_K2_DIRECT 1  // 1: a whole wave per target and n <= 1024 take the barrier-free body below
-#endif
-
-// K2-direct (round 3): the same step for the shape every testcase beyond n = 128 gets — S = 64, a whole wave per target,
-// n <= 1024 — WITHOUT the LDS stage.  Lane l of a wave owns sources l, l + 64, ... (at most 16) exactly as in the staged
-// body, but loads them straight into registers (one coalesced 512-byte request per array per wave; the workgroup's other
-// three waves hit the same lines in the vector L1), computes G*m_eff for them itself, and every wave evaluates the O(1)
-// monitors on its own (wave-uniform addresses; identical inputs -> identical decisions): no ds_write, no s_barrier, no
-// ds_read in the pair loop — one dependent stage less between the loads and the arithmetic of a launch whose whole cost is
-// its dependent chain.  Same per-lane partial sums, same reduction tree, same update: results are bit for bit those of the
-// staged body.
-template <bool SELFCHECK>
-__device__ __forceinline__ void step_f64_direct(const F64Args& a) {
-    constexpr int S = 64, TPB = WG / S, MAXU = K2_TILE / S;  // 4 targets per workgroup, <= 16 sources per lane
-    const int t = threadIdx.x;
-    const int n = a.n;
-    const F64Scenario& sc = a.scn;
-    const int ls = t % S;
-    const int i = blockIdx.x * TPB + t / S;
-    const bool owner = (ls == 0) && (i < n);
-    const int ic = i < n ? i : n - 1;
-    const int nu = (n + S - 1) / S;  // passes over the lane's sources (workgroup-uniform)
-
-    double lx[MAXU], ly[MAXU], lz[MAXU], lm[MAXU], lc[MAXU];
-#pragma unroll
-    for (int u = 0; u < MAXU; ++u) {
-        if (u < nu) {
-            const int j = u * S + ls;
-            const int jc = j < n ? j : n - 1;
-            lx[u] = a.qin[jc]; ly[u] = a.qin[n + jc]; lz[u] = a.qin[2 * n + jc];
-            lm[u] = a.m[jc]; lc[u] = a.coef[jc];
-        }
-    }
-#if NB_STEP_STAMPS
-    const bool stamping = a.stamps && blockIdx.x == 0 && t == 0;
-    const unsigned long long t_entry = stamping ? wall_clock64() : 0;
-    unsigned long long* stamp = nullptr;
-#endif
-    const double xi = a.qin[ic], yi = a.qin[n + ic], zi = a.qin[2 * n + ic];
-    double vx0 = 0, vy0 = 0, vz0 = 0;
-    if (owner) { vx0 = a.v[i]; vy0 = a.v[n + i]; vz0 = a.v[2 * n + i]; }
-
-    int step = a.step, do_update = a.do_update;
-    double fst = a.fst;
-    if (a.ctl) {
-        fst = a.fst_chunk[a.t];
-        const F64Ctl ctl = *a.ctl;
-        step = ctl.base_step + a.t;
-        if (!ctl.active || step > a.last_step + 1) return;  // dormant slot / past the end: workgroup-uniform
-        do_update = step <= a.last_step;
-    }
-#if NB_STEP_STAMPS
-    if (stamping) {
-        stamp = a.stamps + 2 * (size_t)((a.ctl ? a.t - 1 : a.step) % a.stamp_slots);
-        stamp[0] = t_entry;
-        stamp[1] = 0;
-    }
-#endif
-
-    int skip = 0;
-    unsigned destroyed = 0, snap = 0;
-    monitor_f64(a, sc, n, step, blockIdx.x == 0 && t == 0, skip, destroyed, snap);
-    if (!do_update) skip = 1;
-
-    if (snap && owner && a.snap_q) {  // snapshot of (q,v) at missile arrival, from the not-yet-updated state (hw5.cu:277-285)
-        for (int k = 0; k < sc.n_watch; ++k)
-            if (snap & (1u << k)) {
-                double* dq = a.snap_q + (size_t)k * 3 * n;
-                double* dv = a.snap_v + (size_t)k * 3 * n;
-                dq[i] = xi; dq[n + i] = yi; dq[2 * n + i] = zi;
-                dv[i] = vx0; dv[n + i] = vy0; dv[2 * n + i] = vz0;
-            }
-    }
-    if (skip) return;  // the same decision in every lane of every workgroup
-
-    int dead_j = -1;  // a destroyed device has mass 0 from the step after its arrival (hw5.cu:306)
-    for (int k = 0; k < sc.n_watch; ++k)
-        if (destroyed & (1u << k)) dead_j = sc.watch[k];
-
-    double ax = 0, ay = 0, az = 0;
-#pragma unroll
-    for (int u = 0; u < MAXU; ++u) {
-        if (u < nu) {
-            const int j = u * S + ls;
-            if (j < n) {
-                // G*m_eff with the device-mass law, rounded exactly like the CPU reference (nbody.cc:14-16,61-64,70)
-                const double mj = __dadd_rn(lm[u], __dmul_rn(__dmul_rn(lc[u], lm[u]), fst));
-                const double g = (j == dead_j) ? 0.0 : __dmul_rn(a.G, mj);
-                double dx = lx[u] - xi;
-                double dy = ly[u] - yi;
-                double dz = lz[u] - zi;
-                double r2 = dx * dx + dy * dy + dz * dz + a.eps2;
-                double rinv = rsqrt_fast(r2);
-                double sc_ = g * rinv * rinv * rinv;
-                if (SELFCHECK) sc_ = (j == i) ? 0.0 : sc_;
-                ax += sc_ * dx;
-                ay += sc_ * dy;
-                az += sc_ * dz;
-            }
-        }
-    }
-    ax += shfl_xor_f64(ax, 32); ay += shfl_xor_f64(ay, 32); az += shfl_xor_f64(az, 32);
-    ax += shfl_xor_f64(ax, 16); ay += shfl_xor_f64(ay, 16); az += shfl_xor_f64(az, 16);
-    ax += row_shl_f64<8>(ax); ay += row_shl_f64<8>(ay); az += row_shl_f64<8>(az);
-    ax += row_shl_f64<4>(ax); ay += row_shl_f64<4>(ay); az += row_shl_f64<4>(az);
-    ax += row_shl_f64<2>(ax); ay += row_shl_f64<2>(ay); az += row_shl_f64<2>(az);
-    ax += row_shl_f64<1>(ax); ay += row_shl_f64<1>(ay); az += row_shl_f64<1>(az);
-
-    if (owner) {
-        if (a.acc_out) {
-            a.acc_out[i] = ax; a.acc_out[n + i] = ay; a.acc_out[2 * n + i] = az;
-        } else {
-            double vx = __dadd_rn(vx0, __dmul_rn(ax, a.dt));
-            double vy = __dadd_rn(vy0, __dmul_rn(ay, a.dt));
-            double vz = __dadd_rn(vz0, __dmul_rn(az, a.dt));
-            a.v[i] = vx; a.v[n + i] = vy; a.v[2 * n + i] = vz;
-            a.qout[i] = __dadd_rn(xi, __dmul_rn(vx, a.dt));
-            a.qout[n + i] = __dadd_rn(yi, __dmul_rn(vy, a.dt));
-            a.qout[2 * n + i] = __dadd_rn(zi, __dmul_rn(vz, a.dt));
-        }
-    }
-#if NB_STEP_STAMPS
-    if (stamp) stamp[1] = wall_clock64();
-#endif
-}
-
 template <int S, bool SELFCHECK>
 __global__ __launch_bounds__(WG) void nbody_step_f64(F64Args a) {
-    if constexpr (S == 64 && NB_K2_DIRECT) {
-        if (a.n <= K2_TILE) {  // kernel-uniform
-            step_f64_direct<SELFCHECK>(a);
-            return;
-        }
-    }
     step_f64_body<S, SELFCHECK>(a);
 }
 
@@ -441,12 +308,6 @@ template <int S, bool SELFCHECK>
 __global__ __launch_bounds__(WG) void nbody_step_f64_batched(F64BatchArgs b) {
     const F64Args& a = b.item[blockIdx.y];
     if (a.n <= 0) return;  // finished / not started: nothing to do for this slot
-    if constexpr (S == 64 && NB_K2_DIRECT) {
-        if (a.n <= K2_TILE) {
-            step_f64_direct<SELFCHECK>(a);
-            return;
-        }
-    }
     step_f64_body<S, SELFCHECK>(a);
 }
 
