@@ -122,6 +122,12 @@ __device__ __forceinline__ void monitor_f64(const F64Args& a, const F64Scenario&
     }
 }
 
+#ifndef NB_K2_WG
+#define NB_K2_WG 256  // threads per workgroup of the per-step kernel = 4 targets (one wave each) sharing one LDS stage of the
+                      // system.  Measured optimum (profiles/r03_k2_wg_sweep.txt, n = 1024): 128 -> 6.56, 256 -> 5.26,
+                      // 512 -> 5.44, 1024 -> 7.15 us/step
+#endif
+constexpr int K2_WG = NB_K2_WG;
 constexpr int K2_TILE = 1024;  // sources staged per pass: 4 per thread, 32 KB of LDS; n <= 1024 needs ONE pass
 
 // SELFCHECK: eps == 0 — the self pair must be skipped explicitly (r2 = 0); with eps > 0 it contributes s * 0 = +0 by
@@ -136,8 +142,8 @@ __device__ __forceinline__ void step_f64_body(const F64Args& a) {
     const int t = threadIdx.x;
     const int n = a.n;
     const F64Scenario& sc = a.scn;
-    constexpr int PER = K2_TILE / WG;                    // sources each thread stages per full pass
-    const int per_n = n >= K2_TILE ? PER : (n + WG - 1) / WG;  // ... and for a small system (workgroup-uniform)
+    constexpr int PER = K2_TILE / K2_WG;                    // sources each thread stages per full pass
+    const int per_n = n >= K2_TILE ? PER : (n + K2_WG - 1) / K2_WG;  // ... and for a small system (workgroup-uniform)
 
     // ---- first pass's source loads are issued BEFORE the monitor so that their latency and thread 0's dependent
     //      monitor chain (flag -> positions -> compare) overlap instead of adding up
@@ -146,7 +152,7 @@ __device__ __forceinline__ void step_f64_body(const F64Args& a) {
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             if (u < per_n) {
-                const int j = base + u * WG + t;
+                const int j = base + u * K2_WG + t;
                 const int jc = j < n ? j : n - 1;
                 lx[u] = a.qin[jc]; ly[u] = a.qin[n + jc]; lz[u] = a.qin[2 * n + jc];
                 lm[u] = a.m[jc]; lc[u] = a.coef[jc];
@@ -160,7 +166,7 @@ __device__ __forceinline__ void step_f64_body(const F64Args& a) {
     unsigned long long* stamp = nullptr;
 #endif
 
-    constexpr int TPB = WG / S;  // targets per workgroup
+    constexpr int TPB = K2_WG / S;  // targets per workgroup
     const int ls = t % S;        // this lane's slice of the source range
     const int i = blockIdx.x * TPB + t / S;
     const bool owner = (ls == 0) && (i < n);
@@ -211,7 +217,7 @@ __device__ __forceinline__ void step_f64_body(const F64Args& a) {
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             if (u < per_n) {
-                const int jl = u * WG + t;
+                const int jl = u * K2_WG + t;
                 const double mj = __dadd_rn(lm[u], __dmul_rn(__dmul_rn(lc[u], lm[u]), fst));
                 sx[jl] = lx[u]; sy[jl] = ly[u]; sz[jl] = lz[u];
                 sg[jl] = (base + jl < n) ? __dmul_rn(a.G, mj) : 0.0;  // G*mj, the reference's first product (nbody.cc:70)
@@ -297,7 +303,7 @@ __device__ __forceinline__ void step_f64_body(const F64Args& a) {
 }
 
 template <int S, bool SELFCHECK>
-__global__ __launch_bounds__(WG) void nbody_step_f64(F64Args a) {
+__global__ __launch_bounds__(K2_WG) void nbody_step_f64(F64Args a) {
     step_f64_body<S, SELFCHECK>(a);
 }
 
@@ -305,7 +311,7 @@ __global__ __launch_bounds__(WG) void nbody_step_f64(F64Args a) {
 // scenarios hw5 runs side by side (P3 per device: hw5.cu:587-588) then share ONE launch per step instead of contending
 // for the command processor with one launch stream each.  Every system carries its own step index, |sin| and monitor.
 template <int S, bool SELFCHECK>
-__global__ __launch_bounds__(WG) void nbody_step_f64_batched(F64BatchArgs b) {
+__global__ __launch_bounds__(K2_WG) void nbody_step_f64_batched(F64BatchArgs b) {
     const F64Args& a = b.item[blockIdx.y];
     if (a.n <= 0) return;  // finished / not started: nothing to do for this slot
     step_f64_body<S, SELFCHECK>(a);
@@ -675,21 +681,21 @@ int launch_f64_large(const F64LargeArgs& a, hipStream_t stream) {
 
 template <int S>
 static int launch_s(const F64Args& a, hipStream_t stream) {
-    constexpr int TPB = WG / S;
+    constexpr int TPB = K2_WG / S;
     // a monitor-only launch (do_update == 0) still needs every owner lane when a missile-arrival snapshot may be due
     int blocks = (a.do_update || a.snap_q) ? (a.n + TPB - 1) / TPB : 1;
-    if (a.eps2 > 0.0) hipLaunchKernelGGL((nbody_step_f64<S, false>), dim3(blocks), dim3(WG), 0, stream, a);
-    else hipLaunchKernelGGL((nbody_step_f64<S, true>), dim3(blocks), dim3(WG), 0, stream, a);
+    if (a.eps2 > 0.0) hipLaunchKernelGGL((nbody_step_f64<S, false>), dim3(blocks), dim3(K2_WG), 0, stream, a);
+    else hipLaunchKernelGGL((nbody_step_f64<S, true>), dim3(blocks), dim3(K2_WG), 0, stream, a);
     return (int)hipGetLastError();
 }
 
 template <int S>
 static int launch_batched_s(const F64BatchArgs& b, int n, hipStream_t stream) {
-    constexpr int TPB = WG / S;
+    constexpr int TPB = K2_WG / S;
     bool eps_positive = true;
     for (int k = 0; k < b.count; ++k) eps_positive &= (b.item[k].n <= 0 || b.item[k].eps2 > 0.0);
-    if (eps_positive) hipLaunchKernelGGL((nbody_step_f64_batched<S, false>), dim3((n + TPB - 1) / TPB, b.count), dim3(WG), 0, stream, b);
-    else hipLaunchKernelGGL((nbody_step_f64_batched<S, true>), dim3((n + TPB - 1) / TPB, b.count), dim3(WG), 0, stream, b);
+    if (eps_positive) hipLaunchKernelGGL((nbody_step_f64_batched<S, false>), dim3((n + TPB - 1) / TPB, b.count), dim3(K2_WG), 0, stream, b);
+    else hipLaunchKernelGGL((nbody_step_f64_batched<S, true>), dim3((n + TPB - 1) / TPB, b.count), dim3(K2_WG), 0, stream, b);
     return (int)hipGetLastError();
 }
 
@@ -753,7 +759,7 @@ int launch_f64(const F64Args& a, int S, hipStream_t stream) {
 // lane) 7.1, S = 16 10.5 (profiles/r02_scenario_batch_timing.txt; NB_F64_SPLIT overrides for experiments).
 int auto_split_f64(int n, int n_cus) {
     // beyond the testcase sizes the launch is compute-bound instead: give every SIMD ~4 waves of fp64 work
-    long want = (long)n_cus * WG * (n > K2_TILE ? 8 : 1);
+    long want = (long)n_cus * K2_WG * (n > K2_TILE ? 8 : 1);
     int S = 1;
     while (S < 64 && (long)n * S * 2 <= want) S <<= 1;
     return S;
