@@ -7,6 +7,9 @@
 //   V_SMEM     no LDS: sources are wave-uniform, fetched with scalar loads (s_load_dwordx4..16) into SGPRs,
 //              software-prefetched one batch ahead (compiler-scheduled)
 //   V_SMEM_PF  the same with the s_load / s_waitcnt placed by hand (inline asm, explicit SGPR ping-pong)
+//   V_SMEM_AB  V_SMEM with the batch loop unrolled by two over two named SGPR sets A/B (compiler-scheduled loads): each set is
+//              reloaded right after it was consumed, one whole batch ahead of its use, and nothing is copied at the loop end
+//              (V_SMEM ends every batch with s_waitcnt + 16 s_mov_b64 from the prefetch registers into the working set)
 //   template knobs: WGS (workgroup size), SYNC (barrier per 256 sources), STAG (de-phase waves sharing a SIMD),
 //   PF (touch-load L2 prefetch distance), js argument of run() (source slices over blockIdx.y)
 // Results of every round of experiments: profiles/r01_force_variants*.txt, profiles/r01_jsplit_search.txt
@@ -26,7 +29,7 @@ __device__ __forceinline__ v2f splat(float x) { return (v2f){x, x}; }
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
 constexpr int WG = 256, TILE = 256;
-enum { V_LDS = 0, V_STAGE = 1, V_SMEM = 2, V_SMEM_PF = 3 };
+enum { V_LDS = 0, V_STAGE = 1, V_SMEM = 2, V_SMEM_PF = 3, V_SMEM_AB = 4 };
 typedef float v16f __attribute__((ext_vector_type(16)));
 // 4 bodies (64 B) into 16 SGPRs; completion is NOT tracked by the compiler: pair with sload_wait() before use
 __device__ __forceinline__ v16f sload16(const float4* p) { v16f v; asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(v) : "s"(p)); return v; }
@@ -190,6 +193,25 @@ __global__ __launch_bounds__(WGS, MINW) void force(const float4* __restrict__ sr
             sload_wait_after(a, A.az[P - 1]);
             if (((j + 8) & (TILE - 1)) == 0) A.flush();
         }
+    } else if constexpr (VAR == V_SMEM_AB) {
+        float4 SA[U], SB[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) SA[u] = src[u];
+        for (long j = 0; j < n_src; j += 2 * U) {  // harness: n_src a multiple of 2U
+#pragma unroll
+            for (int u = 0; u < U; ++u) SB[u] = src[j + U + u];
+#pragma unroll
+            for (int u = 0; u < U; ++u) interact<P, ORDER>(SA[u], xi, yi, zi, eps2, A);
+            const long jn = (j + 2 * U < n_src) ? j + 2 * U : 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) SA[u] = src[jn + u];
+#pragma unroll
+            for (int u = 0; u < U; ++u) interact<P, ORDER>(SB[u], xi, yi, zi, eps2, A);
+            if (((j + 2 * U) & (TILE - 1)) == 0) {
+                A.flush();
+                if (SYNC) __syncthreads();
+            }
+        }
     } else if constexpr (VAR == V_SMEM) {
         // sources straight from memory with wave-uniform addresses (scalar loads), one batch prefetched ahead
         float4 cur[U], nxt[U];
@@ -292,17 +314,15 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&d_src, n_tgt * sizeof(float4))); CK(hipMalloc(&d_acc, 16 * n_tgt * sizeof(float4)));
     CK(hipMemcpy(d_src, h.data(), n_tgt * sizeof(float4), hipMemcpyHostToDevice));
     printf("n_tgt=%ld n_src=%ld\n", n_tgt, n_src);
-    // round 3: the order in which a source meets the P pairs (s_nop / forwarding-hazard question), product shape
-    // (512-thread workgroups, P = 4, U = 8, barrier per tile), whole range and 16 slices, each variant twice (A/B/A/B)
+    // round 3b: product shape (pairs of two, 512-thread workgroups compiled for 4 waves per SIMD = 128 VGPRs), loop-end
+    // copies vs A/B SGPR sets, batch of 8 and 16 sources; each twice
     for (int rep = 0; rep < 2; ++rep) {
-        run<4, V_SMEM, 8, 2, 512, true, 0, 0, 0>("SMEM P=4 U=8 wg512 order0 (product)", d_src, n_src, n_tgt, d_acc);
-        run<4, V_SMEM, 8, 2, 512, true, 0, 0, 1>("SMEM P=4 U=8 wg512 order1 gm-last", d_src, n_src, n_tgt, d_acc);
-        run<4, V_SMEM, 8, 2, 512, true, 0, 0, 2>("SMEM P=4 U=8 wg512 order2 pairs-of-2", d_src, n_src, n_tgt, d_acc);
-        run<4, V_SMEM, 8, 2, 512, true, 0, 0, 3>("SMEM P=4 U=8 wg512 order3 staged-4", d_src, n_src, n_tgt, d_acc);
-        run<4, V_SMEM, 8, 2, 512, true, 0, 0, 0>("SMEM P=4 U=8 wg512 order0 js16", d_src, n_src, n_tgt, d_acc, 16);
-        run<4, V_SMEM, 8, 2, 512, true, 0, 0, 1>("SMEM P=4 U=8 wg512 order1 js16", d_src, n_src, n_tgt, d_acc, 16);
-        run<4, V_SMEM, 8, 2, 512, true, 0, 0, 2>("SMEM P=4 U=8 wg512 order2 js16", d_src, n_src, n_tgt, d_acc, 16);
-        run<4, V_SMEM, 8, 2, 512, true, 0, 0, 3>("SMEM P=4 U=8 wg512 order3 js16", d_src, n_src, n_tgt, d_acc, 16);
+        run<4, V_SMEM, 8, 4, 512, true, 0, 0, 2>("SMEM    U=8  order2 4w (product)", d_src, n_src, n_tgt, d_acc);
+        run<4, V_SMEM_AB, 8, 4, 512, true, 0, 0, 2>("SMEM_AB U=8  order2 4w", d_src, n_src, n_tgt, d_acc);
+        run<4, V_SMEM, 16, 4, 512, true, 0, 0, 2>("SMEM    U=16 order2 4w", d_src, n_src, n_tgt, d_acc);
+        run<4, V_SMEM_AB, 4, 4, 512, true, 0, 0, 2>("SMEM_AB U=4  order2 4w", d_src, n_src, n_tgt, d_acc);
+        run<4, V_SMEM, 8, 4, 512, true, 0, 0, 2>("SMEM    U=8  order2 4w js16", d_src, n_src, n_tgt, d_acc, 16);
+        run<4, V_SMEM_AB, 8, 4, 512, true, 0, 0, 2>("SMEM_AB U=8  order2 4w js16", d_src, n_src, n_tgt, d_acc, 16);
     }
     return 0;
 }

@@ -206,7 +206,9 @@ __global__ __launch_bounds__(WGS, (WGS == 1024 ? 4 : WGS == 512 ? (SPLIT ? NB_K1
         const long jb = j0 + (j1 - j0) / U * U;  // end of the whole batches
         if (jb > j0) {
             // wave-uniform addresses on a read-only array: the compiler selects s_load_dwordx16; one batch is
-            // requested ahead of the one being consumed
+            // requested ahead of the one being consumed.  (Two named SGPR sets with the loop unrolled by two — no s_waitcnt +
+            // 16 s_mov_b64 at the loop end — measured +2.5 % on an unsliced launch in the harness and +0.2 % on the sliced
+            // product launch, below the noise between devices: not adopted, profiles/r03_k1_sgpr_ab.txt.)
             float4 cur[U], nxt[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) cur[u] = a.src[j0 + u];
