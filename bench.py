@@ -103,7 +103,7 @@ def load_traffic(n_bodies, world, kernel, j_split):
     return e.get("hbm_bytes_per_launch"), e.get("reduce_share_of_span"), e.get("valu_busy"), e.get("tag")
 
 
-def live_pmc(argv_tail, kernel_prefix="nbody_force_f32", timeout=150):
+def live_pmc(argv_tail, kernel_prefix="nbody_force_f32", timeout=90):
     """HBM traffic and VALU-busy of the force kernel measured BY THIS RUN: three short child runs of this same program
     (2 steps each) under `rocprofv3 --pmc`, one counter group per pass as the guide prescribes — FETCH_SIZE, WRITE_SIZE,
     then SQ_ACTIVE_INST_VALU + GRBM_GUI_ACTIVE — with the program directly after `--`.  FETCH_SIZE / WRITE_SIZE are KiB;
