@@ -30,6 +30,17 @@ PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 flop/c
 ISSUE_CEILING_FRAC = 0.62     # what the pair loop's instruction mix can issue (derivation in the JSON and DESIGN.md §3)
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(n_sample=16384, steps=2):
     """Reference run_step on the first n_sample synthetic bodies, single thread (what samples/nbody.cc is)."""
     import numpy as np
@@ -55,7 +66,7 @@ def cpu_baseline(n_sample=16384, steps=2):
         dt = time.perf_counter() - t0
         what = "oracle/nbody_oracle.c run_step (bit-identical restatement)"
     assert np.isfinite(s.q).all()
-    return {"value": pairs / dt, "unit": "pairs/s", "cores": 1, "kind": kind,
+    return {"value": pairs / dt, "unit": "pairs/s", "cores": 1, "kind": kind, "cpu_model": cpu_model(),
             "sample": f"{what}, {steps} steps on the first {n_sample} bodies of the same synthetic input "
                       f"({pairs:.3g} pairs, {dt:.1f} s)"}
 
@@ -81,7 +92,7 @@ def cpu_baseline_all_cores(n_total, rows=2048):
     dt = time.perf_counter() - t0
     assert np.isfinite(a).all()
     pairs = rows * (n_total - 1)
-    return {"value": pairs / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+    return {"value": pairs / dt, "unit": "pairs/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
             "sample": f"oracle/nbody_oracle.c accel rows (OpenMP, {cores} threads), {rows} targets x {n_total} sources "
                       f"of the same input ({pairs:.3g} pairs, {dt:.1f} s)"}
 
