@@ -48,8 +48,15 @@ oracle:
 	$(MAKE) -C oracle
 
 # host-side sanitizer builds (GPU AddressSanitizer is not available on the pool): text I/O + the CPU checker
-asan: bin/io_check_asan
+asan: bin/io_check_asan bin/asan/hw5
 	$(MAKE) -C oracle asan
+# the whole product with HOST-side AddressSanitizer (device code is the plain gfx950 build: -fno-gpu-sanitize, no xnack): the
+# threaded nb_solve host, graph scheduler, follower queue and I/O under ASan on a real GPU
+# (tests/test_gpu_solve_schedule.py::test_whole_program_under_host_asan)
+bin/asan/hw5: $(KSRC) $(HOSTSRC) $(HDR) $(SRC)/nbody_internal.h $(SRC)/main_hw5.cpp $(SRC)/nbody_io.cpp $(SRC)/nbody_io_state.cpp $(SRC)/nbody_io.h
+	@mkdir -p bin/asan
+	$(HIPCC) --offload-arch=$(ARCH) -O1 -g -std=c++17 -fPIC -fsanitize=address -fno-gpu-sanitize -shared -o bin/asan/libnbody_amd.so $(KSRC) -x hip $(HOSTSRC) -lpthread -ldl
+	$(HIPCC) -O1 -g -std=c++17 -fsanitize=address -fno-gpu-sanitize -o $@ $(SRC)/main_hw5.cpp $(SRC)/nbody_io.cpp $(SRC)/nbody_io_state.cpp -Lbin/asan -lnbody_amd -Wl,-rpath,'$$ORIGIN' -lpthread
 bin/io_check_asan: $(SRC)/io_check.cpp $(SRC)/nbody_io.cpp $(SRC)/nbody_io.h
 	@mkdir -p bin
 	g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=all -o $@ $(SRC)/io_check.cpp $(SRC)/nbody_io.cpp

@@ -364,3 +364,22 @@ def _stamps_checks(c, s):
             assert np.all(st[k + 1, 0] >= st[k, 1])       # a node starts after its predecessor's last store
     with c.Context(1024, c.NB_F32, eps=1e-3) as x, pytest.raises(c.NBodyError):
         x.enable_step_stamps(8)  # fp64 engine only
+
+
+@pytest.mark.parametrize("case,devices,handoff", [("b30", "0", ""), ("b200", "0,0", "host"), ("b512", "0,0", "host"),
+                                                  ("b1024", "0", "")])
+def test_whole_program_under_host_asan(nb, case, devices, handoff, tmp_path):
+    """bin/asan/hw5 (`make asan`): the product's host code — nb_solve's threads, the graph scheduler and follower queue, the
+    host-staged hand-off, the I/O — compiled with AddressSanitizer (device code: the plain gfx950 build) and run on the GPU.
+    No report, golden output.  (GPU-side sanitizers are not available on the pool; the reference's equivalent was
+    cuda-memcheck, hw5.cu:631-642.)"""
+    exe = os.path.join(ROOT, "bin", "asan", "hw5")
+    if not os.path.exists(exe):
+        pytest.skip("bin/asan/hw5 not built (make asan)")
+    out = str(tmp_path / "out")
+    env = dict(os.environ, NB_DEVICES=devices, NB_HW5_CLEAN_EXIT="1", ASAN_OPTIONS="detect_leaks=0")
+    if handoff:
+        env["NB_SOLVE_HANDOFF"] = handoff
+    p = subprocess.run([exe, case_path(case, "in"), out], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0 and "AddressSanitizer" not in p.stderr, p.stderr[-2000:]
+    assert open(out).read() == read_golden(case)[4]
