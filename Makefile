@@ -48,18 +48,19 @@ oracle:
 	$(MAKE) -C oracle
 
 # host-side sanitizer builds (GPU AddressSanitizer is not available on the pool): text I/O + the CPU checker
-asan: bin/io_check_asan bin/asan/hw5
+asan: bin/io_check_asan bin/asan/hw5 bin/asan/nbody_bench
 	$(MAKE) -C oracle asan
 # the whole product with HOST-side AddressSanitizer (device code is the plain gfx950 build: -fno-gpu-sanitize, no xnack): the
 # threaded nb_solve host, graph scheduler, follower queue and I/O under ASan on a real GPU
 # (tests/test_gpu_solve_schedule.py::test_whole_program_under_host_asan)
-bin/asan/hw5: $(KSRC) $(HOSTSRC) $(HDR) $(SRC)/nbody_internal.h $(SRC)/main_hw5.cpp $(SRC)/nbody_io.cpp $(SRC)/nbody_io_state.cpp $(SRC)/nbody_io.h
+ASANFLAGS := -O1 -g -std=c++17 -fsanitize=address -fno-gpu-sanitize
+bin/asan/libnbody_amd.so: $(KSRC) $(HOSTSRC) $(HDR) $(SRC)/nbody_internal.h
 	@mkdir -p bin/asan
-	$(HIPCC) --offload-arch=$(ARCH) -O1 -g -std=c++17 -fPIC -fsanitize=address -fno-gpu-sanitize -shared -o bin/asan/libnbody_amd.so $(KSRC) -x hip $(HOSTSRC) -lpthread -ldl
-	$(HIPCC) -O1 -g -std=c++17 -fsanitize=address -fno-gpu-sanitize -o $@ $(SRC)/main_hw5.cpp $(SRC)/nbody_io.cpp $(SRC)/nbody_io_state.cpp -Lbin/asan -lnbody_amd -Wl,-rpath,'$$ORIGIN' -lpthread
-bin/io_check_asan: $(SRC)/io_check.cpp $(SRC)/nbody_io.cpp $(SRC)/nbody_io.h
-	@mkdir -p bin
-	g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=all -o $@ $(SRC)/io_check.cpp $(SRC)/nbody_io.cpp
+	$(HIPCC) --offload-arch=$(ARCH) $(ASANFLAGS) -fPIC -shared -o $@ $(KSRC) -x hip $(HOSTSRC) -lpthread -ldl
+bin/asan/hw5: $(SRC)/main_hw5.cpp $(SRC)/nbody_io.cpp $(SRC)/nbody_io_state.cpp $(SRC)/nbody_io.h bin/asan/libnbody_amd.so
+	$(HIPCC) $(ASANFLAGS) -o $@ $(SRC)/main_hw5.cpp $(SRC)/nbody_io.cpp $(SRC)/nbody_io_state.cpp -Lbin/asan -lnbody_amd -Wl,-rpath,'$$ORIGIN' -lpthread
+bin/asan/nbody_bench: $(SRC)/main_nbody_bench.cpp bin/asan/libnbody_amd.so
+	$(HIPCC) $(ASANFLAGS) -o $@ $(SRC)/main_nbody_bench.cpp -Lbin/asan -lnbody_amd -Wl,-rpath,'$$ORIGIN' -lpthread
 
 ubench: bench/ubench/valu_rate bench/ubench/force_variants bench/ubench/launch_rate bench/debug/startup_probe
 bench/debug/startup_probe: bench/debug/startup_probe.cpp $(LIB)
