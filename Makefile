@@ -53,7 +53,7 @@ asan: bin/io_check_asan bin/asan/hw5 bin/asan/nbody_bench
 # the whole product with HOST-side AddressSanitizer (device code is the plain gfx950 build: -fno-gpu-sanitize, no xnack): the
 # threaded nb_solve host, graph scheduler, follower queue and I/O under ASan on a real GPU
 # (tests/test_gpu_solve_schedule.py::test_whole_program_under_host_asan)
-ASANFLAGS := -O1 -g -std=c++17 -fsanitize=address -fno-gpu-sanitize
+ASANFLAGS := -O1 -g -std=c++17 -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-gpu-sanitize
 bin/asan/libnbody_amd.so: $(KSRC) $(HOSTSRC) $(HDR) $(SRC)/nbody_internal.h
 	@mkdir -p bin/asan
 	$(HIPCC) --offload-arch=$(ARCH) $(ASANFLAGS) -fPIC -shared -o $@ $(KSRC) -x hip $(HOSTSRC) -lpthread -ldl

@@ -370,7 +370,7 @@ def _stamps_checks(c, s):
                                                   ("b1024", "0", "")])
 def test_whole_program_under_host_asan(nb, case, devices, handoff, tmp_path):
     """bin/asan/hw5 (`make asan`): the product's host code — nb_solve's threads, the graph scheduler and follower queue, the
-    host-staged hand-off, the I/O — compiled with AddressSanitizer (device code: the plain gfx950 build) and run on the GPU.
+    host-staged hand-off, the I/O — compiled with AddressSanitizer + UBSan (device code: the plain gfx950 build) and run on the GPU.
     No report, golden output.  (GPU-side sanitizers are not available on the pool; the reference's equivalent was
     cuda-memcheck, hw5.cu:631-642.)"""
     exe = os.path.join(ROOT, "bin", "asan", "hw5")
@@ -381,5 +381,5 @@ def test_whole_program_under_host_asan(nb, case, devices, handoff, tmp_path):
     if handoff:
         env["NB_SOLVE_HANDOFF"] = handoff
     p = subprocess.run([exe, case_path(case, "in"), out], capture_output=True, text=True, timeout=600, env=env)
-    assert p.returncode == 0 and "AddressSanitizer" not in p.stderr, p.stderr[-2000:]
+    assert p.returncode == 0 and "AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr, p.stderr[-2000:]
     assert open(out).read() == read_golden(case)[4]
