@@ -148,7 +148,6 @@ struct FollowerPolicy {
 };
 // all groups to completion, one host thread
 int run_groups_graph(std::vector<GraphGroup*>& groups, const FollowerPolicy& policy);
-int default_graph_chunk();
 bool valid_graph_chunk(int chunk);
 
 nbk::F64Scenario device_scenario(const nb_context* c, const nb_scenario* s);

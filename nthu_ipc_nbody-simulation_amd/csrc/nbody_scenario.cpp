@@ -167,7 +167,6 @@ constexpr int GRAPH_CHUNK_DEFAULT = 1000;  // K2, graph-driven: steps per replay
                                            // in place after a chunk); nb_scenario.graph_chunk / nb_solve_options.graph_chunk
                                            // override it per run (shorter graphs for tracing tools)
 }  // namespace
-int nbi::default_graph_chunk() { return GRAPH_CHUNK_DEFAULT; }
 bool nbi::valid_graph_chunk(int chunk) { return chunk >= 2 && chunk <= 4000 && chunk % 2 == 0; }
 namespace {
 constexpr int GRAPH_MIN_STEPS = 4000;  // shorter ranges are launched eagerly: capture + instantiate would cost more
