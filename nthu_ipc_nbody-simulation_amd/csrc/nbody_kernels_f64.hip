@@ -548,8 +548,14 @@ __global__ __launch_bounds__(WG) void nbody_gm_f64(const double* __restrict__ m,
     if (j < n) gm[j] = __dmul_rn(G, __dadd_rn(m[j], __dmul_rn(__dmul_rn(coef[j], m[j]), fst)));  // as K2 / nbody.cc:14-16,70
 }
 
-constexpr int F64L_R = 2;      // targets per lane
-constexpr int F64L_BATCH = 4;  // sources per scalar-load batch: 4 planes x 8 dwords = 32 SGPRs, two batches live
+#ifndef NB_F64L_R
+#define NB_F64L_R 2
+#endif
+#ifndef NB_F64L_BATCH
+#define NB_F64L_BATCH 4
+#endif
+constexpr int F64L_R = NB_F64L_R;          // targets per lane
+constexpr int F64L_BATCH = NB_F64L_BATCH;  // sources per scalar-load batch: 4 planes x 8 dwords = 32 SGPRs, two batches live
 
 template <bool SPLIT, bool ACCEL_ONLY, bool SELFCHECK>
 __global__ __launch_bounds__(WG, 4) void nbody_force_f64_large(F64LargeArgs a) {
