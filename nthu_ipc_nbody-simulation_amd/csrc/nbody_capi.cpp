@@ -212,9 +212,8 @@ int nbi::create_context(nb_context** out, const nb_config* cfg, hipStream_t borr
     for (int k = 0; k < NB_MAX_WATCH; ++k) c->snap_arrival[k] = -2;
     *out = c;  // returned even on failure so the caller can read nb_last_error, then nb_destroy
     NB_HIP(c, hipSetDevice(cfg->device));
-    hipDeviceProp_t prop;
-    NB_HIP(c, hipGetDeviceProperties(&prop, cfg->device));
-    c->n_cus = prop.multiProcessorCount;
+    // (one attribute, not hipGetDeviceProperties: nb_solve creates 2 + D contexts per program run)
+    NB_HIP(c, hipDeviceGetAttribute(&c->n_cus, hipDeviceAttributeMultiprocessorCount, cfg->device));
     // nb_config.cu_mask (bench/scenario_concurrency.py) confines this context's stream to half of the compute units, so
     // that two scenario streams do not share CUs
     if (borrowed) {
