@@ -241,7 +241,10 @@ typedef struct nb_launch_f32 {
     void* vel64; /* NULL unless acc64 */
     void* acc;   /* nb_launch_accel_f32 only: float4[n_tgt] {ax,ay,az,0} (acc64: double4[n_tgt]) */
     void* workspace; /* optional scratch for source slicing (partial + running sums); NULL -> never slice */
-    int64_t workspace_bytes; /* its size; must be >= nb_workspace_bytes_f32() or the sources are not sliced */
+    int64_t workspace_bytes; /* its size; must be >= nb_workspace_bytes_f32() (18 records per target: 16 partial-sum slots,
+                                running sum, compensation) or the sources are not sliced.  A larger one — up to 66 records —
+                                gives a launch as many slots, so that a step of up to 64 slices is ONE force launch + ONE
+                                reducer instead of j_split/16 of each (results are bit for bit the same) */
     int64_t n_src;
     int64_t tgt_off;
     int64_t n_tgt;

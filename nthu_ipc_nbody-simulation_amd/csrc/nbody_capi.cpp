@@ -551,6 +551,15 @@ static int check_launch(const nb_launch_f32* a, bool accel_only) {
     return NB_OK;
 }
 
+// partial-sum slots the caller's workspace holds beside the running sum and its compensation (18 records per target is the
+// documented minimum; a larger workspace, up to 66 records, lets up to 64 slices go out in one launch)
+static int workspace_slots(const nb_launch_f32* a) {
+    if (!a->workspace || a->n_tgt <= 0) return 0;
+    const size_t rec = a->acc64 ? sizeof(double4) : sizeof(float4);
+    const long records = (long)((size_t)a->workspace_bytes / ((size_t)a->n_tgt * rec));
+    return (int)std::min<long>(std::max<long>(records - 2, 0), MAX_SLICES_PER_LAUNCH);
+}
+
 static F32Plan resolve_plan(const nb_launch_f32* a) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -559,8 +568,7 @@ static F32Plan resolve_plan(const nb_launch_f32* a) {
     F32Plan p = plan_f32(a->n_tgt, n_cover, cus, a->targets_per_lane, a->j_split, a->workspace != nullptr,
                          a->source_path, a->wg_size);
     // the caller's workspace must hold SLICES_PER_LAUNCH partial records + running sum + compensation per target
-    const size_t rec = a->acc64 ? sizeof(double4) : sizeof(float4);
-    if ((size_t)(SLICES_PER_LAUNCH + 2) * (size_t)a->n_tgt * rec > (size_t)a->workspace_bytes) p.j_split = 1;
+    if (workspace_slots(a) < SLICES_PER_LAUNCH) p.j_split = 1;
     return p;
 }
 
@@ -574,6 +582,7 @@ static F32Args to_args(const nb_launch_f32* a) {
     k.vel64 = (double4*)a->vel64;
     k.acc = a->acc;
     k.partial = a->workspace;
+    k.slots = workspace_slots(a);
     k.n_src = a->n_src;
     k.tgt_off = a->tgt_off;
     k.n_tgt = a->n_tgt;

@@ -31,6 +31,9 @@ struct F32Args {
     long src_begin, src_end;  // sources of THIS launch sequence: [src_begin, src_end) (src_begin a multiple of 256);
                               // 0,0 = all n_src.  A step may be cut into several such phases (own shard first, the
                               // gathered remote shards later): the running sum in the workspace carries across them
+    int slots;                // partial-sum slots the workspace holds = blockIdx.y extent of one split launch: 0 -> the default
+                              // SLICES_PER_LAUNCH; a larger workspace (up to MAX_SLICES_PER_LAUNCH) lets a step with more
+                              // slices go out as ONE launch + ONE reducer instead of js/16 of each
     int phase;                // F32_PHASE_* below
     long tiles_per_slice;  // SPLIT launches: 256-source tiles per source slice ...
     int slice0;            // ... and the index of the slice blockIdx.y == 0 works on
@@ -40,7 +43,8 @@ constexpr int F32_PHASE_WHOLE = 0;   // all of the step: start the sums, run the
 constexpr int F32_PHASE_FIRST = 1;   // start the sums, keep them in the workspace
 constexpr int F32_PHASE_LAST = 2;    // continue the sums, then the epilogue (store accelerations / kick-drift)
 constexpr int F32_PHASE_MIDDLE = 3;  // continue the sums, keep them
-constexpr int SLICES_PER_LAUNCH = 16;  // blockIdx.y extent of one split launch = partial-sum slots in the workspace
+constexpr int SLICES_PER_LAUNCH = 16;  // default blockIdx.y extent of one split launch = partial-sum slots in the workspace
+constexpr int MAX_SLICES_PER_LAUNCH = 64;
 constexpr int MAX_JSPLIT = 1024;       // source slices per step (processed SLICES_PER_LAUNCH at a time)
 struct F32Plan {
     int targets_per_lane = 4;  // 2, 4 or 8 (one, two or four packed pairs per lane)

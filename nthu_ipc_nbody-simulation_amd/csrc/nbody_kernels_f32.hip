@@ -276,7 +276,7 @@ template <bool ACC64, bool ACCEL_ONLY>
 __global__ __launch_bounds__(WG) void nbody_reduce_update_f32(F32Args a, int gy, int first, int last) {
     const long i = (long)blockIdx.x * WG + threadIdx.x;
     if (i >= a.n_tgt) return;
-    const long run_at = (long)SLICES_PER_LAUNCH * a.n_tgt + i, comp_at = run_at + a.n_tgt;
+    const long run_at = (long)a.slots * a.n_tgt + i, comp_at = run_at + a.n_tgt;  // behind the launch's partial-sum slots
     if (ACC64) {
         double4* ws = (double4*)a.partial;
         double4 run = first ? make_double4(0, 0, 0, 0) : ws[run_at];
@@ -334,8 +334,10 @@ static int launch_one(const F32Args& a0, int js, hipStream_t stream) {
     a.tiles_per_slice = (ntiles + js - 1) / js;
     if (a.tiles_per_slice < 1) a.tiles_per_slice = 1;  // an empty range still runs its reducer (phase bookkeeping)
     const long rblocks = (a.n_tgt + WG - 1) / WG;
-    for (int s0 = 0; s0 < js; s0 += SLICES_PER_LAUNCH) {  // 16 slices per launch; the running sum carries across
-        const int gy = js - s0 < SLICES_PER_LAUNCH ? js - s0 : SLICES_PER_LAUNCH;
+    if (a.slots <= 0) a.slots = SLICES_PER_LAUNCH;
+    if (a.slots > MAX_SLICES_PER_LAUNCH) a.slots = MAX_SLICES_PER_LAUNCH;
+    for (int s0 = 0; s0 < js; s0 += a.slots) {  // `slots` slices per launch; the running sum carries across launches
+        const int gy = js - s0 < a.slots ? js - s0 : a.slots;
         a.slice0 = s0;
         hipLaunchKernelGGL((nbody_force_f32<P, ACC64, ACCEL_ONLY, true, SGPR, WGS>), dim3((unsigned)blocks, (unsigned)gy),
                            dim3(WGS), 0, stream, a);

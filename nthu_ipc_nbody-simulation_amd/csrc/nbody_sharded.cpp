@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -86,6 +87,7 @@ struct Rank {
     double4* pos64 = nullptr;
     double4* vel64 = nullptr;
     void* ws = nullptr;
+    int ws_slots = 0;  // partial-sum slots of `ws` (>= 16; up to 64 when the plan cuts the sources into that many slices)
     ncclComm_t comm = nullptr;
 };
 
@@ -130,7 +132,18 @@ bool acc64(const nb_sharded* s) { return s->precision == NB_F32_ACC64; }
 bool overlapped(const nb_sharded* s) { return (s->flags & NB_SHARDED_OVERLAP) && s->P > 1; }
 bool copy_exchange(const nb_sharded* s) { return (s->flags & NB_SHARDED_COPY_EXCHANGE) != 0; }
 
-int64_t workspace_bytes(const nb_sharded* s) { return nb_workspace_bytes_f32(s->per, acc64(s)); }
+// slots of the source-slice workspace: the documented minimum of 16, or as many as the whole-step plan has slices (up to
+// 64) so that a step is ONE force launch + ONE reducer per phase instead of js/16 of each — N = 2^20 over 8 ranks
+// (64 slices): 29.7 instead of 30.5 ms per step and rank (profiles/r03_shard_slots.txt); at most 8 GiB
+int workspace_slots(const nb_sharded* s, int n_cus) {
+    const int js = plan_f32(s->per, s->n, n_cus, 0, 0, true).j_split;
+    const int64_t rec = nb_workspace_bytes_f32(s->per, acc64(s)) / (SLICES_PER_LAUNCH + 2);
+    const int64_t cap = ((int64_t)8 << 30) / rec - 2;
+    return (int)std::max<int64_t>(SLICES_PER_LAUNCH, std::min<int64_t>(std::min<int64_t>(js, MAX_SLICES_PER_LAUNCH), cap));
+}
+int64_t workspace_bytes(const nb_sharded* s, int slots) {
+    return nb_workspace_bytes_f32(s->per, acc64(s)) / (SLICES_PER_LAUNCH + 2) * (slots + 2);
+}
 
 // one phase of rank r's step: sources [src_begin, src_end) of the gathered array `cur`
 int launch_phase(nb_sharded* s, Rank& k, int64_t src_begin, int64_t src_end, int phase) {
@@ -141,6 +154,7 @@ int launch_phase(nb_sharded* s, Rank& k, int64_t src_begin, int64_t src_end, int
     a.pos64 = k.pos64;
     a.vel64 = k.vel64;
     a.partial = k.ws;
+    a.slots = k.ws_slots;
     a.n_src = s->n;
     a.tgt_off = k.lo;
     a.n_tgt = s->per;
@@ -320,8 +334,10 @@ int create_impl(nb_sharded** out, const int* devices, int n_devices, int64_t n, 
         }
         // the workspace lets the step slice the sources (and carry sums between phases): allocate it whenever the plan
         // would slice, and always for overlap
-        if (overlapped(s) || plan_f32(s->per, s->n, k.n_cus, 0, 0, true).j_split > 1)
-            SH_HIP(s, hipMalloc(&k.ws, (size_t)workspace_bytes(s)));
+        if (overlapped(s) || plan_f32(s->per, s->n, k.n_cus, 0, 0, true).j_split > 1) {
+            k.ws_slots = workspace_slots(s, k.n_cus);
+            SH_HIP(s, hipMalloc(&k.ws, (size_t)workspace_bytes(s, k.ws_slots)));
+        }
     }
     if (copy_exchange(s)) {
         // direct xGMI copies between distinct GPUs; without peer access the runtime stages through the host, which is

@@ -41,6 +41,19 @@ def shard_range(n, rank, world):
     return rank * per, (rank + 1) * per
 
 
+def workspace_bytes(n_src, n_tgt, acc64=False, targets_per_lane=0, j_split=0, source_path=0, wg_size=0, cap=8 << 30):
+    """Bytes of the source-slice workspace for one rank's launches: running sum + compensation + one partial-sum slot per
+    source slice of a launch.  The documented minimum is 16 slots (capi.workspace_bytes_f32); a shard whose plan cuts the
+    sources into more slices gets up to 64 slots, so that the whole step is ONE force launch + ONE reducer instead of
+    js/16 of each (N = 2^20 over 8 ranks, 64 slices: 29.7 instead of 30.5 ms per step and rank,
+    profiles/r03_shard_slots.txt), within `cap` bytes."""
+    base = capi.workspace_bytes_f32(n_tgt, acc64)
+    _, js, _ = capi.plan_f32(n_src, n_tgt, acc64, targets_per_lane, j_split, base, source_path, wg_size)
+    rec = base // 18
+    slots = max(16, min(64, js, cap // rec - 2))
+    return (slots + 2) * rec
+
+
 def hip_compute(acc64=False, targets_per_lane=0, j_split=0, source_path=0, wg_size=0):
     """The product compute step: nb_launch_step_f32 on torch's current HIP stream.  The j-split workspace
     (partial sums when a shard's targets alone cannot fill the chip) is a torch tensor allocated once."""
@@ -52,8 +65,8 @@ def hip_compute(acc64=False, targets_per_lane=0, j_split=0, source_path=0, wg_si
             raise RuntimeError("nbody_amd has no CPU compute path: tensors must live on a HIP device")
         key = (src.device, src.shape[0], n_tgt)
         if key not in ws:
-            # 18 records per target: 16 partial-sum slots of one launch + running sum + compensation
-            ws[key] = torch.empty(capi.workspace_bytes_f32(n_tgt, acc64), dtype=torch.uint8, device=src.device)
+            ws[key] = torch.empty(workspace_bytes(src.shape[0], n_tgt, acc64, targets_per_lane, j_split, source_path,
+                                                  wg_size), dtype=torch.uint8, device=src.device)
         w = ws[key]
         stream = torch.cuda.current_stream(src.device).cuda_stream
         capi.launch_f32(src.data_ptr(), out.data_ptr(), src.shape[0], off, n_tgt, eps2, dt, stream,

@@ -420,3 +420,43 @@ def test_travelling_source_blocks_against_the_oracle(nb, oracle, acc64):
     assert np.abs(q_gpu - q_ref).max() <= (1e-9 if acc64 else 1.2e-7)       # fp32 drift rounds at ulp(1)/2 = 6e-8
     if acc64:  # the fp32 copy that travels on is the rounded master
         assert np.array_equal(o[tgt_off:tgt_off + n_tgt, :3], p64.cpu().numpy()[:, :3].astype(np.float32))
+
+
+@pytest.mark.parametrize("acc64", [False, True])
+def test_one_launch_of_many_slices_equals_several_launches(nb, acc64):
+    """A workspace with more than the minimum of 16 partial-sum slots (up to 64) lets a step of js > 16 source slices go
+    out as ONE force launch + ONE reducer instead of js/16 of each: the reducer folds the same slices in the same order,
+    so accelerations and the fused update are bit for bit the same — also across the phases of a cut step."""
+    import torch
+    c, syn = nb.capi, nb.synthetic
+    n, off, cnt, js, dt = 16384 + 77, 2048, 4096, 40, 1e-2
+    pos, _ = syn.body4_f32(n)
+    _, vel_np = syn.body4_f32(n, off, off + cnt)
+    src = torch.from_numpy(pos).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    rec = 32 if acc64 else 16
+    outs = []
+    for slots in (16, 64, 24):
+        ws = torch.empty((slots + 2) * cnt * rec, dtype=torch.uint8, device="cuda")
+        assert ws.numel() >= c.workspace_bytes_f32(cnt, acc64)
+        acc = torch.zeros((cnt, 4), dtype=torch.float64 if acc64 else torch.float32, device="cuda")
+        kw = dict(workspace_ptr=ws.data_ptr(), workspace_bytes=ws.numel(), acc64=acc64, j_split=js)
+        c.launch_f32(src.data_ptr(), 0, n, off, cnt, syn.EPS ** 2, dt, stream, accel_only=True, acc_ptr=acc.data_ptr(), **kw)
+        out = torch.zeros_like(src)
+        if acc64:
+            q, v, m = syn.bodies(n, off, off + cnt)
+            p64 = torch.from_numpy(np.ascontiguousarray(np.concatenate([q.T, (syn.G * m)[:, None]], axis=1))).cuda()
+            v64 = torch.from_numpy(np.ascontiguousarray(np.concatenate([v.T, np.zeros((cnt, 1))], axis=1))).cuda()
+            kw.update(pos64_ptr=p64.data_ptr(), vel64_ptr=v64.data_ptr())
+        else:
+            v32 = torch.from_numpy(vel_np).cuda()
+            kw.update(vel_ptr=v32.data_ptr())
+        for b, e, ph in ((off, off + cnt, c.NB_PHASE_FIRST), (0, off, c.NB_PHASE_MIDDLE), (off + cnt, n, c.NB_PHASE_LAST)):
+            c.launch_f32(src.data_ptr(), out.data_ptr(), n, off, cnt, syn.EPS ** 2, dt, stream, phase=ph, src_begin=b,
+                         src_end=e, **kw)
+        torch.cuda.synchronize()
+        outs.append((acc.cpu().numpy(), out.cpu().numpy(), (v64 if acc64 else v32).cpu().numpy()))
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert np.array_equal(a, b)
+    assert outs[0][0].any() and outs[0][1][off:off + cnt].any()
