@@ -132,6 +132,7 @@ F32Args f32_args(nb_context* c) {
     a.vel64 = c->vel64;
     a.acc = c->acc32;
     a.partial = c->partial;
+    a.slots = c->partial_slots;
     a.n_src = c->n;
     a.tgt_off = 0;
     a.n_tgt = c->n;
@@ -262,9 +263,13 @@ int nbi::create_context(nb_context** out, const nb_config* cfg, hipStream_t borr
         NB_HIP(c, hipMalloc(&c->pos[1], n * sizeof(float4)));
         NB_HIP(c, hipMalloc(&c->vel, n * sizeof(float4)));
         NB_HIP(c, hipMalloc(&c->acc32, n * sizeof(double4)));
-        if (plan_f32(c->n, c->n, c->n_cus, 0, 0, true).j_split > 1) {  // the step launches will slice the sources
+        const int js = plan_f32(c->n, c->n, c->n_cus, 0, 0, true).j_split;
+        if (js > 1) {  // the step launches will slice the sources: one partial-sum slot per slice of a launch (16 .. 64,
+                       // within 8 GiB), so that a step is one force launch + one reducer (profiles/r03_shard_slots.txt)
             const size_t rec = cfg->precision == NB_F32_ACC64 ? sizeof(double4) : sizeof(float4);
-            NB_HIP(c, hipMalloc(&c->partial, (size_t)(SLICES_PER_LAUNCH + 2) * n * rec));
+            const long cap = (long)(((size_t)8 << 30) / (n * rec)) - 2;
+            c->partial_slots = (int)std::max<long>(SLICES_PER_LAUNCH, std::min<long>(std::min<long>(js, MAX_SLICES_PER_LAUNCH), cap));
+            NB_HIP(c, hipMalloc(&c->partial, (size_t)(c->partial_slots + 2) * n * rec));
         }
         if (cfg->precision == NB_F32_ACC64) {
             NB_HIP(c, hipMalloc(&c->pos64, n * sizeof(double4)));

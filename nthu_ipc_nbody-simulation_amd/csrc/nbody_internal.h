@@ -67,7 +67,8 @@ struct nb_context {
     double4* pos64 = nullptr;
     double4* vel64 = nullptr;
     void* acc32 = nullptr;
-    void* partial = nullptr;  // source-slice workspace [SLICES_PER_LAUNCH + 2][n] float4 (double4 for ACC64)
+    void* partial = nullptr;  // source-slice workspace [partial_slots + 2][n] float4 (double4 for ACC64)
+    int partial_slots = 0;
 };
 
 namespace nbi {
