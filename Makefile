@@ -12,7 +12,7 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-result
 LIB      ?= $(PKG)/libnbody_amd.so
 
 KSRC := $(SRC)/nbody_kernels_f32.hip $(SRC)/nbody_kernels_f64.hip
-HDR  := $(SRC)/nbody_kernels.h include/nbody_amd.h
+HDR  := $(SRC)/nbody_kernels.h include/nbody_amd.h include/nbody_amd_debug.h
 
 .PHONY: all lib hw5 nbody_bench nbconv oracle ubench asan clean stamps
 all: lib hw5 nbody_bench nbconv stamps

@@ -5,9 +5,15 @@
 
 A "step" is one run_step of the whole system (samples/nbody.cc:51-89): all-pairs force + kick + drift on
 synthetic uniform-random bodies (nbody_amd.synthetic, seed 42) already resident in HBM.  N=1 runs BASELINE
-configs[2] (N=2^20, fp32, 1 GPU).  With --gpus P > 1 (launched by torch.distributed.run, one rank per GPU) the same
-N=2^20 bodies are sharded by index over the ranks with one in-place RCCL all-gather of positions per step
-(nbody_amd.distributed), i.e. STRONG scaling of the metric's own N; --bodies 4194304 gives configs[3].
+configs[2] (N=2^20, fp32, 1 GPU).  With --gpus P > 1 the same N=2^20 bodies are sharded by index over P GPUs with one
+in-place RCCL all-gather of positions per step, i.e. STRONG scaling of the metric's own N (--bodies 4194304 gives
+configs[3]), through one of the two hosts of that scheme:
+  * typed as is (`python3 bench.py --gpus P`, no launcher — the reference is one command on its GPUs too, hw5.cu:618):
+    the C-ABI host nb_sharded_* — this ONE process drives the P GPUs, ncclCommInitAll + one in-place ncclAllGather per
+    GPU per step (csrc/nbody_sharded.cpp); the line says "host": "native";
+  * under `python -m torch.distributed.run --nproc-per-node P` (WORLD_SIZE = P): one process per GPU with
+    torch.distributed for the collective (nbody_amd.distributed); "host": "torch".  Rank 0 then also runs the native
+    host once as a bounded child process and embeds its line under "native_host".
 
 Rank 0 prints ONE JSON line.  `value` = N(N-1)*K / wall (max over ranks, barrier + synchronize on both sides).
 `roofline` prices the force kernel against the fp32 vector-FMA peak (157.3 TFLOP/s = the dense f32 MFMA peak in
@@ -98,10 +104,10 @@ def cpu_baseline_all_cores(n_total, rows=2048):
 
 
 def load_traffic(n_bodies, world, kernel, j_split):
-    """HBM bytes per step of the force + reducer launches, and the VALU-busy fraction, from the committed rocprofv3 PMC
-    passes (profiles/pmc_traffic.json, written by bench/parse_profile.py on the builder's box — NOT measured by this
-    run) — only when that profile was taken on THIS kernel, body count, rank count and source split; any other
-    configuration reports null (and the reducer's share likewise)."""
+    """HBM bytes per step of the force + reducer launches (None when the committed profile predates the reducer being
+    counted), and the VALU-busy fraction, from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, written by
+    bench/parse_profile.py on the builder's box — NOT measured by this run) — only when that profile was taken on THIS
+    kernel, body count, rank count and source split; any other configuration reports null."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
@@ -111,11 +117,12 @@ def load_traffic(n_bodies, world, kernel, j_split):
     e = t.get(f"n{n_bodies}_p{world}", {})
     if e.get("kernel") != kernel or e.get("j_split") != j_split:
         return None, None, None, None
-    return e.get("hbm_bytes_per_launch"), e.get("reduce_share_of_span"), e.get("valu_busy"), e.get("tag")
+    return e.get("hbm_bytes_per_step"), e.get("reduce_share_of_span"), e.get("valu_busy"), e.get("tag")
 
 
-def live_pmc(argv_tail, kernel_prefix="nbody_force_f32", timeout=90):
-    """HBM traffic and VALU-busy of the force kernel measured BY THIS RUN: three short child runs of this same program
+def live_pmc(argv_tail, kernels=("nbody_force_f32", "nbody_reduce_update_f32"), timeout=90):
+    """HBM traffic of one step's launches (force kernel + reducer — the same launches `kernel_ms` spans) and VALU-busy of
+    the force kernel, measured BY THIS RUN: three short child runs of this same program
     (2 steps each) under `rocprofv3 --pmc`, one counter group per pass as the guide prescribes — FETCH_SIZE, WRITE_SIZE,
     then SQ_ACTIVE_INST_VALU + GRBM_GUI_ACTIVE — with the program directly after `--`.  FETCH_SIZE / WRITE_SIZE are KiB;
     on gfx950 FETCH_SIZE reports half of a streaming read and is doubled (MI355X_MICROARCH.md, HBM section).  Returns a
@@ -139,21 +146,28 @@ def live_pmc(argv_tail, kernel_prefix="nbody_force_f32", timeout=90):
         p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, env=env, cwd="/tmp")
         if p.returncode != 0:
             raise RuntimeError(f"rocprofv3 pass {tag}: rc={p.returncode}")
-        vals = {}
+        vals = {}  # kernel family -> counter -> values of its launches
         for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             with open(path, newline="") as f:
                 for r in csv.DictReader(f):
-                    if kernel_prefix in r.get("Kernel_Name", ""):
-                        vals.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-        return {k: sum(v) / len(v) for k, v in vals.items()}
+                    for k in kernels:
+                        if k in r.get("Kernel_Name", ""):
+                            vals.setdefault(k, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in vals.items()}
 
     try:
         f = one_pass("fetch", ["FETCH_SIZE"])
         w = one_pass("write", ["WRITE_SIZE"])
         q = one_pass("sq", ["SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"])
-        res = {"hbm_bytes_per_launch": (2.0 * f["FETCH_SIZE"] + w["WRITE_SIZE"]) * 1024.0,
-               "fetch_kib_raw": f["FETCH_SIZE"], "write_kib": w["WRITE_SIZE"],
-               "valu_busy": q["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * q["GRBM_GUI_ACTIVE"] / 8)}
+        force, red = kernels
+        per = {}
+        for k in kernels:  # one launch of each per step (plan: <= 64 slices); a step without slices has no reducer
+            if k in f and k in w:
+                per[k] = {"hbm_bytes": (2.0 * f[k]["FETCH_SIZE"] + w[k]["WRITE_SIZE"]) * 1024.0,
+                          "fetch_kib_raw": f[k]["FETCH_SIZE"], "write_kib": w[k]["WRITE_SIZE"]}
+        res = {"hbm_bytes_per_step": sum(v["hbm_bytes"] for v in per.values()),
+               "force": per.get(force), "reducer": per.get(red),
+               "valu_busy": q[force]["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * q[force]["GRBM_GUI_ACTIVE"] / 8)}
     except Exception as e:  # noqa: BLE001  (tool crash, timeout, missing counter: fall back to the committed profile)
         res = {"error": f"{type(e).__name__}: {e}"}
     shutil.rmtree(out, ignore_errors=True)
@@ -230,6 +244,282 @@ def sharded_check(torch, dist, world, rank, device, dev_index, backend):
     return out
 
 
+def spot_rows(n, world, rows=64):
+    """`rows` target indices spread over EVERY rank's shard (the first and the last body of the system among them)."""
+    per = n // world
+    k_per = max(1, rows // world)
+    stride = max(1, per // k_per)
+    idx = [r * per + (k * stride + (k * 37) % stride) % per for r in range(world) for k in range(k_per)]
+    idx[0], idx[-1] = 0, n - 1
+    return idx
+
+
+def step_rows_vs_oracle(q0, gm, idx, v0_rows, v1_rows, acc64, world):
+    """One run_step of the sharded system against the oracle (samples/nbody.cc:56-88), on the rows `idx`:
+    a = (v' - v) / dt recovered from the velocities before and after ONE more step, against oracle.accel_rows on the
+    positions the step started from (q0: (3, N) — the fp32 records the pair loop reads, widened; gm: G*m as stored).
+    Error relative to sum_j |a_ij|; v' stored in fp32 recovers a only to ulp(v')/dt, which is allowed on top of the
+    tolerance (and reported).  Bound 1e-5 for fp32 sums, 1e-6 for fp64-accumulated ones."""
+    import numpy as np
+    from nbody_amd import synthetic
+    from oracle import oracle as O
+    dt = float(np.float32(synthetic.DT))  # the kernels step with the fp32 value of dt
+    m = np.ascontiguousarray(gm / synthetic.G)
+    tol = 1e-6 if acc64 else 1e-5
+    worst = worst_slack = 0.0
+    ok = True
+    t0 = time.perf_counter()
+    for c, i in enumerate(idx):
+        a, ab = O.accel_rows(q0, m, synthetic.G, synthetic.EPS, i, i + 1, want_abs=True, omp=True)
+        a_gpu = (v1_rows[:, c] - v0_rows[:, c]) / dt
+        slack = 0.0 if acc64 else 2.0 ** -23 * float(np.abs(v1_rows[:, c]).max()) / dt
+        err = float(np.abs(a_gpu - a[:, 0]).max())
+        ok = ok and err <= tol * ab[0] + slack
+        worst, worst_slack = max(worst, err / ab[0]), max(worst_slack, slack / ab[0])
+    per = len(q0[0]) // world
+    return {"rows": len(idx), "rows_per_rank": len(idx) // world, "ranks_covered": len({i // per for i in idx}),
+            "pairs_checked": len(idx) * (len(q0[0]) - 1), "max_err_over_sum_abs": worst, "tol": tol,
+            "fp32_velocity_recovery_slack_over_sum_abs": worst_slack, "ok": bool(ok),
+            "oracle_s": round(time.perf_counter() - t0, 2),
+            "what": "one more sharded step after the timed region; (v' - v)/dt of rows from every rank's shard vs "
+                    "oracle/ fp64 accelerations on the positions that step started from"}
+
+
+_LAUNCHER_ENV = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK",
+                 "ROLE_WORLD_SIZE", "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS")
+
+
+def child_env(**extra):
+    """Environment for a child process that must not think it is a rank of this job."""
+    env = {k: v for k, v in os.environ.items() if k not in _LAUNCHER_ENV and not k.startswith("TORCHELASTIC_")}
+    env.update(extra)
+    return env
+
+
+def run_bench_child(argv, timeout):
+    """This program again as a bounded child (its own HIP contexts; a hang or crash costs `timeout` seconds and a
+    recorded error, never the parent's measurement).  -> parsed JSON line, or {"error": ...}."""
+    import subprocess
+    try:
+        p = subprocess.run([sys.executable, os.path.abspath(__file__)] + list(argv), stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True, timeout=timeout, env=child_env(), cwd=ROOT)
+    except subprocess.TimeoutExpired:
+        return {"error": f"timeout after {timeout} s", "argv": list(argv)}
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    if p.returncode != 0 or not lines:
+        return {"error": f"rc={p.returncode}", "stderr_tail": p.stderr[-400:], "argv": list(argv)}
+    try:
+        return json.loads(lines[-1])
+    except ValueError as e:
+        return {"error": f"unparsable line: {e}", "argv": list(argv)}
+
+
+def replicas_check(devices, cases=("b1024", "b200"), timeout=60):
+    """The reference's OWN multi-GPU mode on these GPUs (hw5.cu:564-567,587-588: task parallelism — P1, P2 and the
+    Problem-3 runs spread over the devices, P2's arrival snapshot crossing from one GPU to another, hw5.cu:482-484):
+    `NB_DEVICES=d0,d1 bin/hw5 bN.in out` as a child, wall time and the three output lines against the golden file."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "bin", "hw5")
+    devs = ",".join(str(d) for d in devices[:2])
+    out = {"devices": devs, "what": "NB_DEVICES=%s bin/hw5 (whole reference program, scenarios spread over the GPUs)" % devs}
+    for case in cases:
+        inp = os.path.join(ROOT, "tests", "golden", "testcases", case + ".in")
+        gold = os.path.join(ROOT, "tests", "golden", "testcases", case + ".out")
+        with tempfile.TemporaryDirectory(dir="/tmp") as d:
+            dst = os.path.join(d, case + ".out")
+            t0 = time.perf_counter()
+            try:
+                p = subprocess.run([exe, inp, dst], env=child_env(NB_DEVICES=devs), stdout=subprocess.PIPE,
+                                   stderr=subprocess.PIPE, text=True, timeout=timeout)
+                wall = time.perf_counter() - t0
+                same = p.returncode == 0 and open(dst, "rb").read() == open(gold, "rb").read()
+                out[case] = {"wall_s": round(wall, 3), "rc": p.returncode, "byte_identical": bool(same)}
+                if p.returncode != 0:
+                    out[case]["stderr_tail"] = p.stderr[-300:]
+            except subprocess.TimeoutExpired:
+                out[case] = {"error": f"timeout after {timeout} s"}
+            except OSError as e:
+                out[case] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
+def roofline_block(achieved, kname, k_ms, tpl, jsp, wgs, acc64, traffic=None, traffic_source=None, live=None,
+                   valu_busy=None, reduce_share=None):
+    reducer = f"nbody_reduce_update_f32<{'true' if acc64 else 'false'}, false>"
+    return {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
+            "traffic_detail": ({"force_kernel": live["force"]["hbm_bytes"] if live.get("force") else None,
+                                "reducer": live["reducer"]["hbm_bytes"] if live.get("reducer") else None,
+                                "algorithmic": None} if live and "error" not in live else None),
+            "traffic_source": traffic_source,
+            "live_pmc": live,
+            "valu_busy": valu_busy,
+            "kernel": kname, "kernel_ms": k_ms,
+            "kernel_ms_spans": [kname] + ([reducer] if jsp > 1 else []),
+            "reduce_share_of_span": reduce_share,
+            "targets_per_lane": tpl, "j_split": jsp, "wg_size": wgs, "flop_per_pair": FLOP_PER_PAIR,
+            "issue_ceiling_frac": ISSUE_CEILING_FRAC,
+            "frac_of_issue_ceiling": achieved / PEAK_FP32_TFLOPS / ISSUE_CEILING_FRAC,
+            "issue_ceiling_detail": "per 64 pairs a SIMD issues 12 fp32 VALU ops (2 cycles each, packed: 6 x 4) "
+                                    "+ 1 v_rsq_f32 (8 cycles, does not overlap VALU) = 32 cycles -> 1024 SIMDs "
+                                    "x 2.4 GHz x 64/32 = 4.9e12 pairs/s = 0.62 of peak at 20 flop/pair "
+                                    "(profiles/r01_ubench_valu_rate.txt)",
+            "bound_detail": "compute-bound on the fp32 vector-FMA (VALU) pipe: peak 157.3 TFLOP/s (numerically "
+                            "the dense f32 MFMA peak, which is why the contract's hbm|mfma enum would say "
+                            "'mfma'); the kernel issues v_pk_*_f32 + v_rsq_f32 and no MFMA instruction",
+            "valu_busy_detail": "SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), "
+                                "same source as `traffic` (see traffic_source)"}
+
+
+def workload_config(n, world, how):
+    return {"workload": f"N={n} synthetic uniform-random bodies (splitmix64 seed 42), all-pairs "
+                        f"force + fused kick-drift, eps=1e-3, dt=1e-4", "bodies": n,
+            "parallelism": how if world > 1 else "single GPU"}
+
+
+def main_native(args):
+    """`python3 bench.py --gpus P` typed as is (no launcher): the C-ABI host.  ONE process drives the P GPUs through
+    nb_sharded_* (csrc/nbody_sharded.cpp): per step and GPU one force + fused kick-drift launch sequence on the GPU's own
+    stream and ONE in-place ncclAllGather(sendbuff = recvbuff + r*4N/P) — RCCL over xGMI, ncclCommInitAll, no torch, no
+    launcher.  --exchange copy = the all-gather as peer copies on the copy engines; copy-one-gpu = the same with every rank
+    on device 0 (rehearsal of the whole P > 1 host on a one-GPU box; the ranks then share the chip)."""
+    import numpy as np
+    import nbody_amd  # noqa: F401
+    from nbody_amd import capi, synthetic
+    if args.lib:
+        capi.library_path = lambda: os.path.abspath(args.lib)
+    P, n = args.gpus, args.bodies
+    acc64 = args.precision == "f32acc64"
+    exchange = args.exchange or "rccl"
+    if exchange not in ("rccl", "copy", "copy-one-gpu"):
+        raise SystemExit(f"--exchange {exchange}: the native host takes rccl, copy or copy-one-gpu "
+                         f"(in_place/staged/ring belong to the torch host: launch with torch.distributed.run)")
+    if args.resume or args.checkpoint or args.conservation or args.dump_rows:
+        raise SystemExit("--resume/--checkpoint/--conservation/--dump-rows: single rank or the torch host")
+    devices = [0] * P if exchange == "copy-one-gpu" else list(range(P))
+    prec = capi.NB_F32_ACC64 if acc64 else capi.NB_F32
+    kw = dict(G=synthetic.G, eps=synthetic.EPS, dt=synthetic.DT)
+    try:
+        sh = capi.Sharded(n, devices, prec, overlap=args.overlap, exchange="rccl" if exchange == "rccl" else "copy", **kw)
+    except capi.NBodyError as e:  # no GPU (NB_ERR_NO_DEVICE), fewer than P GPUs, RCCL missing: fail loudly, no fallback
+        raise SystemExit(f"bench.py --gpus {P} (native host, devices {devices}): {e}")
+    q, v, m = synthetic.bodies(n)
+    sh.set_state(q, v, m)
+    del q, v
+    info = sh.info()
+    ranks = [sh.rank_info(r) for r in range(P)]
+    if args.warmup:
+        sh.step(args.warmup)
+    # ---- timed region: K steps, all GPUs idle on both sides (nb_sharded_step_profiled synchronises every stream before
+    #      its first launch and after its last; the per-rank event pairs are created before its clock starts)
+    chunk = args.report_every if args.report_every else 1024
+    kern = [0.0] * P
+    steps_done = 0
+    t0 = time.perf_counter()
+    while steps_done < args.steps:
+        k = min(chunk, args.steps - steps_done, 1024)
+        _, kms = sh.step_profiled(k)
+        kern = [a + b * k for a, b in zip(kern, kms)]
+        steps_done += k
+        el = time.perf_counter() - t0
+        if args.report_every and steps_done < args.steps:
+            print(f"[bench] {steps_done}/{args.steps} steps, {el:.1f} s, "
+                  f"{n * (n - 1) * steps_done / el:.4e} pairs/s sustained", file=sys.stderr, flush=True)
+            if args.time_box and el > args.time_box:
+                break
+    wall = time.perf_counter() - t0
+    kern = [x / steps_done for x in kern]
+    per = info["targets_per_device"]
+    k_ms = max(kern)  # the slowest rank prices the roofline
+    achieved = FLOP_PER_PAIR * per * (n - 1) / (k_ms * 1e-3) / 1e12
+    ws_bytes = capi.workspace_bytes_f32(per, acc64)
+    kname = capi.kernel_name_f32(n, per, acc64, 0, 0, ws_bytes)
+    out = {
+        "metric": "body-pair interactions/sec",
+        "value": n * (n - 1) * steps_done / wall,
+        "unit": "pairs/s",
+        "n_gpus": P,
+        "steps": steps_done,
+        "warmup": args.warmup,
+        "ms_per_step": wall / steps_done * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32" if not acc64 else "f32 pair math / f64 accumulate",
+        "data": "synthetic",
+        "config": workload_config(n, P, f"index-sharded x{P}, one process, 1 in-place "
+                                  f"{'ncclAllGather' if exchange == 'rccl' else 'copy-engine all-gather'} of float4 positions/step"),
+        "host": "native",
+        "host_detail": "nb_sharded_* (csrc/nbody_sharded.cpp): ONE process, one stream per GPU, "
+                       + ("ncclCommInitAll + one in-place ncclAllGather per GPU per step (RCCL over xGMI)" if exchange == "rccl"
+                          else "P-1 peer copies per GPU per step on the copy engines (NB_SHARDED_COPY_EXCHANGE)"),
+        "exchange": exchange,
+        "overlap": bool(args.overlap),
+        "ranks": {"count": P, "distinct_devices": len({r["uuid"] for r in ranks}),
+                  "exchange": ranks[0]["exchange"],
+                  "comm_ranks_seen_by_every_rank": sorted({r["comm_ranks"] for r in ranks}),
+                  "per_rank": [{k: r[k] for k in ("rank", "device", "comm_rank", "comm_device", "pci_bus_id", "uuid",
+                                                  "name", "compute_units", "first_target", "targets")} for r in ranks]},
+        "roofline": roofline_block(achieved, kname, k_ms, info["targets_per_lane"], info["j_split"], info["wg_size"], acc64),
+        "kernel_ms_per_rank": kern,
+        "non_kernel_ms_per_step": wall / steps_done * 1e3 - k_ms,
+    }
+    out["roofline"]["kernel_ms_detail"] = ("slowest rank's mean per step, HIP events on each rank's own compute stream "
+                                           "around its launch sequence (nb_sharded_step_profiled); all ranks in kernel_ms_per_rank")
+    # ---- untimed: the line carries its own proof
+    if not args.no_parity_spot:
+        try:
+            idx = spot_rows(n, P)
+            q0, v0 = sh.get_state()
+            sh.step(1)
+            _, v1 = sh.get_state()
+            q32 = np.ascontiguousarray(q0.astype(np.float32).astype(np.float64))  # what the pair loop reads
+            gm = (synthetic.G * m).astype(np.float32).astype(np.float64)
+            out["parity_spot"] = step_rows_vs_oracle(q32, gm, idx, v0[:, idx], v1[:, idx], acc64, P)
+            del q0, v0, v1, q32
+        except Exception as e:  # noqa: BLE001
+            out["parity_spot"] = {"ok": False, "error": f"{type(e).__name__}: {e}"}
+    sh.close()
+    if not args.no_diagnostics:
+        # agreement with the unsharded stepper on a small system (the oracle check is parity_spot above)
+        try:
+            nn, steps, dt = 32768, 3, 1e-2
+            q, v, mm = synthetic.bodies(nn)
+            with capi.Sharded(nn, devices, capi.NB_F32, G=synthetic.G, eps=synthetic.EPS, dt=dt, overlap=args.overlap,
+                              exchange="rccl" if exchange == "rccl" else "copy") as s2:
+                s2.set_state(q, v, mm)
+                s2.step(steps)
+                q2, _ = s2.get_state()
+            with capi.Context(nn, capi.NB_F32, devices[0], G=synthetic.G, eps=synthetic.EPS, dt=dt) as ctx:
+                ctx.set_state(q, v, mm)
+                ctx.step(1, steps)
+                q1, _ = ctx.get_state()
+            diff, moved = float(np.abs(q2 - q1).max()), float(np.abs(q1 - q.astype(np.float32)).max())
+            out["sharded_check"] = {"bodies": nn, "steps": steps, "max_abs_diff_vs_unsharded": diff,
+                                    "max_displacement": moved, "ok": bool(diff < 5e-7 and moved > 1e-6)}
+        except Exception as e:  # noqa: BLE001
+            out["sharded_check"] = {"ok": False, "error": f"{type(e).__name__}: {e}"}
+        # the other settings of the same run, each as a bounded child: overlap toggled, the other exchange
+        base = ["--gpus", str(P), "--bodies", str(n), "--precision", args.precision, "--steps", str(min(5, max(2, args.steps))),
+                "--warmup", "1", "--no-diagnostics", "--no-parity-spot"]
+        ab = {}
+        for name, extra in (("overlap_" + ("off" if args.overlap else "on"), ["--exchange", exchange] + ([] if args.overlap else ["--overlap"])),
+                            ("exchange_" + ("copy" if exchange == "rccl" else "rccl"),
+                             ["--exchange", "copy" if exchange == "rccl" else "rccl"] + (["--overlap"] if args.overlap else []))):
+            if name == "exchange_rccl" and exchange == "copy-one-gpu":
+                continue  # RCCL takes one rank per GPU
+            if name.startswith("overlap") and per % 256:
+                continue
+            r = run_bench_child(base + extra, timeout=240)
+            ab[name] = ({"ms_per_step": r["ms_per_step"], "kernel_ms_per_rank": r.get("kernel_ms_per_rank"),
+                         "non_kernel_ms_per_step": r.get("non_kernel_ms_per_step")} if "error" not in r else r)
+        out["variants"] = {"this_run": {"ms_per_step": out["ms_per_step"], "overlap": bool(args.overlap), "exchange": exchange},
+                           **ab, "note": "same system, few steps, each variant its own child process after the timed region"}
+        out["replicas"] = replicas_check(devices)
+    print(json.dumps(out), flush=True)
+
+
 def conservation(torch, sysm, n, sample=1024):
     """Integrals of motion of the state the system holds now (single rank): total momentum sum G m v exactly, kinetic
     energy exactly, potential energy from `sample` strided targets against ALL sources in fp64 (scaled by n/sample; the
@@ -273,8 +563,15 @@ def main():
     ap.add_argument("--wg-size", type=int, default=0, help="0 auto, 256, 512 (with --targets-per-lane 8), 1024 (4)")
     ap.add_argument("--overlap", action="store_true", help="multi-GPU: two-phase step, own-shard sources while the "
                     "all-gather of the other shards is in flight (SURVEY 8(f)-3); default off, see overlap_ab in the JSON")
-    ap.add_argument("--exchange", choices=["in_place", "staged", "ring"], default="in_place", help="multi-GPU: in-place "
-                    "all-gather (default), all-gather from a cloned shard, or the ring pass (no rank holds all positions)")
+    ap.add_argument("--exchange", choices=["in_place", "staged", "ring", "rccl", "copy", "copy-one-gpu"], default=None,
+                    help="multi-GPU, torch host: in_place all-gather (default), all-gather from a cloned shard (staged), or "
+                    "the ring pass (no rank holds all positions).  Native host: rccl (default, in-place ncclAllGather), copy "
+                    "(peer copies on the copy engines) or copy-one-gpu (all ranks on device 0: rehearsal on a one-GPU box)")
+    ap.add_argument("--host", choices=["auto", "native", "torch"], default="auto", help="auto: the torch host under "
+                    "torch.distributed.run (WORLD_SIZE > 1) or with one GPU, the native C-ABI host (nb_sharded_*, one "
+                    "process for all GPUs) when --gpus > 1 is typed without a launcher")
+    ap.add_argument("--no-diagnostics", action="store_true", help="multi-GPU: skip the untimed diagnostics after the timed "
+                    "region (agreement check, overlap / exchange variants, native-host child, hw5 replicas)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-spot", action="store_true", help="skip the oracle spot check of the final state (N=1)")
     ap.add_argument("--no-live-pmc", action="store_true", help="N=1: do not re-run 2 steps three times under rocprofv3 --pmc "
@@ -298,6 +595,13 @@ def main():
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     args = ap.parse_args()
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.host == "native" or (args.host == "auto" and args.gpus > 1 and world == 1):
+        return main_native(args)
+    if args.exchange in ("rccl", "copy", "copy-one-gpu"):
+        raise SystemExit(f"--exchange {args.exchange} belongs to the native host (run without a launcher, or --host native)")
+    args.exchange = args.exchange or "in_place"
+
     import torch
     import torch.distributed as dist
 
@@ -307,11 +611,11 @@ def main():
     if args.lib:
         capi.library_path = lambda: os.path.abspath(args.lib)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the torch host runs one rank per GPU under "
+                         f"torch.distributed.run (or type the command without a launcher for the native host)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: nbody_amd has no CPU path")
     dev_index = 0 if args.single_device else local_rank
@@ -325,6 +629,9 @@ def main():
             dist.init_process_group("nccl", device_id=device, timeout=patience)
         else:
             dist.init_process_group(args.backend, timeout=patience)
+        # host-side control group: waiting at it parks no collective kernel on the GPUs (rank 0 runs child processes on them
+        # during the diagnostics) and moves Python objects
+        ctl = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=900))
 
     n = args.bodies
     acc64 = args.precision == "f32acc64"
@@ -403,12 +710,72 @@ def main():
         vd = (sysm.vel64 if acc64 else sysm.vel)[idx].cpu().numpy()
         np.savez(args.dump_rows, idx=idx.cpu().numpy(), q=qd, v=vd, step=first_step + args.warmup + steps_done)
 
-    # --- untimed diagnostics of the multi-GPU path (after the timed region; not part of `value`)
-    exchange_ms = check = overlap_ab = None
+    # --- untimed diagnostics (after the timed region; not part of `value`)
+    exchange_ms = check = overlap_ab = spot = lds = native = replicas = None
+    kern_per_rank = rank_ids = None
     diag_errors = []
+    if world == 1 and not args.no_diagnostics and not sysm.ring and args.source_path != 1 and not args.lib:
+        # the north star's named kernel — sources staged through an LDS tile — on the same system, five untimed steps:
+        # the adopted SGPR path's margin over it comes from this run, not from a builder profile
+        try:
+            main_compute, sysm.compute = sysm.compute, hip_compute(acc64, 0, 0, 1, 0)
+            sysm.step()
+            torch.cuda.synchronize()
+            sysm.kernel_events = ev_lds = []
+            for _ in range(5):
+                sysm.step()
+            torch.cuda.synchronize()
+            ms = sum(a.elapsed_time(b) for a, b in ev_lds) / len(ev_lds)
+            ws1 = capi.workspace_bytes_f32(n, acc64)
+            lds = {"ms_per_step": ms, "frac": FLOP_PER_PAIR * n * (n - 1) / (ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
+                   "kernel": capi.kernel_name_f32(n, n, acc64, 0, 0, ws1, source_path=1),
+                   "plan": list(capi.plan_f32(n, n, acc64, 0, 0, ws1, 1, 0)), "steps": 5,
+                   "what": "source_path=1: 256-body float4 tiles through LDS, one coalesced 16-B load per lane per tile, "
+                           "broadcast ds_read_b128 in the pair loop; same slicing, same arithmetic, HIP events on the launch stream"}
+            sysm.compute, sysm.kernel_events = main_compute, None
+        except Exception as e:  # noqa: BLE001
+            diag_errors.append(f"lds_path: {type(e).__name__}: {e}")
     if world > 1:
+        # who ran: every rank's GPU, read by the rank itself; and every rank's own kernel time (rank 0's prices `roofline`
+        # unless another rank was slower)
+        try:
+            pr = torch.cuda.get_device_properties(dev_index)
+            me = {"rank": rank, "device": dev_index, "name": pr.name, "uuid": str(getattr(pr, "uuid", "")),
+                  "pci_bus_id": f"{getattr(pr, 'pci_domain_id', 0):04x}:{getattr(pr, 'pci_bus_id', 0):02x}:"
+                                f"{getattr(pr, 'pci_device_id', 0):02x}.0",
+                  "compute_units": pr.multi_processor_count, "first_target": lo, "targets": hi - lo, "kernel_ms": k_ms}
+            ids = [None] * world
+            dist.all_gather_object(ids, me, group=ctl)
+            rank_ids, kern_per_rank = ids, [r["kernel_ms"] for r in ids]
+        except Exception as e:  # noqa: BLE001
+            diag_errors.append(f"ranks: {type(e).__name__}: {e}")
+    if world > 1 and not args.no_diagnostics:
         # every rank takes the same path through these: an exception that all ranks raise alike (a refused argument) is
         # recorded in the JSON instead of losing the measurement above
+        sysm.kernel_events = None
+        if not sysm.ring and not args.no_parity_spot:
+            # the published number carries its own proof: ONE more step, rows from every rank's shard against the oracle
+            try:
+                import numpy as np
+                mine = [i for i in spot_rows(n, world) if lo <= i < hi]
+                loc = torch.tensor([i - lo for i in mine], dtype=torch.long, device=device)
+                pos0 = sysm.positions.clone() if rank == 0 else None
+                vsrc = sysm.vel64 if acc64 else sysm.vel
+                v0 = vsrc[loc, :3].double().cpu().numpy().T
+                sysm.step()
+                torch.cuda.synchronize()
+                v1 = vsrc[loc, :3].double().cpu().numpy().T
+                parts = [None] * world
+                dist.all_gather_object(parts, (mine, v0, v1), group=ctl)
+                if rank == 0:
+                    idx = [i for part in parts for i in part[0]]
+                    v0a, v1a = np.concatenate([p_[1] for p_ in parts], axis=1), np.concatenate([p_[2] for p_ in parts], axis=1)
+                    p0 = pos0.cpu().numpy().astype(np.float64)
+                    spot = step_rows_vs_oracle(np.ascontiguousarray(p0[:, :3].T), np.ascontiguousarray(p0[:, 3]), idx,
+                                               v0a, v1a, acc64, world)
+                del pos0
+            except Exception as e:  # noqa: BLE001
+                diag_errors.append(f"parity_spot: {type(e).__name__}: {e}")
         try:
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
             barrier()
@@ -426,11 +793,10 @@ def main():
             diag_errors.append(f"sharded_check: {type(e).__name__}: {e}")
         # the same system stepped with the other setting of --overlap, a few steps, wall clock (max over ranks)
         try:
-            sysm.kernel_events = None
             ab = {}
             k_ab = min(5, max(2, args.steps))
             for mode in (False, True):
-                if mode and sysm.n_tgt % 256:
+                if (mode and sysm.n_tgt % 256) or sysm.ring:
                     continue
                 sysm._wait_gather()
                 sysm.overlap = mode
@@ -452,11 +818,26 @@ def main():
         except Exception:  # noqa: BLE001
             pass
         sysm.overlap = args.overlap and world > 1
+        # rank 0 alone now drives all the GPUs from child processes — the C-ABI host (nb_sharded_*: one process,
+        # ncclCommInitAll) on the same workload, and the reference's own multi-GPU mode (bin/hw5 with NB_DEVICES) — while the
+        # other ranks wait on the host-side group, GPUs idle
+        torch.cuda.synchronize()
+        dist.barrier(group=ctl)
+        if rank == 0:
+            nat = ["--gpus", str(world), "--host", "native", "--bodies", str(n), "--precision", args.precision,
+                   "--steps", str(min(10, max(2, args.steps))), "--warmup", "2", "--no-diagnostics",
+                   "--exchange", "copy-one-gpu" if args.single_device else "rccl"]
+            native = run_bench_child(nat, timeout=300)
+            replicas = replicas_check([0, 0] if args.single_device else list(range(world)))
+        dist.barrier(group=ctl)
 
     if rank == 0:
         pairs_step = n * (n - 1)
         value = pairs_step * args.steps / wall
-        # dominant kernel: this rank's force+kick-drift launch = n_tgt x N pair evaluations, 20 flop each
+        # dominant kernel: a rank's force+kick-drift launch sequence = n_tgt x N pair evaluations, 20 flop each; with
+        # several ranks the slowest one's time
+        if kern_per_rank:
+            k_ms = max(kern_per_rank)
         flops_launch = FLOP_PER_PAIR * sysm.n_tgt * (n - 1)
         achieved = flops_launch / (k_ms * 1e-3) / 1e12
         ws_bytes = capi.workspace_bytes_f32(sysm.n_tgt, acc64)  # what hip_compute sizes its workspace from
@@ -465,19 +846,20 @@ def main():
                                      source_path=args.source_path, wg_size=args.wg_size)
         tpl, jsp, wgs = capi.plan_f32(n_cover, sysm.n_tgt, acc64, args.targets_per_lane, args.j_split, ws_bytes,
                                       args.source_path, args.wg_size)
-        reducer = f"nbody_reduce_update_f32<{'true' if acc64 else 'false'}, false>"
         traffic, reduce_share, valu_busy, pmc_tag = load_traffic(n, world, kname, jsp)
         traffic_source = (f"profiles/pmc_traffic.json ({pmc_tag}: builder's rocprofv3 PMC passes on this kernel, N and source "
                           f"split; not measured by this run)") if traffic else None
         live = None
         if world == 1 and not args.no_live_pmc and not args.lib:
             tail = ["--bodies", str(n), "--precision", args.precision, "--targets-per-lane", str(args.targets_per_lane),
-                    "--j-split", str(args.j_split), "--source-path", str(args.source_path), "--wg-size", str(args.wg_size)]
+                    "--j-split", str(args.j_split), "--source-path", str(args.source_path), "--wg-size", str(args.wg_size),
+                    "--no-diagnostics"]
             live = live_pmc(tail)
             if live and "error" not in live:
-                traffic, valu_busy = live["hbm_bytes_per_launch"], live["valu_busy"]
+                traffic, valu_busy = live["hbm_bytes_per_step"], live["valu_busy"]
                 traffic_source = ("measured by this run: three 2-step child runs under rocprofv3 --pmc (FETCH_SIZE x2 gfx950 "
-                                  "correction + WRITE_SIZE; SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE), mean over the force launches")
+                                  "correction + WRITE_SIZE; SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE); bytes = force kernel + "
+                                  "reducer of one step (the launches kernel_ms spans), VALU-busy of the force kernel")
         out = {
             "metric": "body-pair interactions/sec",
             "value": value,
@@ -491,43 +873,47 @@ def main():
             "vs_baseline": None,
             "dtype": "f32" if not acc64 else "f32 pair math / f64 accumulate",
             "data": "synthetic",
-            "config": {"workload": f"N={n} synthetic uniform-random bodies (splitmix64 seed 42), all-pairs "
-                                   f"force + fused kick-drift, eps=1e-3, dt=1e-4", "bodies": n,
-                       "parallelism": (f"index-sharded x{world}, ring pass of float4 position blocks" if sysm.ring else
-                                       f"index-sharded x{world}, 1 RCCL all-gather of float4 positions/step")
-                       if world > 1 else "single GPU"},
+            "config": workload_config(n, world, f"index-sharded x{world}, ring pass of float4 position blocks" if sysm.ring
+                                      else f"index-sharded x{world}, 1 RCCL all-gather of float4 positions/step"),
+            "host": "torch" if world > 1 else "single",
             "exchange": sysm.exchange_mode,
-            "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
-                         "traffic_source": traffic_source,
-                         "live_pmc": live,
-                         "valu_busy": valu_busy,
-                         "kernel": kname, "kernel_ms": k_ms,
-                         "kernel_ms_spans": [kname] + ([reducer] if jsp > 1 else []),
-                         "reduce_share_of_span": reduce_share,
-                         "targets_per_lane": tpl, "j_split": jsp, "wg_size": wgs, "flop_per_pair": FLOP_PER_PAIR,
-                         "issue_ceiling_frac": ISSUE_CEILING_FRAC,
-                         "frac_of_issue_ceiling": achieved / PEAK_FP32_TFLOPS / ISSUE_CEILING_FRAC,
-                         "issue_ceiling_detail": "per 64 pairs a SIMD issues 12 fp32 VALU ops (2 cycles each, packed: 6 x 4) "
-                                                 "+ 1 v_rsq_f32 (8 cycles, does not overlap VALU) = 32 cycles -> 1024 SIMDs "
-                                                 "x 2.4 GHz x 64/32 = 4.9e12 pairs/s = 0.62 of peak at 20 flop/pair "
-                                                 "(profiles/r01_ubench_valu_rate.txt)",
-                         "bound_detail": "compute-bound on the fp32 vector-FMA (VALU) pipe: peak 157.3 TFLOP/s (numerically "
-                                         "the dense f32 MFMA peak, which is why the contract's hbm|mfma enum would say "
-                                         "'mfma'); the kernel issues v_pk_*_f32 + v_rsq_f32 and no MFMA instruction",
-                         "valu_busy_detail": "SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), "
-                                             "same source as `traffic` (see traffic_source)"},
+            "roofline": roofline_block(achieved, kname, k_ms, tpl, jsp, wgs, acc64, traffic, traffic_source, live,
+                                       valu_busy, reduce_share),
         }
+        if out["roofline"]["traffic_detail"]:
+            out["roofline"]["traffic_detail"]["algorithmic"] = 56 * n  # 16N + 12N read, 12N + 16N written
+        if world > 1:
+            out["host_detail"] = ("nbody_amd.distributed: one process per GPU, torch.distributed (backend "
+                                  f"{args.backend}) for the collective only; kernels through the C ABI (nb_launch_step_f32)")
+        if rank_ids:
+            out["ranks"] = {"count": world, "distinct_devices": len({(r["uuid"], r["pci_bus_id"]) for r in rank_ids}),
+                            "backend": args.backend, "per_rank": rank_ids}
+            out["kernel_ms_per_rank"] = kern_per_rank
+        if lds is not None:
+            out["lds_path"] = lds
         if exchange_ms is not None:
             out["exchange_ms"] = exchange_ms  # one all-gather of float4[N] by itself, mean of 20
         if check is not None:
             out["sharded_check"] = check
+        if spot is not None:
+            out["parity_spot"] = spot
         if diag_errors:
             out["diagnostics_errors"] = diag_errors
         if overlap_ab:
             out["overlap"] = bool(args.overlap)
             out["overlap_ab"] = {"ms_per_step": overlap_ab, "note": "two-phase step (own-shard sources during the "
                                  "all-gather) on vs off, same system, untimed diagnostic after the timed region"}
+        if native is not None:
+            keep = ("value", "ms_per_step", "n_gpus", "steps", "host", "exchange", "ranks", "kernel_ms_per_rank",
+                    "non_kernel_ms_per_step", "parity_spot", "error", "stderr_tail")
+            out["native_host"] = {k: native[k] for k in keep if k in native}
+            if "roofline" in native:
+                out["native_host"]["roofline_frac"] = native["roofline"]["frac"]
+            out["native_host"]["what"] = ("the same workload through the C-ABI host (nb_sharded_*: ONE process, ncclCommInitAll, "
+                                          "one in-place ncclAllGather per GPU per step), run by rank 0 as a child process after "
+                                          "the timed region while the other ranks wait on the host")
+        if replicas is not None:
+            out["replicas"] = replicas
         if first_step:
             out["resumed_from_step"] = first_step
         if ckpt_s:

@@ -11,6 +11,7 @@ import os
 import sys
 
 KERNEL = "nbody_force_f32"
+REDUCER = "nbody_reduce_update_f32"  # counted in the step's traffic: kernel_ms spans force + reducer, so must the bytes
 
 
 def rows(pattern):
@@ -48,21 +49,30 @@ def main():
             break
 
     # 2./3./4. counters: one row per dispatch and counter
-    def counter(sub, name):
+    def counter(sub, name, kernel=KERNEL):
         vals = [float(r["Counter_Value"]) for r in rows(f"{out}/{sub}/**/*counter_collection.csv")
-                if r.get("Counter_Name") == name and KERNEL in r.get("Kernel_Name", "")]
+                if r.get("Counter_Name") == name and kernel in r.get("Kernel_Name", "")]
         return vals
 
     fetch = counter("pmc_fetch", "FETCH_SIZE")
     write = counter("pmc_write", "WRITE_SIZE")
+    rfetch = counter("pmc_fetch", "FETCH_SIZE", REDUCER)
+    rwrite = counter("pmc_write", "WRITE_SIZE", REDUCER)
     lines += ["", "## --pmc (separate passes)", ""]
-    traffic = None
+    traffic = force_bytes = reducer_bytes = None
     if fetch and write:
         f_kib, w_kib = sum(fetch) / len(fetch), sum(write) / len(write)
-        traffic = (2.0 * f_kib + w_kib) * 1024.0
-        lines += [f"* FETCH_SIZE = {f_kib:.1f} KiB per launch (raw) -> x2 gfx950 correction = {2 * f_kib * 1024 / 1e6:.2f} MB read",
-                  f"* WRITE_SIZE = {w_kib:.1f} KiB per launch = {w_kib * 1024 / 1e6:.2f} MB written",
-                  f"* HBM traffic per launch = {traffic / 1e6:.2f} MB"]
+        force_bytes = traffic = (2.0 * f_kib + w_kib) * 1024.0
+        lines += [f"* force kernel: FETCH_SIZE = {f_kib:.1f} KiB per launch (raw) -> x2 gfx950 correction = {2 * f_kib * 1024 / 1e6:.2f} MB read",
+                  f"* force kernel: WRITE_SIZE = {w_kib:.1f} KiB per launch = {w_kib * 1024 / 1e6:.2f} MB written",
+                  f"* force kernel: HBM traffic per launch = {traffic / 1e6:.2f} MB"]
+        if rfetch and rwrite:
+            rf, rw = sum(rfetch) / len(rfetch), sum(rwrite) / len(rwrite)
+            reducer_bytes = (2.0 * rf + rw) * 1024.0
+            traffic += reducer_bytes
+            lines += [f"* reducer: FETCH_SIZE = {rf:.1f} KiB (raw, x2 = {2 * rf * 1024 / 1e6:.2f} MB read), WRITE_SIZE = {rw:.1f} KiB "
+                      f"= {rw * 1024 / 1e6:.2f} MB written -> {reducer_bytes / 1e6:.2f} MB per launch",
+                      f"* **HBM traffic per step (force + reducer, the launches kernel_ms spans) = {traffic / 1e6:.2f} MB**"]
     sq = {}
     for name in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY",
                  "SQ_INSTS_LDS", "SQ_ACTIVE_INST_ANY", "GRBM_GUI_ACTIVE"):
@@ -98,7 +108,8 @@ def main():
             t = {}
         key = os.environ.get("NB_TRAFFIC_KEY", "n1048576_p1")
         # bench.py only quotes these numbers for the configuration they were measured on
-        t[key] = {"hbm_bytes_per_launch": traffic, "fetch_kib_raw": f_kib, "write_kib": w_kib, "tag": tag,
+        t[key] = {"hbm_bytes_per_step": traffic, "force_bytes": force_bytes, "reducer_bytes": reducer_bytes,
+                  "fetch_kib_raw": f_kib, "write_kib": w_kib, "tag": tag,
                   "kernel_avg_ms": avg_ms, "kernel": kernel, "j_split": int(os.environ.get("NB_TRAFFIC_JSPLIT", "8")),
                   "reduce_share_of_span": reduce_total / (reduce_total + force_total) if force_total else None,
                   "valu_busy": valu_busy}

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Two (or more) independent scenario streams at once: per-step cost of each when they share the chip, and when each is
-confined to half of the compute units (nb_config.cu_mask).  Feeds nb_solve's stream layout for
+confined to half of the compute units (nb_create_cu_masked, include/nbody_amd_debug.h: the instrumented build).  Feeds nb_solve's stream layout for
 n > 256.   python bench/scenario_concurrency.py [b1024 ...]"""
 import os
 import sys
@@ -13,6 +13,7 @@ import nbody_amd  # noqa: E402,F401
 from nbody_amd import capi as c  # noqa: E402
 from oracle import oracle as O  # noqa: E402  (input parsing only)
 
+c.use_library(c.stamps_library_path()).__enter__()  # the masks are a hook of the instrumented build
 STEPS = 40000
 
 

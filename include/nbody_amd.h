@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NB_ABI_VERSION 3
+#define NB_ABI_VERSION 4
 
 typedef enum nb_status {
     NB_OK = 0,
@@ -52,14 +52,11 @@ typedef struct nb_config {
     int32_t device;    /* HIP device ordinal */
     int32_t f64_large_min; /* NB_F64: from this many bodies on, nb_step/nb_accel use the large-n kernel; 0 = default (32768) */
     int32_t f64_split;     /* NB_F64: lanes of a wave that share one target in the step kernel; 0 = auto, else a power of two <= 64 */
-    int32_t cu_mask;       /* nb_cu_mask: confine the context's stream to half of the compute units (measurements of
-                              concurrent scenario streams, bench/scenario_concurrency.py); 0 = all CUs */
+    int32_t reserved;      /* must be 0 (ABI 3 carried a measurement knob here; it lives in nbody_amd_debug.h now) */
     double G;   /* 6.674e-11 */
     double eps; /* 1e-3  (Plummer softening; r2 + eps*eps) */
     double dt;  /* 60 */
 } nb_config;
-
-typedef enum nb_cu_mask { NB_CU_ALL = 0, NB_CU_LOW = 1, NB_CU_HIGH = 2, NB_CU_EVEN = 3, NB_CU_ODD = 4 } nb_cu_mask;
 
 /* scenario drivers — the loops main() runs around run_step */
 typedef enum nb_scenario_kind {
@@ -85,7 +82,9 @@ typedef struct nb_scenario {
     int32_t engine;                /* 0 = auto; 1 = one launch per step (any n; long runs replay a hipGraph of launches);
                                       2 = whole step loop inside one persistent single-workgroup launch (n <= 128) */
     int32_t flags;                 /* NB_SCN_NO_SNAPSHOT: FIRST_HIT records arrival steps but keeps no (q,v) snapshots */
-    int32_t graph_chunk;           /* per-step engine: launches per replayed hipGraph; 0 = 1000, else even, 2..4000 */
+    int32_t graph_chunk;           /* per-step engine: launches per replayed hipGraph; 0 = 1000, else even, 2..4000.  A short
+                                      chunk puts many replay boundaries (fill node, advance node, host poll, follower start)
+                                      into a short run: that is what tests use it for; it does not make a replay traceable */
     double planet_radius;          /* 1e7   nbody.cc:17 */
     double missile_speed;          /* 1e6   nbody.cc:18 */
 } nb_scenario;
@@ -129,16 +128,6 @@ int nb_accel(nb_context* ctx, int step, double* ax, double* ay, double* az);
 /* as nb_step, and reports the mean GPU time of one step's launches in milliseconds, measured with HIP events
  * recorded on the context's own stream around the `count` steps */
 int nb_step_timed(nb_context* ctx, int first_step, int count, float* ms_per_step);
-
-/* measurement hook of the per-step fp64 engine — INSTRUMENTED BUILD ONLY (libnbody_amd_stamps.so, `make stamps`; the
- * product library answers NB_ERR_STATE: its latency-bound step kernel carries no instrumentation).  With slots > 0 every
- * step launch of this context that does work records the GPU's 100 MHz wall clock at kernel entry and after its last
- * store (workgroup 0) into slot k = (node index within a replayed graph, or the step index for eager launches) mod slots;
- * nb_read_step_stamps copies {entry, exit} pairs out (exit = 0: a monitor-only launch).  Gives the per-launch duration
- * and the launch-to-launch gap of a replayed hipGraph where tracing tools cannot (bench/replay_stamps.py).  slots = 0
- * switches it off again. */
-int nb_enable_step_stamps(nb_context* ctx, int slots);
-int nb_read_step_stamps(nb_context* ctx, uint64_t* out /* [2*slots] */, int slots);
 
 /* ---- scenario drivers (monitors evaluated on the GPU, no per-step host round trip) ----
  * After a scenario that ends in a hit the context's (q,v) are unspecified — the reference discards that state too
@@ -241,10 +230,12 @@ typedef struct nb_launch_f32 {
     void* vel64; /* NULL unless acc64 */
     void* acc;   /* nb_launch_accel_f32 only: float4[n_tgt] {ax,ay,az,0} (acc64: double4[n_tgt]) */
     void* workspace; /* optional scratch for source slicing (partial + running sums); NULL -> never slice */
-    int64_t workspace_bytes; /* its size; must be >= nb_workspace_bytes_f32() (18 records per target: 16 partial-sum slots,
-                                running sum, compensation) or the sources are not sliced.  A larger one — up to 66 records —
-                                gives a launch as many slots, so that a step of up to 64 slices is ONE force launch + ONE
-                                reducer instead of j_split/16 of each (results are bit for bit the same) */
+    int64_t workspace_bytes; /* its size; must be >= nb_workspace_bytes_f32() (18 records per target: running sum,
+                                compensation, 16 partial-sum slots) or the sources are not sliced.  A larger one — up to 66
+                                records — gives a launch as many slots, so that a step of up to 64 slices is ONE force launch +
+                                ONE reducer instead of j_split/16 of each (results are bit for bit the same).  The running sum
+                                and its compensation are records 0 and 1 whatever the size, so the FIRST / MIDDLE / LAST
+                                launches of one step may pass different sizes of the same buffer */
     int64_t n_src;
     int64_t tgt_off;
     int64_t n_tgt;
@@ -277,7 +268,7 @@ int nb_launch_accel_f32(const nb_launch_f32* a, void* hip_stream); /* force only
 const char* nb_kernel_name_f32(const nb_launch_f32* a, int accel_only);
 /* the register blocking, source split and workgroup size the launches above will use for these arguments */
 int nb_plan_f32(const nb_launch_f32* a, int* targets_per_lane, int* j_split, int* wg_size);
-/* workspace size that allows source slicing for n_tgt targets: 18 records per target */
+/* workspace size that allows source slicing for n_tgt targets: 18 records per target (2 + 16 slots) */
 int64_t nb_workspace_bytes_f32(int64_t n_tgt, int acc64);
 
 /* ---- index-sharded multi-GPU stepping: ONE process, P GPUs of a node, RCCL over xGMI (csrc/nbody_sharded.cpp) ----
@@ -307,9 +298,32 @@ int nb_sharded_get_state(nb_sharded* s, double* qx, double* qy, double* qz, doub
 int nb_sharded_step(nb_sharded* s, int count); /* `count` run_steps of the whole system; returns with all GPUs idle */
 /* as nb_sharded_step, and reports the host wall time per step in milliseconds (all GPUs idle on both sides) */
 int nb_sharded_step_timed(nb_sharded* s, int count, double* ms_per_step);
+/* as nb_sharded_step_timed, and additionally reports — per rank — the mean GPU time of one step's launch sequence
+ * (force kernels + reducers), from HIP events recorded on that rank's own compute stream around the launches of every step,
+ * the exchange excluded (with NB_SHARDED_OVERLAP the span contains the wait for the gathered remote shards between the
+ * own-shard phase and the remote phases).  kernel_ms: float[n_devices].  count <= 1024 (two events per step and rank). */
+int nb_sharded_step_profiled(nb_sharded* s, int count, double* wall_ms_per_step, float* kernel_ms);
 /* shard size and the launch plan each GPU uses for a whole step (any pointer may be NULL) */
 int nb_sharded_info(const nb_sharded* s, int* n_devices, int64_t* targets_per_device, int* targets_per_lane,
                     int* j_split, int* wg_size);
+/* who rank `rank` is: which GPU it drives (ordinal, PCI bus id, UUID, name), which targets it owns, and what its exchange
+ * is — for RCCL straight from the rank's communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice), so that
+ * "the collective ran over N ranks on N distinct GPUs" is a fact read back from RCCL, not an echo of the arguments */
+typedef enum nb_sharded_exchange { NB_EXCHANGE_RCCL = 1, NB_EXCHANGE_COPY = 2 } nb_sharded_exchange;
+typedef struct nb_sharded_rank {
+    int32_t device;        /* HIP ordinal */
+    int32_t compute_units;
+    int64_t first_target;  /* owns targets [first_target, first_target + targets) */
+    int64_t targets;
+    int32_t exchange;      /* nb_sharded_exchange */
+    int32_t comm_ranks;    /* RCCL: ncclCommCount of this rank's communicator; copy exchange: n_devices */
+    int32_t comm_rank;     /* RCCL: ncclCommUserRank; copy exchange: rank */
+    int32_t comm_device;   /* RCCL: ncclCommCuDevice; copy exchange: device */
+    char pci_bus_id[16];   /* "0000:05:00.0" */
+    char uuid[36];         /* hipDeviceGetUuid, 32 hex digits */
+    char name[64];
+} nb_sharded_rank;
+int nb_sharded_rank_info(const nb_sharded* s, int rank, nb_sharded_rank* out);
 
 #ifdef __cplusplus
 }

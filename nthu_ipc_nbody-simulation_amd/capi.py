@@ -17,7 +17,7 @@ _u8p = C.POINTER(C.c_uint8)
 
 class NbConfig(C.Structure):
     _fields_ = [("n", C.c_int32), ("precision", C.c_int32), ("device", C.c_int32), ("f64_large_min", C.c_int32),
-                ("f64_split", C.c_int32), ("cu_mask", C.c_int32), ("G", C.c_double), ("eps", C.c_double),
+                ("f64_split", C.c_int32), ("reserved", C.c_int32), ("G", C.c_double), ("eps", C.c_double),
                 ("dt", C.c_double)]
 
 
@@ -48,6 +48,12 @@ class NbSolveOptions(C.Structure):
                 ("graph_chunk", C.c_int32), ("handoff", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
+class NbShardedRank(C.Structure):
+    _fields_ = [("device", C.c_int32), ("compute_units", C.c_int32), ("first_target", C.c_int64), ("targets", C.c_int64),
+                ("exchange", C.c_int32), ("comm_ranks", C.c_int32), ("comm_rank", C.c_int32), ("comm_device", C.c_int32),
+                ("pci_bus_id", C.c_char * 16), ("uuid", C.c_char * 36), ("name", C.c_char * 64)]
+
+
 class NbLaunchF32(C.Structure):
     _fields_ = [("src", C.c_void_p), ("out", C.c_void_p), ("vel", C.c_void_p), ("pos64", C.c_void_p),
                 ("vel64", C.c_void_p), ("acc", C.c_void_p), ("workspace", C.c_void_p),
@@ -73,8 +79,6 @@ SYMBOLS = {
     "nb_step": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "nb_accel": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp]),
     "nb_step_timed": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
-    "nb_enable_step_stamps": (C.c_int, [C.c_void_p, C.c_int]),
-    "nb_read_step_stamps": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]),
     "nb_run_scenario": (C.c_int, [C.c_void_p, C.POINTER(NbScenario), C.POINTER(NbScenarioResult)]),
     "nb_run_scenarios_batched": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(NbScenario), C.POINTER(NbScenarioResult),
                                           C.c_int]),
@@ -102,9 +106,18 @@ SYMBOLS = {
     "nb_sharded_get_state": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _dp, _dp]),
     "nb_sharded_step": (C.c_int, [C.c_void_p, C.c_int]),
     "nb_sharded_step_timed": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
+    "nb_sharded_step_profiled": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_float)]),
     "nb_sharded_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int),
                                  C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "nb_sharded_rank_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(NbShardedRank)]),
 }
+# include/nbody_amd_debug.h: exported by the instrumented build (libnbody_amd_stamps.so) only
+DEBUG_SYMBOLS = {
+    "nb_enable_step_stamps": (C.c_int, [C.c_void_p, C.c_int]),
+    "nb_read_step_stamps": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]),
+    "nb_create_cu_masked": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(NbConfig), C.c_int]),
+}
+NB_EXCHANGE_RCCL, NB_EXCHANGE_COPY = 1, 2
 NB_SHARDED_OVERLAP = 1
 NB_CU_ALL, NB_CU_LOW, NB_CU_HIGH, NB_CU_EVEN, NB_CU_ODD = 0, 1, 2, 3, 4
 NB_HANDOFF_AUTO, NB_HANDOFF_HOST_STAGED = 0, 1
@@ -164,7 +177,20 @@ def _load(path):
     for name, (res, args) in SYMBOLS.items():
         f = getattr(L, name)  # AttributeError if the ABI lost a symbol
         f.restype, f.argtypes = res, args
+    for name, (res, args) in DEBUG_SYMBOLS.items():  # the instrumented build's extras, when this is that build
+        if hasattr(L, name):
+            f = getattr(L, name)
+            f.restype, f.argtypes = res, args
     return L
+
+
+def _debug_symbol(name, ctx=None):
+    """A symbol of include/nbody_amd_debug.h; the product library does not export it."""
+    L = lib()
+    if not hasattr(L, name):
+        raise NBodyError(NB_ERR_STATE, name, "this build of the library carries no measurement hooks: use "
+                         "libnbody_amd_stamps.so (make stamps; capi.use_library(capi.stamps_library_path()))")
+    return getattr(L, name)
 
 
 def lib():
@@ -224,7 +250,7 @@ class Context:
         cfg = NbConfig()
         _check(lib().nb_config_default(C.byref(cfg)), "nb_config_default")
         cfg.n, cfg.precision, cfg.device = n, precision, device
-        cfg.f64_large_min, cfg.f64_split, cfg.cu_mask = f64_large_min, f64_split, cu_mask
+        cfg.f64_large_min, cfg.f64_split = f64_large_min, f64_split
         if G is not None:
             cfg.G = G
         if eps is not None:
@@ -233,7 +259,10 @@ class Context:
             cfg.dt = dt
         self.cfg, self.n = cfg, n
         self._h = C.c_void_p()
-        rc = lib().nb_create(C.byref(self._h), C.byref(cfg))
+        if cu_mask != NB_CU_ALL:  # measurement knob of the instrumented build (include/nbody_amd_debug.h)
+            rc = _debug_symbol("nb_create_cu_masked")(C.byref(self._h), C.byref(cfg), cu_mask)
+        else:
+            rc = lib().nb_create(C.byref(self._h), C.byref(cfg))
         if rc != NB_OK:
             h, self._h = self._h, C.c_void_p()
             detail = lib().nb_last_error(h).decode() if h else ""
@@ -291,13 +320,13 @@ class Context:
         return a
 
     def enable_step_stamps(self, slots):
-        _check(lib().nb_enable_step_stamps(self._h, slots), "nb_enable_step_stamps", self._h)
+        _check(_debug_symbol("nb_enable_step_stamps")(self._h, slots), "nb_enable_step_stamps", self._h)
 
     def read_step_stamps(self, slots):
         """-> (slots, 2) uint64: GPU wall clock (100 MHz ticks) at entry / after the last store of each step launch."""
         out = np.zeros((slots, 2), dtype=np.uint64)
-        _check(lib().nb_read_step_stamps(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64)), slots), "nb_read_step_stamps",
-               self._h)
+        _check(_debug_symbol("nb_read_step_stamps")(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64)), slots),
+               "nb_read_step_stamps", self._h)
         return out
 
     def run_scenario(self, kind, planet, asteroid, first_step=0, last_step=200000, watch=(), sync_every=2000,
@@ -420,6 +449,7 @@ class Sharded:
         if exchange not in ("rccl", "copy"):
             raise ValueError("exchange must be 'rccl' or 'copy'")
         self.n = n
+        self.devices = list(devices)
         self._h = C.c_void_p()
         devs = (C.c_int * len(devices))(*devices)
         flags = (NB_SHARDED_OVERLAP if overlap else 0) | (NB_SHARDED_COPY_EXCHANGE if exchange == "copy" else 0)
@@ -469,6 +499,21 @@ class Sharded:
         ms = C.c_double()
         self._check(lib().nb_sharded_step_timed(self._h, count, C.byref(ms)), "nb_sharded_step_timed")
         return ms.value
+
+    def step_profiled(self, count):
+        """-> (host wall ms per step, [mean GPU ms of one step's launch sequence, per rank]); count <= 1024."""
+        ms = C.c_double()
+        k = (C.c_float * len(self.devices))()
+        self._check(lib().nb_sharded_step_profiled(self._h, count, C.byref(ms), k), "nb_sharded_step_profiled")
+        return ms.value, list(k)
+
+    def rank_info(self, rank):
+        r = NbShardedRank()
+        self._check(lib().nb_sharded_rank_info(self._h, rank, C.byref(r)), "nb_sharded_rank_info")
+        return dict(rank=rank, device=r.device, compute_units=r.compute_units, first_target=r.first_target,
+                    targets=r.targets, exchange={NB_EXCHANGE_RCCL: "rccl", NB_EXCHANGE_COPY: "copy"}[r.exchange],
+                    comm_ranks=r.comm_ranks, comm_rank=r.comm_rank, comm_device=r.comm_device,
+                    pci_bus_id=r.pci_bus_id.decode(), uuid=r.uuid.decode(), name=r.name.decode())
 
     def info(self):
         p, per, r, j, w = C.c_int(), C.c_int64(), C.c_int(), C.c_int(), C.c_int()

@@ -5,7 +5,7 @@
 // the per-device P3 runs over several GPUs, as the reference does over its two (hw5.cu:564-567,587-588).
 // Tuning / test hooks of the driver come from the environment HERE and travel to the library as nb_solve_options:
 //   NB_SOLVE_ENGINE=steps|persistent  NB_SOLVE_STREAMS=merged|split  NB_SOLVE_MAX_BATCH=2..8  NB_SOLVE_P3_PARALLEL=k
-//   NB_GRAPH_CHUNK=<even 2..4000> (shorter replayed graphs for tracing tools)  NB_SOLVE_HANDOFF=host
+//   NB_GRAPH_CHUNK=<even 2..4000> (shorter replayed graphs: more replay boundaries in a short run, for tests)  NB_SOLVE_HANDOFF=host
 // (the library itself reads only NB_SOLVE_TRACE=1: a timeline on stderr).
 // <input> may also be the binary form of the same data (an NBODYST2 state file with planet/asteroid recorded, see
 // include/nbody_amd.h; bin/nbconv converts) — recognised by its magic, the text format stays the default.

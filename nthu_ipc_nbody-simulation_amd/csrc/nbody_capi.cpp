@@ -10,6 +10,9 @@
 #include <vector>
 
 #include "nbody_internal.h"
+#if NB_ABI_DEBUG
+#include "../../include/nbody_amd_debug.h"
+#endif
 
 using namespace nbk;
 using namespace nbi;
@@ -194,14 +197,22 @@ const char* nb_last_error(const nb_context* ctx) { return ctx ? ctx->err : threa
 
 int nb_create(nb_context** out, const nb_config* cfg) { return create_context(out, cfg, nullptr); }
 
+#if NB_ABI_DEBUG
+int nb_create_cu_masked(nb_context** out, const nb_config* cfg, int cu_mask) {
+    if (cu_mask < NB_CU_ALL || cu_mask > NB_CU_ODD) return NB_ERR_INVALID;
+    return create_context(out, cfg, nullptr, cu_mask);
+}
+#endif
+
 }  // extern "C"
 
 // `borrowed`: use this stream (of another context on the same GPU, which must outlive this one) instead of creating one
-int nbi::create_context(nb_context** out, const nb_config* cfg, hipStream_t borrowed) {
+// `cu_mask` != 0 (instrumented build only, nb_create_cu_masked): the stream is confined to half of the compute units
+int nbi::create_context(nb_context** out, const nb_config* cfg, hipStream_t borrowed, int cu_mask) {
     if (!out || !cfg || cfg->n <= 0) return NB_ERR_INVALID;
     if (cfg->precision < NB_F64 || cfg->precision > NB_F32_ACC64) return NB_ERR_INVALID;
     if (cfg->precision != NB_F64 && !(cfg->eps > 0)) return NB_ERR_INVALID;  // fp32 kernels evaluate the self pair
-    if (cfg->cu_mask < NB_CU_ALL || cfg->cu_mask > NB_CU_ODD) return NB_ERR_INVALID;
+    if (cfg->reserved != 0) return NB_ERR_INVALID;
     if (cfg->f64_split < 0 || cfg->f64_split > 64 || (cfg->f64_split & (cfg->f64_split - 1))) return NB_ERR_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return NB_ERR_NO_DEVICE;
@@ -215,20 +226,20 @@ int nbi::create_context(nb_context** out, const nb_config* cfg, hipStream_t borr
     NB_HIP(c, hipSetDevice(cfg->device));
     // (one attribute, not hipGetDeviceProperties: nb_solve creates 2 + D contexts per program run)
     NB_HIP(c, hipDeviceGetAttribute(&c->n_cus, hipDeviceAttributeMultiprocessorCount, cfg->device));
-    // nb_config.cu_mask (bench/scenario_concurrency.py) confines this context's stream to half of the compute units, so
-    // that two scenario streams do not share CUs
     if (borrowed) {
         c->stream = borrowed;
         c->owns_stream = false;
-    } else if (cfg->cu_mask != NB_CU_ALL) {
+#if NB_ABI_DEBUG
+    } else if (cu_mask != NB_CU_ALL) {  // bench/scenario_concurrency.py: two scenario streams that do not share CUs
         uint32_t mask[8];
-        const int cus = std::min(256, c->n_cus), how = cfg->cu_mask;
+        const int cus = std::min(256, c->n_cus), how = cu_mask;
         for (int w = 0; w < 8; ++w) mask[w] = 0;
         for (int i = 0; i < cus; ++i) {
             const bool on = how == NB_CU_LOW ? i < cus / 2 : how == NB_CU_HIGH ? i >= cus / 2 : how == NB_CU_EVEN ? !(i & 1) : (i & 1);
             if (on) mask[i >> 5] |= 1u << (i & 31);
         }
         NB_HIP(c, hipExtStreamCreateWithCUMask(&c->stream, 8, mask));
+#endif
     } else {
         NB_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     }
@@ -389,12 +400,9 @@ int nb_set_mass(nb_context* c, int index, double m) {
     return NB_OK;
 }
 
+#if NB_ABI_DEBUG  // include/nbody_amd_debug.h: exported by the instrumented build only
 int nb_enable_step_stamps(nb_context* c, int slots) {
     if (!c || slots < 0 || slots > (1 << 20) || c->cfg.precision != NB_F64) return NB_ERR_INVALID;
-#if !NB_STEP_STAMPS
-    snprintf(c->err, sizeof c->err, "this build of the library carries no stamp hook: use libnbody_amd_stamps.so (make stamps)");
-    return NB_ERR_STATE;
-#endif
     if (int rc = bind(c)) return rc;
     NB_HIP(c, hipStreamSynchronize(c->stream));
     free_dev(c->stamps);
@@ -415,6 +423,7 @@ int nb_read_step_stamps(nb_context* c, uint64_t* out, int slots) {
     NB_HIP(c, hipStreamSynchronize(c->stream));
     return NB_OK;
 }
+#endif  // NB_ABI_DEBUG
 
 int nb_step(nb_context* c, int first_step, int count) {
     if (!c || count < 0) return NB_ERR_INVALID;
@@ -534,7 +543,6 @@ int nb_restore_snapshot(nb_context* dst, nb_context* src, int slot) {
 }
 
 // ---------------------------------------------------------------- raw launches on caller-owned HBM
-// ---------------------------------------------------------------- raw launches on caller-owned HBM
 static int check_launch(const nb_launch_f32* a, bool accel_only) {
     if (!a || !a->src || a->n_src <= 0 || a->n_tgt <= 0 || a->tgt_off < 0) return NB_ERR_INVALID;
     if (!a->tgt && a->tgt_off + a->n_tgt > a->n_src) return NB_ERR_INVALID;  // targets are a window of the sources
@@ -556,8 +564,8 @@ static int check_launch(const nb_launch_f32* a, bool accel_only) {
     return NB_OK;
 }
 
-// partial-sum slots the caller's workspace holds beside the running sum and its compensation (18 records per target is the
-// documented minimum; a larger workspace, up to 66 records, lets up to 64 slices go out in one launch)
+// partial-sum slots the caller's workspace holds behind the running sum and its compensation (records 0 and 1; 18 records
+// per target is the documented minimum; a larger workspace, up to 66 records, lets up to 64 slices go out in one launch)
 static int workspace_slots(const nb_launch_f32* a) {
     if (!a->workspace || a->n_tgt <= 0) return 0;
     const size_t rec = a->acc64 ? sizeof(double4) : sizeof(float4);

@@ -17,6 +17,10 @@
 #include "../../include/nbody_amd.h"
 #include "nbody_kernels.h"
 
+#ifndef NB_ABI_DEBUG
+#define NB_ABI_DEBUG NB_STEP_STAMPS  // the instrumented build also exports include/nbody_amd_debug.h
+#endif
+
 struct nb_context {
     nb_config cfg;
     int n = 0;
@@ -95,7 +99,7 @@ void free_dev(T*& p) {
 }
 
 // `borrowed`: use this stream (of another context on the same GPU, which must outlive this one) instead of creating one
-int create_context(nb_context** out, const nb_config* cfg, hipStream_t borrowed);
+int create_context(nb_context** out, const nb_config* cfg, hipStream_t borrowed, int cu_mask = 0);
 nbk::F64Args base_args(nb_context* c, int step);  // one plain fp64 step launch of this context
 
 // NB_SOLVE_TRACE=1 in the environment: timeline of the drivers' phases on stderr.  The ONLY environment variable the

@@ -26,7 +26,7 @@ struct F32Args {
     double4* vel64;     // [n_tgt]
     void* acc;          // accel-only output
     void* partial;      // source-slice workspace, records float4 (double4 if acc64):
-                        //   [SLICES_PER_LAUNCH][n_tgt] partial sums of one launch + [2][n_tgt] running sum / compensation
+                        //   [2][n_tgt] running sum / compensation + [slots][n_tgt] partial sums of one launch
     long n_src, tgt_off, n_tgt;
     long src_begin, src_end;  // sources of THIS launch sequence: [src_begin, src_end) (src_begin a multiple of 256);
                               // 0,0 = all n_src.  A step may be cut into several such phases (own shard first, the

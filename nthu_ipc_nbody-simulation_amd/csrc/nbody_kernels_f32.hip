@@ -258,7 +258,7 @@ __global__ __launch_bounds__(WGS, (WGS == 1024 ? 4 : WGS == 512 ? (SPLIT ? NB_K1
         long i = base + (long)r * WG + t;
         if (i >= a.n_tgt) continue;
         if (SPLIT) {
-            const long slot = (long)blockIdx.y * a.n_tgt + i;
+            const long slot = (long)(blockIdx.y + 2) * a.n_tgt + i;  // records 0 and 1 hold the running sum / compensation
             if (ACC64) ((double4*)a.partial)[slot] = make_double4(dax[r], day[r], daz[r], 0.0);
             else ((float4*)a.partial)[slot] = make_float4(sx[p][h], sy[p][h], sz[p][h], 0.f);
         } else if (ACC64) {
@@ -270,18 +270,20 @@ __global__ __launch_bounds__(WGS, (WGS == 1024 ? 4 : WGS == 512 ? (SPLIT ? NB_K1
     }
 }
 
-// fold the partial sums of one split launch (a.partial[gy][n_tgt]) into the running sum kept behind them in the
-// workspace (compensated in fp32, plain in fp64); the last fold of a step runs the epilogue instead of storing
+// fold the partial sums of one split launch (a.partial[2 + gy][n_tgt]) into the running sum kept in FRONT of them in the
+// workspace (records 0 and 1: sum and compensation — at an offset that does not depend on how many slots the caller's
+// workspace holds, so the launches of one step may be given different workspace sizes); compensated in fp32, plain in
+// fp64; the last fold of a step runs the epilogue instead of storing
 template <bool ACC64, bool ACCEL_ONLY>
 __global__ __launch_bounds__(WG) void nbody_reduce_update_f32(F32Args a, int gy, int first, int last) {
     const long i = (long)blockIdx.x * WG + threadIdx.x;
     if (i >= a.n_tgt) return;
-    const long run_at = (long)a.slots * a.n_tgt + i, comp_at = run_at + a.n_tgt;  // behind the launch's partial-sum slots
+    const long run_at = i, comp_at = a.n_tgt + i;  // in front of the launch's partial-sum slots
     if (ACC64) {
         double4* ws = (double4*)a.partial;
         double4 run = first ? make_double4(0, 0, 0, 0) : ws[run_at];
         for (int s = 0; s < gy; ++s) {
-            const double4 p = ws[(long)s * a.n_tgt + i];
+            const double4 p = ws[(long)(s + 2) * a.n_tgt + i];
             run.x += p.x; run.y += p.y; run.z += p.z;
         }
         if (last) {
@@ -295,7 +297,7 @@ __global__ __launch_bounds__(WG) void nbody_reduce_update_f32(F32Args a, int gy,
         float4 run = first ? make_float4(0, 0, 0, 0) : ws[run_at];
         float4 c = first ? make_float4(0, 0, 0, 0) : ws[comp_at];
         for (int s = 0; s < gy; ++s) {  // Kahan, like the in-kernel second level
-            const float4 p = ws[(long)s * a.n_tgt + i];
+            const float4 p = ws[(long)(s + 2) * a.n_tgt + i];
             float y, t;
             y = p.x - c.x; t = run.x + y; c.x = (t - run.x) - y; run.x = t;
             y = p.y - c.y; t = run.y + y; c.y = (t - run.y) - y; run.y = t;

@@ -48,6 +48,9 @@ struct RcclApi {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
+    decltype(&ncclCommCuDevice) CommCuDevice = nullptr;
 };
 
 // loaded once per process; never unloaded (communicators may outlive any one sharded system)
@@ -67,10 +70,13 @@ const RcclApi* rccl(char* err, size_t errlen) {
             api.GroupStart = (decltype(api.GroupStart))dlsym(api.handle, "ncclGroupStart");
             api.GroupEnd = (decltype(api.GroupEnd))dlsym(api.handle, "ncclGroupEnd");
             api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.handle, "ncclGetErrorString");
+            api.CommCount = (decltype(api.CommCount))dlsym(api.handle, "ncclCommCount");
+            api.CommUserRank = (decltype(api.CommUserRank))dlsym(api.handle, "ncclCommUserRank");
+            api.CommCuDevice = (decltype(api.CommCuDevice))dlsym(api.handle, "ncclCommCuDevice");
         }
     }
     if (!api.handle || !api.CommInitAll || !api.CommDestroy || !api.AllGather || !api.GroupStart || !api.GroupEnd ||
-        !api.GetErrorString) {
+        !api.GetErrorString || !api.CommCount || !api.CommUserRank || !api.CommCuDevice) {
         snprintf(err, errlen, "cannot load RCCL (librccl.so.1): %s", api.handle ? "missing symbol" : dlerror());
         return nullptr;
     }
@@ -227,22 +233,33 @@ int exchange_copy(nb_sharded* s, int nxt, bool ov) {
     return NB_OK;
 }
 
-int step_once(nb_sharded* s) {
+// nb_sharded_step_profiled: per rank one pair of timing events around the launch sequence of every step
+struct StepEvents {
+    std::vector<std::vector<hipEvent_t>> begin, end;  // [rank][step]
+};
+
+// rank k's launches of one step
+int launch_rank(nb_sharded* s, Rank& k, bool ov) {
+    if (!ov) return launch_phase(s, k, 0, 0, F32_PHASE_WHOLE);
+    // own shard first: final since this GPU's previous launch (or the initial upload); no exchange needed
+    const int64_t lo = k.lo, hi = k.lo + s->per;
+    if (int rc = launch_phase(s, k, lo, hi, F32_PHASE_FIRST)) return rc;
+    if (s->gather_pending) SH_HIP(s, hipStreamWaitEvent(k.stream, k.gathered, 0));  // the other shards have landed
+    if (lo > 0)
+        if (int rc = launch_phase(s, k, 0, lo, hi < s->n ? F32_PHASE_MIDDLE : F32_PHASE_LAST)) return rc;
+    if (hi < s->n)
+        if (int rc = launch_phase(s, k, hi, s->n, F32_PHASE_LAST)) return rc;
+    return NB_OK;
+}
+
+int step_once(nb_sharded* s, StepEvents* ev = nullptr, size_t step = 0) {
     const bool ov = overlapped(s);
-    for (Rank& k : s->rank) {
+    for (size_t r = 0; r < s->rank.size(); ++r) {
+        Rank& k = s->rank[r];
         SH_HIP(s, hipSetDevice(k.device));
-        if (!ov) {
-            if (int rc = launch_phase(s, k, 0, 0, F32_PHASE_WHOLE)) return rc;
-            continue;
-        }
-        // own shard first: final since this GPU's previous launch (or the initial upload); no exchange needed
-        const int64_t lo = k.lo, hi = k.lo + s->per;
-        if (int rc = launch_phase(s, k, lo, hi, F32_PHASE_FIRST)) return rc;
-        if (s->gather_pending) SH_HIP(s, hipStreamWaitEvent(k.stream, k.gathered, 0));  // the other shards have landed
-        if (lo > 0)
-            if (int rc = launch_phase(s, k, 0, lo, hi < s->n ? F32_PHASE_MIDDLE : F32_PHASE_LAST)) return rc;
-        if (hi < s->n)
-            if (int rc = launch_phase(s, k, hi, s->n, F32_PHASE_LAST)) return rc;
+        if (ev) SH_HIP(s, hipEventRecord(ev->begin[r][step], k.stream));
+        if (int rc = launch_rank(s, k, ov)) return rc;
+        if (ev) SH_HIP(s, hipEventRecord(ev->end[r][step], k.stream));
     }
     // exchange: every GPU contributes its own slot of the array its kernels have just written
     const int nxt = s->cur ^ 1;
@@ -489,6 +506,96 @@ int nb_sharded_step_timed(nb_sharded* s, int count, double* ms_per_step) {
         if (int rc = step_once(s)) return rc;
     if (int rc = sync_all(s)) return rc;
     *ms_per_step = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / count;
+    return NB_OK;
+}
+
+static int step_profiled_impl(nb_sharded* s, int count, double* wall_ms_per_step, float* kernel_ms) {
+    if (int rc = sync_all(s)) return rc;
+    const size_t P = s->rank.size(), K = (size_t)count;
+    StepEvents ev;
+    ev.begin.assign(P, std::vector<hipEvent_t>(K, nullptr));
+    ev.end.assign(P, std::vector<hipEvent_t>(K, nullptr));
+    auto destroy = [&]() {
+        for (size_t r = 0; r < P; ++r) {
+            (void)hipSetDevice(s->rank[r].device);
+            for (size_t i = 0; i < K; ++i) {
+                if (ev.begin[r][i]) (void)hipEventDestroy(ev.begin[r][i]);
+                if (ev.end[r][i]) (void)hipEventDestroy(ev.end[r][i]);
+            }
+        }
+    };
+    auto run = [&]() -> int {
+        for (size_t r = 0; r < P; ++r) {
+            SH_HIP(s, hipSetDevice(s->rank[r].device));
+            for (size_t i = 0; i < K; ++i) {
+                SH_HIP(s, hipEventCreate(&ev.begin[r][i]));
+                SH_HIP(s, hipEventCreate(&ev.end[r][i]));
+            }
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        for (size_t i = 0; i < K; ++i)
+            if (int rc = step_once(s, &ev, i)) return rc;
+        if (int rc = sync_all(s)) return rc;
+        *wall_ms_per_step = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / count;
+        for (size_t r = 0; r < P; ++r) {
+            SH_HIP(s, hipSetDevice(s->rank[r].device));
+            double sum = 0;
+            for (size_t i = 0; i < K; ++i) {
+                float ms = 0;
+                SH_HIP(s, hipEventElapsedTime(&ms, ev.begin[r][i], ev.end[r][i]));
+                sum += ms;
+            }
+            kernel_ms[r] = (float)(sum / count);
+        }
+        return NB_OK;
+    };
+    const int rc = run();
+    if (rc) (void)sync_all(s);  // nothing may still be recording into the events
+    destroy();
+    return rc;
+}
+
+int nb_sharded_step_profiled(nb_sharded* s, int count, double* wall_ms_per_step, float* kernel_ms) {
+    if (!s || count <= 0 || count > 1024 || !wall_ms_per_step || !kernel_ms) return NB_ERR_INVALID;
+    if (!s->have_state) return NB_ERR_STATE;
+    try {
+        return step_profiled_impl(s, count, wall_ms_per_step, kernel_ms);
+    } catch (...) {
+        return NB_ERR_NOMEM;
+    }
+}
+
+int nb_sharded_rank_info(const nb_sharded* cs, int rank, nb_sharded_rank* out) {
+    nb_sharded* s = const_cast<nb_sharded*>(cs);  // (error text only)
+    if (!s || !out || rank < 0 || rank >= (int)s->rank.size() || !s->ready) return NB_ERR_INVALID;
+    const Rank& k = s->rank[(size_t)rank];
+    memset(out, 0, sizeof *out);
+    out->device = k.device;
+    out->compute_units = k.n_cus;
+    out->first_target = k.lo;
+    out->targets = s->per;
+    if (copy_exchange(s)) {
+        out->exchange = NB_EXCHANGE_COPY;
+        out->comm_ranks = s->P;
+        out->comm_rank = rank;
+        out->comm_device = k.device;
+    } else {
+        out->exchange = NB_EXCHANGE_RCCL;
+        int v = 0;
+        SH_NCCL(s, s->api->CommCount(k.comm, &v));
+        out->comm_ranks = v;
+        SH_NCCL(s, s->api->CommUserRank(k.comm, &v));
+        out->comm_rank = v;
+        SH_NCCL(s, s->api->CommCuDevice(k.comm, &v));
+        out->comm_device = v;
+    }
+    SH_HIP(s, hipDeviceGetPCIBusId(out->pci_bus_id, (int)sizeof out->pci_bus_id, k.device));
+    hipUUID id;
+    SH_HIP(s, hipDeviceGetUuid(&id, k.device));
+    for (int i = 0; i < 16; ++i) snprintf(out->uuid + 2 * i, 3, "%02x", (unsigned)(unsigned char)id.bytes[i]);
+    hipDeviceProp_t prop;
+    SH_HIP(s, hipGetDeviceProperties(&prop, k.device));
+    snprintf(out->name, sizeof out->name, "%s", prop.name);
     return NB_OK;
 }
 

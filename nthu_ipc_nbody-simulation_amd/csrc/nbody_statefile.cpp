@@ -2,10 +2,12 @@
 // nb_read_state_file, nb_write_state_file): checkpoint / large-N input.  The reference has only the text format
 // (samples/nbody.cc:22-49) and an in-memory snapshot (hw5.cu:265-287); layout in include/nbody_amd.h.
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <cstring>
 #include <memory>
 #include <new>
+#include <string>
 
 #include "nbody_internal.h"
 
@@ -87,7 +89,10 @@ int write_state(const char* path, const nb_state_header* h, const double* const 
     v.planet = h->planet;
     v.asteroid = h->asteroid;
     v.G = h->G; v.eps = h->eps; v.dt = h->dt;
-    FILE* f = fopen(path, "wb");
+    // a checkpoint replaces the previous one: written beside it, flushed to the disk, then renamed over it, so that a
+    // run killed in the middle of a write (956 MB at N = 2^24) still finds the earlier file whole
+    const std::string tmp = std::string(path) + ".tmp";
+    FILE* f = fopen(tmp.c_str(), "wb");
     if (!f) return set_error(NB_ERR_IO, "cannot open state file for writing");
     bool ok = fwrite(&v, sizeof v, 1, f) == 1;
     for (int k = 0; k < 6 && ok; ++k) ok = fwrite(q[k], sizeof(double), n, f) == n;
@@ -97,8 +102,17 @@ int write_state(const char* path, const nb_state_header* h, const double* const 
         std::vector<uint8_t> z(n, 0);
         ok = fwrite(z.data(), 1, n, f) == n;
     }
+    ok = ok && fflush(f) == 0 && fsync(fileno(f)) == 0;
     ok = (fclose(f) == 0) && ok;
-    return ok ? NB_OK : set_error(NB_ERR_IO, "short write to state file");
+    if (!ok) {
+        (void)remove(tmp.c_str());
+        return set_error(NB_ERR_IO, "short write to state file");
+    }
+    if (rename(tmp.c_str(), path) != 0) {
+        (void)remove(tmp.c_str());
+        return set_error(NB_ERR_IO, "cannot move the finished state file into place");
+    }
+    return NB_OK;
 }
 
 int read_state_impl(const char* path, nb_state_header* hdr, int64_t capacity, double* qx, double* qy, double* qz,

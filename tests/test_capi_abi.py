@@ -7,8 +7,8 @@ import pytest
 from conftest import ROOT
 
 
-def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "nbody_amd.h")).read()
+def _declared_symbols(header="nbody_amd.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(nb_[a-z0-9_]+)\s*\(", text)))
 
@@ -20,7 +20,14 @@ def test_header_and_binding_agree(nb):
     L = nb.capi.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.nb_abi_version() == 3
+    assert L.nb_abi_version() == 4
+    # the measurement hooks live in their own header and are NOT exported by the product library
+    debug = _declared_symbols("nbody_amd_debug.h")
+    assert sorted(nb.capi.DEBUG_SYMBOLS) == debug and len(debug) == 3
+    for name in debug:
+        assert not hasattr(L, name), f"{name} leaked into the product ABI"
+    with pytest.raises(nb.capi.NBodyError, match="libnbody_amd_stamps.so"):
+        nb.capi._debug_symbol("nb_enable_step_stamps")
 
 
 def test_struct_layouts_match_header(nb):
@@ -32,6 +39,7 @@ def test_struct_layouts_match_header(nb):
     assert C.sizeof(c.NbStateHeader) == 8 + 4 * 4 + 3 * 8
     assert C.sizeof(c.NbAnswer) == 24
     assert C.sizeof(c.NbLaunchF32) == 7 * 8 + 4 * 8 + 8 * 4 + 3 * 8
+    assert C.sizeof(c.NbShardedRank) == 2 * 4 + 2 * 8 + 4 * 4 + 16 + 36 + 64 + 4  # (+4: padded to a multiple of 8)
 
 
 def test_no_cpu_fallback(nb):
@@ -136,8 +144,10 @@ def test_header_is_plain_c_and_links_from_c(nb, tmp_path):
 int main(void) {
     nb_config cfg;
     nb_scenario scn; nb_scenario_result res; nb_answer ans; nb_launch_f32 l; nb_state_header h; nb_solve_options o;
-    (void)scn; (void)res; (void)ans; (void)l; (void)o;
-    if (sizeof(nb_config) != 48 || sizeof(nb_solve_options) != 32) return 7;
+    nb_sharded_rank rk;
+    (void)scn; (void)res; (void)ans; (void)l; (void)o; (void)rk;
+    if (sizeof(nb_config) != 48 || sizeof(nb_solve_options) != 32 || sizeof(nb_sharded_rank) != 160) return 7;
+    if (nb_sharded_rank_info(0, 0, &rk) != NB_ERR_INVALID) return 8;
     if (nb_read_state_file("/nonexistent/x.nbst", &h, 0, 0, 0, 0, 0, 0, 0, 0, 0) != NB_ERR_IO) return 5;
     if (nb_last_error(0)[0] == 0) return 6;
     if (nb_abi_version() != NB_ABI_VERSION) return 1;
@@ -158,15 +168,19 @@ int main(void) {
 
 
 def test_instrumented_build_exports_the_same_abi(nb):
-    """libnbody_amd_stamps.so (make stamps: the per-step kernel records clock stamps) is the same ABI, symbol for symbol."""
+    """libnbody_amd_stamps.so (make stamps: the per-step kernel records clock stamps) is the same ABI, symbol for symbol,
+    plus the three hooks of include/nbody_amd_debug.h; that header compiles as C99 too."""
     import ctypes as C
+    import subprocess
     path = nb.capi.stamps_library_path()
     assert os.path.exists(path), "make stamps"
     L = C.CDLL(path)
-    for name in nb.capi.SYMBOLS:
+    for name in list(nb.capi.SYMBOLS) + list(nb.capi.DEBUG_SYMBOLS):
         assert hasattr(L, name), name
     L.nb_abi_version.restype = C.c_int
-    assert L.nb_abi_version() == 3
+    assert L.nb_abi_version() == 4
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only", "-x", "c",
+                    os.path.join(ROOT, "include", "nbody_amd_debug.h")], check=True)
 
 
 def test_text_input_parses_like_the_reference_reads_it(nb, oracle, tmp_path):
@@ -229,3 +243,40 @@ def test_output_format_matches_the_reference_stream_formatting(tmp_path):
         p = subprocess.run([io, inp, str(out), repr(d), str(hit), str(dev), repr(cost)], capture_output=True, text=True)
         assert p.returncode == 0, p.stderr
         assert out.read_text() == "%.16e\n%d\n%d %.16e\n" % (d, hit, dev, cost)
+
+
+def test_state_file_is_replaced_atomically(nb, tmp_path):
+    """A checkpoint overwrites the previous one (bench.py --checkpoint-every: 956 MB at N = 2^24): the new file is written
+    beside it and renamed over it, so a write that fails leaves the earlier checkpoint whole and no debris."""
+    import numpy as np
+    c = nb.capi
+    path = str(tmp_path / "ck.nbst")
+    q, v, m = np.arange(12.0).reshape(3, 4), np.ones((3, 4)), np.full(4, 2.0)
+    c.write_state_file(path, q, v, m, step=5)
+    first = open(path, "rb").read()
+    assert not os.path.exists(path + ".tmp")
+    os.mkdir(path + ".tmp")  # the place the next write needs is taken: that write fails ...
+    with pytest.raises(c.NBodyError) as e:
+        c.write_state_file(path, q + 1, v, m, step=6)
+    assert e.value.code == c.NB_ERR_IO
+    assert open(path, "rb").read() == first  # ... and the previous checkpoint is untouched
+    os.rmdir(path + ".tmp")
+    c.write_state_file(path, q + 1, v, m, step=6)
+    h, q2, _, _, _ = c.read_state_file(path)
+    assert h["step"] == 6 and np.array_equal(q2, q + 1) and not os.path.exists(path + ".tmp")
+
+
+def test_bench_multi_gpu_command_needs_no_launcher():
+    """`python3 bench.py --gpus 2` typed as is reaches the native C-ABI host: on a machine without a GPU it fails with
+    NB_ERR_NO_DEVICE from nb_sharded_create — not with a request for torch.distributed.run, and not by computing on the CPU."""
+    import subprocess
+    import sys
+
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: tests/test_gpu_bench_hosts.py runs the command for real")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert p.returncode != 0 and "nb_sharded_create" in p.stderr and "no usable HIP device" in p.stderr
+    assert "torch.distributed.run" not in p.stderr and not p.stdout.strip()

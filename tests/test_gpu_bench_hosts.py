@@ -1,0 +1,158 @@
+"""bench.py's multi-GPU lines, and the native host on distinct GPUs.
+
+`python3 bench.py --gpus P` typed without a launcher must run — the reference is one command on its GPUs (hw5.cu:618,
+564-567) — through the C-ABI host (nb_sharded_*: one process, one in-place all-gather per GPU per step); under
+torch.distributed.run the torch host runs and rank 0 adds the native host as a child.  A one-GPU box rehearses both with
+every rank on device 0 (`--exchange copy-one-gpu`, `--backend gloo --single-device`): exactly the code paths of the driver's
+multi-GPU node except the collective library itself.  The tests at the end need two GPUs and skip on the one-GPU box."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+_LAUNCHER = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")
+
+
+def _env():
+    return {k: v for k, v in os.environ.items() if k not in _LAUNCHER}
+
+
+def _line(p):
+    assert p.returncode == 0, (p.returncode, p.stderr[-3000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]  # ONE JSON line
+    return json.loads(lines[0])
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_native_host_line_without_a_launcher(nb):
+    """The command the verdict names: no launcher, two ranks, both on the one GPU."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--exchange", "copy-one-gpu",
+                        "--bodies", "131072", "--steps", "3", "--warmup", "1"], capture_output=True, text=True,
+                       timeout=900, env=_env(), cwd=ROOT)
+    r = _line(p)
+    assert r["n_gpus"] == 2 and r["host"] == "native" and r["steps"] == 3 and r["unit"] == "pairs/s"
+    assert r["config"]["bodies"] == 131072 and r["scaling"] == "strong" and r["exchange"] == "copy-one-gpu"
+    assert r["value"] == pytest.approx(131072 * 131071 * 3 / (r["ms_per_step"] * 3e-3), rel=1e-9)
+    # who ran: two ranks, one device here (they share it), each with its own shard
+    rk = r["ranks"]
+    assert rk["count"] == 2 and rk["distinct_devices"] == 1 and rk["exchange"] == "copy"
+    assert [x["first_target"] for x in rk["per_rank"]] == [0, 65536] and all(x["targets"] == 65536 for x in rk["per_rank"])
+    assert all(len(x["uuid"]) == 32 and x["pci_bus_id"] and x["name"] for x in rk["per_rank"])
+    # per-rank kernel time from HIP events on each rank's stream; the slowest rank prices the roofline
+    assert len(r["kernel_ms_per_rank"]) == 2 and all(k > 0 for k in r["kernel_ms_per_rank"])
+    assert r["roofline"]["kernel_ms"] == max(r["kernel_ms_per_rank"]) and 0 < r["roofline"]["frac"] < 1
+    assert r["roofline"]["kernel"].startswith("nbody_force_f32<")
+    # the line carries its own proof: rows of BOTH shards against the oracle
+    ps = r["parity_spot"]
+    assert ps["ok"] and ps["ranks_covered"] == 2 and ps["rows"] == 64 and ps["max_err_over_sum_abs"] < ps["tol"] == 1e-5
+    assert r["sharded_check"]["ok"]
+    # variants ran as children: the overlapped step (copy exchange on one GPU: rccl is skipped there)
+    v = r["variants"]
+    assert v["overlap_on"]["ms_per_step"] > 0 and "exchange_rccl" not in v and "exchange_copy" not in v
+    # the reference's own multi-GPU mode (two device slots, both this GPU): golden outputs
+    assert r["replicas"]["b200"]["byte_identical"] and r["replicas"]["b1024"]["byte_identical"]
+
+
+def test_native_host_acc64_overlapped_line(nb):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--exchange", "copy-one-gpu",
+                        "--bodies", "65536", "--steps", "2", "--warmup", "1", "--precision", "f32acc64", "--overlap",
+                        "--no-diagnostics"], capture_output=True, text=True, timeout=600, env=_env(), cwd=ROOT)
+    r = _line(p)
+    assert r["n_gpus"] == 4 and r["overlap"] is True and r["ranks"]["count"] == 4
+    ps = r["parity_spot"]
+    assert ps["ok"] and ps["ranks_covered"] == 4 and ps["tol"] == 1e-6 and "variants" not in r and "replicas" not in r
+
+
+def test_torch_host_two_ranks_line(nb):
+    """bench.py's world > 1 branch exactly as the driver launches it (torch.distributed.run, two ranks), rehearsed on the
+    one GPU through gloo: every diagnostic present, none failed, the native host's line embedded."""
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--backend", "gloo", "--single-device", "--bodies", "32768", "--steps", "3",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=1200, env=_env(), cwd=ROOT)
+    r = _line(p)
+    assert r["n_gpus"] == 2 and r["host"] == "torch" and r["steps"] == 3 and "diagnostics_errors" not in r, r.get("diagnostics_errors")
+    assert r["sharded_check"]["ok"] and r["exchange_ms"] > 0
+    assert r["overlap_ab"]["ms_per_step"]["on"] > 0 and r["overlap_ab"]["ms_per_step"]["off"] > 0
+    assert r["parity_spot"]["ok"] and r["parity_spot"]["ranks_covered"] == 2
+    assert r["ranks"]["count"] == 2 and len(r["kernel_ms_per_rank"]) == 2
+    assert r["roofline"]["kernel_ms"] == max(r["kernel_ms_per_rank"])
+    nh = r["native_host"]
+    assert "error" not in nh, nh
+    assert nh["host"] == "native" and nh["n_gpus"] == 2 and nh["parity_spot"]["ok"] and nh["roofline_frac"] > 0
+    assert r["replicas"]["b200"]["byte_identical"]
+
+
+def test_single_gpu_line_reports_the_lds_kernel_and_step_traffic(nb):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--bodies", "262144", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=_env(), cwd=ROOT)
+    r = _line(p)
+    assert r["n_gpus"] == 1 and r["host"] == "single" and r["parity_spot"]["ok"]
+    lds = r["lds_path"]
+    assert lds["kernel"].startswith("nbody_force_f32<") and ", false, 256>" in lds["kernel"] and 0 < lds["frac"] < 1
+    live = r["roofline"]["live_pmc"]
+    if live and "error" not in live:  # rocprofv3 present: bytes of force kernel + reducer = the launches kernel_ms spans
+        assert live["force"]["hbm_bytes"] > 0 and live["reducer"]["hbm_bytes"] > 0
+        assert r["roofline"]["traffic"] == pytest.approx(live["force"]["hbm_bytes"] + live["reducer"]["hbm_bytes"])
+        assert r["roofline"]["traffic_detail"]["algorithmic"] == 56 * 262144
+        assert 0.5 < r["roofline"]["valu_busy"] <= 1.0
+
+
+# ---------------------------------------------------------------- two distinct GPUs (skipped on the one-GPU box)
+
+def _two_gpus(nb):
+    if nb.capi.device_count() < 2:
+        pytest.skip("needs two GPUs: the cross-device halves of the exchanges (hipMemcpyPeerAsync, RCCL with 2 ranks)")
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+@pytest.mark.parametrize("exchange", ["copy", "rccl"])
+def test_two_distinct_gpus_follow_nb_step(nb, oracle, exchange, overlap):
+    """Devices [0, 1]: peer copies over xGMI / a two-rank RCCL all-gather, plain and overlapped, against nb_step and
+    oracle rows from both shards.  NOT EXECUTED on the builder's one-GPU boxes."""
+    _two_gpus(nb)
+    from test_gpu_sharded_native import _oracle_one_step
+    c, syn = nb.capi, nb.synthetic
+    n, dt = 32768, 1e-2
+    q, v, m = syn.bodies(n)
+    with c.Context(n, c.NB_F32, 0, G=syn.G, eps=syn.EPS, dt=dt) as ctx:
+        ctx.set_state(q, v, m)
+        ctx.step(1, 3)
+        q_ref, _ = ctx.get_state()
+    with c.Sharded(n, [0, 1], c.NB_F32, G=syn.G, eps=syn.EPS, dt=dt, overlap=overlap, exchange=exchange) as sh:
+        ids = [sh.rank_info(r) for r in range(2)]
+        assert ids[0]["uuid"] != ids[1]["uuid"] and [i["comm_ranks"] for i in ids] == [2, 2]
+        assert [i["comm_device"] for i in ids] == [0, 1]
+        sh.set_state(q, v, m)
+        sh.step(1)
+        q1, v1 = sh.get_state()
+        sh.step(2)
+        q3, _ = sh.get_state()
+    per = n // 2
+    rows = [(r * per + off, 8) for r in range(2) for off in (0, per // 2 + 3, per - 8)]
+    idx, qo, vo = _oracle_one_step(oracle, syn, q, v, m, dt, rows, f32_start=True)
+    assert np.abs(v1[:, idx] - vo).max() < 2e-6 and np.abs(q1[:, idx] - qo).max() < 2e-7
+    assert np.abs(q3 - q_ref).max() < 5e-7
+
+
+def test_reference_mode_on_two_distinct_gpus(nb):
+    """NB_DEVICES=0,1 bin/hw5: P2's arrival snapshot crosses a real device boundary (hw5.cu:482-484)."""
+    _two_gpus(nb)
+    sys.path.insert(0, ROOT)
+    import bench
+    r = bench.replicas_check([0, 1])
+    assert r["b1024"]["byte_identical"] and r["b200"]["byte_identical"], r
