@@ -11,8 +11,8 @@ EXTRA    ?=
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-result $(EXTRA)
 LIB      ?= $(PKG)/libnbody_amd.so
 
-KSRC := $(SRC)/nbody_kernels_f32.hip $(SRC)/nbody_kernels_f64.hip
-HDR  := $(SRC)/nbody_kernels.h include/nbody_amd.h include/nbody_amd_debug.h
+KSRC := $(SRC)/nbody_kernels_f32.hip $(SRC)/nbody_kernels_f32_sym.hip $(SRC)/nbody_kernels_f64.hip
+HDR  := $(SRC)/nbody_kernels.h $(SRC)/nbody_f32_common.h include/nbody_amd.h include/nbody_amd_debug.h
 
 .PHONY: all lib hw5 nbody_bench nbconv oracle ubench asan clean stamps
 all: lib hw5 nbody_bench nbconv stamps
@@ -62,15 +62,17 @@ bin/asan/hw5: $(SRC)/main_hw5.cpp $(SRC)/nbody_io.cpp $(SRC)/nbody_io_state.cpp 
 bin/asan/nbody_bench: $(SRC)/main_nbody_bench.cpp bin/asan/libnbody_amd.so
 	$(HIPCC) $(ASANFLAGS) -o $@ $(SRC)/main_nbody_bench.cpp -Lbin/asan -lnbody_amd -Wl,-rpath,'$$ORIGIN' -lpthread
 
-ubench: bench/ubench/valu_rate bench/ubench/force_variants bench/ubench/launch_rate bench/debug/startup_probe
+ubench: bench/ubench/valu_rate bench/ubench/force_variants bench/ubench/launch_rate bench/ubench/sym_force bench/debug/startup_probe
 bench/debug/startup_probe: bench/debug/startup_probe.cpp $(LIB)
 	$(HIPCC) -O2 -std=c++17 -Wno-unused-value -o $@ $< -L$(PKG) -lnbody_amd -Wl,-rpath,'$$ORIGIN/../../$(PKG)'
 bench/ubench/launch_rate: bench/ubench/launch_rate.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
+bench/ubench/sym_force: bench/ubench/sym_force.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -o $@ $<
 bench/ubench/force_variants: bench/ubench/force_variants.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -o $@ $<
 bench/ubench/valu_rate: bench/ubench/valu_rate.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
 
 clean:
-	rm -f $(LIB) $(STAMPLIB) bin/hw5 bin/nbody_bench bin/nbconv hw5 bench/ubench/valu_rate bench/ubench/force_variants bench/ubench/launch_rate bench/debug/startup_probe
+	rm -f $(LIB) $(STAMPLIB) bin/hw5 bin/nbody_bench bin/nbconv hw5 bench/ubench/valu_rate bench/ubench/force_variants bench/ubench/launch_rate bench/ubench/sym_force bench/debug/startup_probe

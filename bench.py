@@ -33,7 +33,8 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_PAIR = 20            # GPU Gems 3 ch.31 convention
 PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz
-ISSUE_CEILING_FRAC = 0.62     # what the pair loop's instruction mix can issue (derivation in the JSON and DESIGN.md §3)
+ISSUE_CEILING_FRAC = 0.62     # K1 (every ordered pair): what the pair loop's instruction mix can issue
+ISSUE_CEILING_FRAC_SYM = 0.957  # K1s (every unordered pair once): 16 packed VALU + 2 v_rsq_f32 per 4 interactions + 14 moves / 32
 
 
 def cpu_model():
@@ -120,7 +121,7 @@ def load_traffic(n_bodies, world, kernel, j_split):
     return e.get("hbm_bytes_per_step"), e.get("reduce_share_of_span"), e.get("valu_busy"), e.get("tag")
 
 
-def live_pmc(argv_tail, kernels=("nbody_force_f32", "nbody_reduce_update_f32"), timeout=90):
+def live_pmc(argv_tail, kernels=("nbody_force_f32", "nbody_reduce_update_f32"), timeout=120):
     """HBM traffic of one step's launches (force kernel + reducer — the same launches `kernel_ms` spans) and VALU-busy of
     the force kernel, measured BY THIS RUN: three short child runs of this same program
     (2 steps each) under `rocprofv3 --pmc`, one counter group per pass as the guide prescribes — FETCH_SIZE, WRITE_SIZE,
@@ -186,7 +187,8 @@ def parity_spot(torch, sysm, n, acc64, compute_kw, rows=64):
     pos = sysm.positions
     rec = 32 if acc64 else 16
     acc = torch.empty((n, 4), dtype=torch.float64 if acc64 else torch.float32, device=pos.device)
-    ws = torch.empty(capi.workspace_bytes_f32(n, acc64), dtype=torch.uint8, device=pos.device)
+    from nbody_amd.distributed import workspace_bytes
+    ws = torch.empty(workspace_bytes(n, n, acc64, **compute_kw), dtype=torch.uint8, device=pos.device)
     capi.launch_f32(pos.data_ptr(), 0, n, 0, n, synthetic.EPS ** 2, synthetic.DT,
                     torch.cuda.current_stream(pos.device).cuda_stream, accel_only=True, acc_ptr=acc.data_ptr(),
                     acc64=acc64, workspace_ptr=ws.data_ptr(), workspace_bytes=ws.numel(), **compute_kw)
@@ -344,9 +346,27 @@ def replicas_check(devices, cases=("b1024", "b200"), timeout=60):
     return out
 
 
+def step_kernels(kname):
+    """(force kernel family, reducer family) of a step, for matching rocprofv3 rows."""
+    return ("nbody_force_sym_f32", "nbody_reduce_sym_f32") if kname.startswith("nbody_force_sym_f32") else \
+        ("nbody_force_f32", "nbody_reduce_update_f32")
+
+
 def roofline_block(achieved, kname, k_ms, tpl, jsp, wgs, acc64, traffic=None, traffic_source=None, live=None,
                    valu_busy=None, reduce_share=None):
-    reducer = f"nbody_reduce_update_f32<{'true' if acc64 else 'false'}, false>"
+    sym = kname.startswith("nbody_force_sym_f32")
+    reducer = (f"nbody_reduce_sym_f32<{'true' if acc64 else 'false'}, 0>" if sym else
+               f"nbody_reduce_update_f32<{'true' if acc64 else 'false'}, false>")
+    ceiling = ISSUE_CEILING_FRAC_SYM if sym else ISSUE_CEILING_FRAC
+    detail = ("every UNORDERED pair once (Newton's third law; `value` counts the N(N-1) ordered interactions the reference "
+              "evaluates, nbody.cc:57-60): per 4 interactions x 64 lanes a SIMD issues 16 packed fp32 VALU ops (4 cycles each) "
+              "+ 2 v_rsq_f32 (8 cycles each) = 80 cycles, plus 14 v_mov_b32_dpp (2 cycles) per 32 such sets that rotate the "
+              "travelling sources -> 20.9 cycles per 64 interactions = 0.957 of peak at 20 flop/pair "
+              "(nbody_kernels_f32_sym.hip, profiles/r01_ubench_valu_rate.txt)") if sym else (
+              "per 64 pairs a SIMD issues 12 fp32 VALU ops (2 cycles each, packed: 6 x 4) "
+              "+ 1 v_rsq_f32 (8 cycles, does not overlap VALU) = 32 cycles -> 1024 SIMDs "
+              "x 2.4 GHz x 64/32 = 4.9e12 pairs/s = 0.62 of peak at 20 flop/pair "
+              "(profiles/r01_ubench_valu_rate.txt)")
     return {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
             "traffic_detail": ({"force_kernel": live["force"]["hbm_bytes"] if live.get("force") else None,
@@ -356,15 +376,13 @@ def roofline_block(achieved, kname, k_ms, tpl, jsp, wgs, acc64, traffic=None, tr
             "live_pmc": live,
             "valu_busy": valu_busy,
             "kernel": kname, "kernel_ms": k_ms,
-            "kernel_ms_spans": [kname] + ([reducer] if jsp > 1 else []),
+            "kernel_ms_spans": [kname] + ([reducer] if (jsp > 1 or sym) else []),
+            "pair_evaluation": "each unordered pair once, both bodies served" if sym else "every ordered pair",
             "reduce_share_of_span": reduce_share,
             "targets_per_lane": tpl, "j_split": jsp, "wg_size": wgs, "flop_per_pair": FLOP_PER_PAIR,
-            "issue_ceiling_frac": ISSUE_CEILING_FRAC,
-            "frac_of_issue_ceiling": achieved / PEAK_FP32_TFLOPS / ISSUE_CEILING_FRAC,
-            "issue_ceiling_detail": "per 64 pairs a SIMD issues 12 fp32 VALU ops (2 cycles each, packed: 6 x 4) "
-                                    "+ 1 v_rsq_f32 (8 cycles, does not overlap VALU) = 32 cycles -> 1024 SIMDs "
-                                    "x 2.4 GHz x 64/32 = 4.9e12 pairs/s = 0.62 of peak at 20 flop/pair "
-                                    "(profiles/r01_ubench_valu_rate.txt)",
+            "issue_ceiling_frac": ceiling,
+            "frac_of_issue_ceiling": achieved / PEAK_FP32_TFLOPS / ceiling,
+            "issue_ceiling_detail": detail,
             "bound_detail": "compute-bound on the fp32 vector-FMA (VALU) pipe: peak 157.3 TFLOP/s (numerically "
                             "the dense f32 MFMA peak, which is why the contract's hbm|mfma enum would say "
                             "'mfma'); the kernel issues v_pk_*_f32 + v_rsq_f32 and no MFMA instruction",
@@ -559,7 +577,8 @@ def main():
     ap.add_argument("--precision", choices=["f32", "f32acc64"], default="f32")
     ap.add_argument("--targets-per-lane", type=int, default=0)
     ap.add_argument("--j-split", type=int, default=0)
-    ap.add_argument("--source-path", type=int, default=0, help="0 auto, 1 LDS tile, 2 SGPR/scalar loads")
+    ap.add_argument("--source-path", type=int, default=0, help="0 auto, 1 LDS tile, 2 SGPR/scalar loads (both: every ordered "
+                    "pair), 3 every unordered pair once (K1s; auto picks it for a whole system of >= 262144 bodies on one GPU)")
     ap.add_argument("--wg-size", type=int, default=0, help="0 auto, 256, 512 (with --targets-per-lane 8), 1024 (4)")
     ap.add_argument("--overlap", action="store_true", help="multi-GPU: two-phase step, own-shard sources while the "
                     "all-gather of the other shards is in flight (SURVEY 8(f)-3); default off, see overlap_ab in the JSON")
@@ -607,7 +626,7 @@ def main():
 
     import nbody_amd  # noqa: F401
     from nbody_amd import capi, synthetic
-    from nbody_amd.distributed import ShardedSystem, hip_compute, shard_range
+    from nbody_amd.distributed import ShardedSystem, hip_compute, shard_range, workspace_bytes
     if args.lib:
         capi.library_path = lambda: os.path.abspath(args.lib)
 
@@ -711,30 +730,38 @@ def main():
         np.savez(args.dump_rows, idx=idx.cpu().numpy(), q=qd, v=vd, step=first_step + args.warmup + steps_done)
 
     # --- untimed diagnostics (after the timed region; not part of `value`)
-    exchange_ms = check = overlap_ab = spot = lds = native = replicas = None
+    exchange_ms = check = overlap_ab = spot = lds = sgpr = native = replicas = None
     kern_per_rank = rank_ids = None
     diag_errors = []
-    if world == 1 and not args.no_diagnostics and not sysm.ring and args.source_path != 1 and not args.lib:
-        # the north star's named kernel — sources staged through an LDS tile — on the same system, five untimed steps:
-        # the adopted SGPR path's margin over it comes from this run, not from a builder profile
-        try:
-            main_compute, sysm.compute = sysm.compute, hip_compute(acc64, 0, 0, 1, 0)
-            sysm.step()
-            torch.cuda.synchronize()
-            sysm.kernel_events = ev_lds = []
-            for _ in range(5):
+    if world == 1 and not args.no_diagnostics and not sysm.ring and not args.lib:
+        # the other kernels of the family on the same system, five untimed steps each, so that the adopted kernel's margin
+        # comes from this run and not from a builder profile: the north star's named kernel — sources staged through an LDS
+        # tile (source_path 1) — and K1 with sources broadcast from SGPRs (source_path 2), both evaluating every ORDERED pair
+        def other_path(sp, what):
+            main_compute, sysm.compute = sysm.compute, hip_compute(acc64, 0, 0, sp, 0)
+            try:
                 sysm.step()
-            torch.cuda.synchronize()
-            ms = sum(a.elapsed_time(b) for a, b in ev_lds) / len(ev_lds)
-            ws1 = capi.workspace_bytes_f32(n, acc64)
-            lds = {"ms_per_step": ms, "frac": FLOP_PER_PAIR * n * (n - 1) / (ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
-                   "kernel": capi.kernel_name_f32(n, n, acc64, 0, 0, ws1, source_path=1),
-                   "plan": list(capi.plan_f32(n, n, acc64, 0, 0, ws1, 1, 0)), "steps": 5,
-                   "what": "source_path=1: 256-body float4 tiles through LDS, one coalesced 16-B load per lane per tile, "
-                           "broadcast ds_read_b128 in the pair loop; same slicing, same arithmetic, HIP events on the launch stream"}
-            sysm.compute, sysm.kernel_events = main_compute, None
+                torch.cuda.synchronize()
+                sysm.kernel_events = evs = []
+                for _ in range(5):
+                    sysm.step()
+                torch.cuda.synchronize()
+                ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+            finally:
+                sysm.compute, sysm.kernel_events = main_compute, None
+            ws1 = workspace_bytes(n, n, acc64, 0, 0, sp, 0)
+            return {"ms_per_step": ms, "frac": FLOP_PER_PAIR * n * (n - 1) / (ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
+                    "kernel": capi.kernel_name_f32(n, n, acc64, 0, 0, ws1, source_path=sp),
+                    "plan": list(capi.plan_f32(n, n, acc64, 0, 0, ws1, sp, 0)), "steps": 5, "what": what}
+        try:
+            if args.source_path != 1:
+                lds = other_path(1, "source_path=1: every ordered pair; 256-body float4 tiles through LDS, one coalesced 16-B load "
+                                    "per lane per tile, broadcast ds_read_b128 in the pair loop; HIP events on the launch stream")
+            if args.source_path != 2:
+                sgpr = other_path(2, "source_path=2: every ordered pair (K1); sources broadcast from SGPRs (s_load_dwordx16), "
+                                     "sliced launch + reducer; HIP events on the launch stream")
         except Exception as e:  # noqa: BLE001
-            diag_errors.append(f"lds_path: {type(e).__name__}: {e}")
+            diag_errors.append(f"other kernels: {type(e).__name__}: {e}")
     if world > 1:
         # who ran: every rank's GPU, read by the rank itself; and every rank's own kernel time (rank 0's prices `roofline`
         # unless another rank was slower)
@@ -840,8 +867,9 @@ def main():
             k_ms = max(kern_per_rank)
         flops_launch = FLOP_PER_PAIR * sysm.n_tgt * (n - 1)
         achieved = flops_launch / (k_ms * 1e-3) / 1e12
-        ws_bytes = capi.workspace_bytes_f32(sysm.n_tgt, acc64)  # what hip_compute sizes its workspace from
         n_cover = sysm.n_tgt if sysm.ring else n  # sources one launch sequence covers (ring pass: one travelling block)
+        ws_bytes = workspace_bytes(n_cover, sysm.n_tgt, acc64, args.targets_per_lane, args.j_split, args.source_path,
+                                   args.wg_size)  # what hip_compute allocates
         kname = capi.kernel_name_f32(n_cover, sysm.n_tgt, acc64, args.targets_per_lane, args.j_split, ws_bytes,
                                      source_path=args.source_path, wg_size=args.wg_size)
         tpl, jsp, wgs = capi.plan_f32(n_cover, sysm.n_tgt, acc64, args.targets_per_lane, args.j_split, ws_bytes,
@@ -854,7 +882,7 @@ def main():
             tail = ["--bodies", str(n), "--precision", args.precision, "--targets-per-lane", str(args.targets_per_lane),
                     "--j-split", str(args.j_split), "--source-path", str(args.source_path), "--wg-size", str(args.wg_size),
                     "--no-diagnostics"]
-            live = live_pmc(tail)
+            live = live_pmc(tail, step_kernels(kname))
             if live and "error" not in live:
                 traffic, valu_busy = live["hbm_bytes_per_step"], live["valu_busy"]
                 traffic_source = ("measured by this run: three 2-step child runs under rocprofv3 --pmc (FETCH_SIZE x2 gfx950 "
@@ -891,6 +919,8 @@ def main():
             out["kernel_ms_per_rank"] = kern_per_rank
         if lds is not None:
             out["lds_path"] = lds
+        if sgpr is not None:
+            out["ordered_pair_path"] = sgpr
         if exchange_ms is not None:
             out["exchange_ms"] = exchange_ms  # one all-gather of float4[N] by itself, mean of 20
         if check is not None:

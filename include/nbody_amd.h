@@ -245,7 +245,12 @@ typedef struct nb_launch_f32 {
     int32_t targets_per_lane; /* 0 = auto; 2, 4 or 8 (packed pairs of targets per lane) */
     int32_t j_split;          /* 0 = auto; 1..1024 source slices (~1 MiB each when auto): workgroups sharing a target
                                  block each take one slice; 16 slices per launch, partial sums folded by a reducer */
-    int32_t source_path;      /* 0 = auto; 1 = sources through the LDS tile; 2 = sources through scalar loads/SGPRs */
+    int32_t source_path;      /* 0 = auto; 1 = sources through the LDS tile; 2 = sources through scalar loads/SGPRs (both: every
+                                 ORDERED pair, kernel K1); 3 = every UNORDERED pair once, Newton's third law (kernel K1s: the
+                                 sources travel through the wave by DPP rotation) — needs the whole system in this one launch
+                                 (n_tgt == n_src, tgt_off 0, phase WHOLE), n_src >= 262144 and a workspace of
+                                 nb_workspace_bytes_sym_f32(); auto picks it whenever that holds and nothing else is forced;
+                                 j_split then = workgroups per 4096-body superblock (0 = auto) */
     int32_t wg_size;          /* 0 = auto; 256, 512 (targets_per_lane 8) or 1024 (targets_per_lane 4) */
     int32_t phase;            /* nb_launch_phase: a step may be cut into several launches over disjoint source ranges
                                  (own shard while the all-gather of the other shards is still in flight);
@@ -270,6 +275,10 @@ const char* nb_kernel_name_f32(const nb_launch_f32* a, int accel_only);
 int nb_plan_f32(const nb_launch_f32* a, int* targets_per_lane, int* j_split, int* wg_size);
 /* workspace size that allows source slicing for n_tgt targets: 18 records per target (2 + 16 slots) */
 int64_t nb_workspace_bytes_f32(int64_t n_tgt, int acc64);
+/* workspace size that lets a whole-system launch of n bodies use K1s (source_path 3): one float4 record per body and
+ * superblock round, n/8192 + 1 records per body — 2.2 GB at n = 2^20, 34 GB at 2^22; 0 = K1s does not apply to this n
+ * (fewer than 262144 bodies, or more than 40 GiB of slots) */
+int64_t nb_workspace_bytes_sym_f32(int64_t n, int acc64);
 
 /* ---- index-sharded multi-GPU stepping: ONE process, P GPUs of a node, RCCL over xGMI (csrc/nbody_sharded.cpp) ----
  * The reference's only multi-GPU use is task parallelism (hw5.cu:564-567,587-588); this is the data-parallel scheme of

@@ -98,6 +98,7 @@ SYMBOLS = {
     "nb_kernel_name_f32": (C.c_char_p, [C.POINTER(NbLaunchF32), C.c_int]),
     "nb_plan_f32": (C.c_int, [C.POINTER(NbLaunchF32), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "nb_workspace_bytes_f32": (C.c_int64, [C.c_int64, C.c_int]),
+    "nb_workspace_bytes_sym_f32": (C.c_int64, [C.c_int64, C.c_int]),
     "nb_sharded_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int64, C.c_int, C.c_double,
                                    C.c_double, C.c_double, C.c_int]),
     "nb_sharded_destroy": (C.c_int, [C.c_void_p]),
@@ -553,6 +554,11 @@ def plan_f32(n_src, n_tgt, acc64=False, targets_per_lane=0, j_split=0, workspace
 
 def workspace_bytes_f32(n_tgt, acc64=False):
     return lib().nb_workspace_bytes_f32(n_tgt, int(acc64))
+
+
+def workspace_bytes_sym_f32(n, acc64=False):
+    """Bytes that let a whole-system launch of n bodies use the symmetric kernel K1s; 0 = not applicable to this n."""
+    return lib().nb_workspace_bytes_sym_f32(n, int(acc64))
 
 
 def kernel_name_f32(n_src, n_tgt, acc64=False, targets_per_lane=0, j_split=0, workspace_bytes=0, accel_only=False,

@@ -144,9 +144,17 @@ F32Args f32_args(nb_context* c) {
     return a;
 }
 
+// the context's launch plan: K1s (every unordered pair once) when the system is large enough for it and the workspace
+// was sized for it at creation, else K1
+F32Plan context_plan_f32(nb_context* c) {
+    F32Plan plan = plan_f32(c->n, c->n, c->n_cus, 0, 0, c->partial != nullptr);
+    (void)plan_symmetric(plan, c->n, c->n, true, c->partial_bytes, c->cfg.precision == NB_F32_ACC64, c->n_cus, 0, 0);
+    return plan;
+}
+
 int step_f32(nb_context* c, int count) {
     const bool acc64 = c->cfg.precision == NB_F32_ACC64;
-    const F32Plan plan = plan_f32(c->n, c->n, c->n_cus, 0, 0, c->partial != nullptr);
+    const F32Plan plan = context_plan_f32(c);
     for (int s = 0; s < count; ++s) {
         F32Args a = f32_args(c);
         NB_HIP(c, (hipError_t)launch_f32(a, plan, acc64, false, c->stream));
@@ -280,8 +288,13 @@ int nbi::create_context(nb_context** out, const nb_config* cfg, hipStream_t borr
             const size_t rec = cfg->precision == NB_F32_ACC64 ? sizeof(double4) : sizeof(float4);
             const long cap = (long)(((size_t)8 << 30) / (n * rec)) - 2;
             c->partial_slots = (int)std::max<long>(SLICES_PER_LAUNCH, std::min<long>(std::min<long>(js, MAX_SLICES_PER_LAUNCH), cap));
-            NB_HIP(c, hipMalloc(&c->partial, (size_t)(c->partial_slots + 2) * n * rec));
+            c->partial_bytes = (size_t)(c->partial_slots + 2) * n * rec;
         }
+        if (c->n >= SYM_MIN_N) {  // K1s: a slot per superblock round, B/2 + 1 records per body (2.2 GB at 2^20)
+            const size_t sym = sym_workspace_bytes(sym_shape(c->n, c->n_cus), cfg->precision == NB_F32_ACC64);
+            if (sym <= SYM_MAX_WORKSPACE) c->partial_bytes = std::max(c->partial_bytes, sym);
+        }
+        if (c->partial_bytes) NB_HIP(c, hipMalloc(&c->partial, c->partial_bytes));
         if (cfg->precision == NB_F32_ACC64) {
             NB_HIP(c, hipMalloc(&c->pos64, n * sizeof(double4)));
             NB_HIP(c, hipMalloc(&c->vel64, n * sizeof(double4)));
@@ -473,8 +486,7 @@ static int nb_accel_impl(nb_context* c, int step, double* ax, double* ay, double
     } else {
         const bool acc64 = c->cfg.precision == NB_F32_ACC64;
         F32Args a = f32_args(c);
-        NB_HIP(c, (hipError_t)launch_f32(a, plan_f32(c->n, c->n, c->n_cus, 0, 0, c->partial != nullptr), acc64, true,
-                                         c->stream));
+        NB_HIP(c, (hipError_t)launch_f32(a, context_plan_f32(c), acc64, true, c->stream));
         if (acc64) {
             std::vector<double4> h(n);
             NB_HIP(c, hipMemcpyAsync(h.data(), c->acc32, n * sizeof(double4), hipMemcpyDeviceToHost, c->stream));
@@ -552,7 +564,7 @@ static int check_launch(const nb_launch_f32* a, bool accel_only) {
     if (r != 0 && r != 2 && r != 4 && r != 8) return NB_ERR_INVALID;
     if (a->j_split < 0 || a->j_split > MAX_JSPLIT) return NB_ERR_INVALID;
     if (a->j_split > 1 && !a->workspace) return NB_ERR_INVALID;
-    if (a->source_path < 0 || a->source_path > 2) return NB_ERR_INVALID;
+    if (a->source_path < 0 || a->source_path > 3) return NB_ERR_INVALID;
     if (a->wg_size != 0 && a->wg_size != 256 && a->wg_size != 512 && a->wg_size != 1024) return NB_ERR_INVALID;
     if (a->phase < NB_PHASE_WHOLE || a->phase > NB_PHASE_MIDDLE) return NB_ERR_INVALID;
     if (a->src_begin || a->src_end) {  // a sub-range of the sources: whole 256-body tiles, except at the very end
@@ -582,7 +594,20 @@ static F32Plan resolve_plan(const nb_launch_f32* a) {
                          a->source_path, a->wg_size);
     // the caller's workspace must hold SLICES_PER_LAUNCH partial records + running sum + compensation per target
     if (workspace_slots(a) < SLICES_PER_LAUNCH) p.j_split = 1;
+    // K1s (every unordered pair once): the whole system in one launch and a workspace of nb_workspace_bytes_sym_f32
+    const bool whole = a->phase == NB_PHASE_WHOLE && !a->src_begin && !a->src_end && !a->tgt && a->tgt_off == 0;
+    // (a forced register blocking, workgroup size or slice count asks for K1; with source_path 3 j_split = chunks)
+    if (a->targets_per_lane == 0 && a->wg_size == 0 && (a->j_split == 0 || a->source_path == 3))
+        (void)plan_symmetric(p, a->n_tgt, a->n_src, whole, a->workspace ? (size_t)a->workspace_bytes : 0, a->acc64 != 0, cus,
+                             a->source_path, a->j_split);
     return p;
+}
+
+static int refuse_unmet_symmetric(const nb_launch_f32* a, const F32Plan& p) {
+    if (a->source_path == 3 && !p.symmetric)
+        return set_error(NB_ERR_INVALID, "source_path 3 (every unordered pair once) needs the whole system in one launch "
+                         "(n_tgt == n_src, tgt_off 0, no phases), n_src >= 262144 and a workspace of nb_workspace_bytes_sym_f32");
+    return NB_OK;
 }
 
 static F32Args to_args(const nb_launch_f32* a) {
@@ -609,13 +634,17 @@ static F32Args to_args(const nb_launch_f32* a) {
 
 int nb_launch_step_f32(const nb_launch_f32* a, void* hip_stream) {
     if (int rc = check_launch(a, false)) return rc;
-    hipError_t e = (hipError_t)launch_f32(to_args(a), resolve_plan(a), a->acc64 != 0, false, (hipStream_t)hip_stream);
+    const F32Plan plan = resolve_plan(a);
+    if (int rc = refuse_unmet_symmetric(a, plan)) return rc;
+    hipError_t e = (hipError_t)launch_f32(to_args(a), plan, a->acc64 != 0, false, (hipStream_t)hip_stream);
     return e == hipSuccess ? NB_OK : fail_hip(nullptr, e, "nb_launch_step_f32");
 }
 
 int nb_launch_accel_f32(const nb_launch_f32* a, void* hip_stream) {
     if (int rc = check_launch(a, true)) return rc;
-    hipError_t e = (hipError_t)launch_f32(to_args(a), resolve_plan(a), a->acc64 != 0, true, (hipStream_t)hip_stream);
+    const F32Plan plan = resolve_plan(a);
+    if (int rc = refuse_unmet_symmetric(a, plan)) return rc;
+    hipError_t e = (hipError_t)launch_f32(to_args(a), plan, a->acc64 != 0, true, (hipStream_t)hip_stream);
     return e == hipSuccess ? NB_OK : fail_hip(nullptr, e, "nb_launch_accel_f32");
 }
 
@@ -631,6 +660,14 @@ int nb_plan_f32(const nb_launch_f32* a, int* targets_per_lane, int* j_split, int
     if (j_split) *j_split = p.j_split;
     if (wg_size) *wg_size = p.wg_size;
     return NB_OK;
+}
+
+int64_t nb_workspace_bytes_sym_f32(int64_t n, int acc64) {
+    if (n < SYM_MIN_N) return 0;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const size_t b = sym_workspace_bytes(sym_shape(n, cus), acc64 != 0);
+    return b <= SYM_MAX_WORKSPACE ? (int64_t)b : 0;
 }
 
 int64_t nb_workspace_bytes_f32(int64_t n_tgt, int acc64) {

@@ -71,8 +71,10 @@ struct nb_context {
     double4* pos64 = nullptr;
     double4* vel64 = nullptr;
     void* acc32 = nullptr;
-    void* partial = nullptr;  // source-slice workspace [partial_slots + 2][n] float4 (double4 for ACC64)
+    void* partial = nullptr;  // workspace: source slices [2 + partial_slots][n] float4 (double4 for ACC64), and — large
+                              // enough for it from SYM_MIN_N bodies on — the pair slots of the symmetric kernel K1s
     int partial_slots = 0;
+    size_t partial_bytes = 0;
 };
 
 namespace nbi {

@@ -46,13 +46,45 @@ constexpr int F32_PHASE_MIDDLE = 3;  // continue the sums, keep them
 constexpr int SLICES_PER_LAUNCH = 16;  // default blockIdx.y extent of one split launch = partial-sum slots in the workspace
 constexpr int MAX_SLICES_PER_LAUNCH = 64;
 constexpr int MAX_JSPLIT = 1024;       // source slices per step (processed SLICES_PER_LAUNCH at a time)
+// ---- K1s (nbody_kernels_f32_sym.hip): every unordered pair once — Newton's third law
+constexpr int SYM_P = 4, SYM_WGS = 512;            // packed target pairs per lane, threads per workgroup (8 waves)
+constexpr int SYM_SB = SYM_WGS * 2 * SYM_P;        // superblock: 4096 bodies, the targets one workgroup holds in registers
+constexpr long SYM_MIN_N = 262144;                 // below this the pair list is too short to fill the chip (64 superblocks)
+constexpr size_t SYM_MAX_WORKSPACE = (size_t)40 << 30;  // partial-sum slots grow with n^2/8192 * 16 B: 2.2 GB at 2^20, 34 GB at 2^22
+struct F32SymShape {  // who computes what in one launch
+    int B;         // superblocks covering the system
+    int b0, nb;    // I-superblocks this launch owns: [b0, b0 + nb)   (one GPU: 0, B)
+    int chunks;    // workgroups per I-superblock: its 1 + rounds work units are split evenly over them
+    int by_super;  // slot of a finished superblock pair: 0 = round - 1 (one GPU: B/2 slots), 1 = I-superblock - b0 (several
+                   // GPUs share the pairs: nb slots)
+    long npad;     // B * SYM_SB: bodies per slot
+};
+__host__ __device__ inline int sym_own_slots(const F32SymShape& s, bool acc64) { return s.chunks * (acc64 ? 2 : 1); }
+__host__ __device__ inline int sym_total_slots(const F32SymShape& s, bool acc64) {
+    return sym_own_slots(s, acc64) + (s.by_super ? s.nb : s.B / 2);
+}
+F32SymShape sym_shape(long n, int n_cus, int b0 = 0, int nb = 0, int force_chunks = 0);
+size_t sym_workspace_bytes(const F32SymShape& s, bool acc64);
+// mode 0: force + kick-drift of the whole system; 1: accelerations out; 2: this launch's partial force out (a.acc:
+// float4[n] / double4[n]) for the reduce-scatter of a multi-GPU step.  a.partial = the slot workspace.
+int launch_f32_sym(const F32Args& a, const F32SymShape& s, bool acc64, int mode, hipStream_t stream);  // hipError_t
+// kick-drift of targets [tgt_off, tgt_off + n_tgt) from finished accelerations a.acc[n_tgt]
+int launch_kick_drift_f32(const F32Args& a, bool acc64, hipStream_t stream);
+
 struct F32Plan {
     int targets_per_lane = 4;  // 2, 4 or 8 (one, two or four packed pairs per lane)
     int j_split = 1;           // source slices: workgroups sharing one target block, each over 1/j_split of the sources
     bool sgpr_sources = true;  // sources via scalar loads into SGPRs (default) instead of the LDS tile
     int wg_size = 256;         // threads per workgroup: 256, 512 (R = 8) or 1024 (R = 4); LDS path: 256
+    bool symmetric = false;    // K1s instead of K1 (whole-system launches with a slot workspace; plan_symmetric)
+    F32SymShape sym{};
 };
-// source_path: 0 = auto (SGPR), 1 = LDS tile, 2 = SGPR ; force_wg: 0 = auto
+// K1s for this launch?  Needs the whole system as targets AND sources in one launch (n_tgt == n_src, no phases, no
+// travelling target block), SYM_MIN_N bodies or more and a workspace of sym_workspace_bytes.  source_path: 0 = auto (yes
+// when eligible), 3 = required (false if not eligible, the plan is left alone), 1 / 2 = never.
+bool plan_symmetric(F32Plan& p, long n_tgt, long n_src, bool whole, size_t workspace_bytes, bool acc64, int n_cus,
+                    int source_path, int force_chunks);
+// source_path: 0 = auto (SGPR), 1 = LDS tile, 2 = SGPR (3 = K1s, see plan_symmetric) ; force_wg: 0 = auto
 F32Plan plan_f32(long n_tgt, long n_src, int n_cus, int force_tpl, int force_js, bool have_workspace,
                  int source_path = 0, int force_wg = 0);
 int launch_f32(const F32Args& a, const F32Plan& plan, bool acc64, bool accel_only, hipStream_t stream);  // hipError_t

@@ -48,7 +48,7 @@
 //  * kick-drift fused: v += a*dt ; q_new = q + v*dt written to the OTHER position array (ping-pong), because
 //    other workgroups still read the old positions — the barrier the reference gets from its kernel boundary
 //    between hw5.cu:371 and :375.
-#include "nbody_kernels.h"
+#include "nbody_f32_common.h"
 
 #ifndef NB_K1_PAIR_GROUP
 #define NB_K1_PAIR_GROUP 2  // pairs taken two at a time, stage by stage (see `interact`); 1 = pair after pair
@@ -60,39 +60,6 @@
 #endif
 
 namespace nbk {
-
-typedef float v2f __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ v2f splat(float x) { return (v2f){x, x}; }
-__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
-
-// ---- shared epilogue: store accelerations, or kick + drift (samples/nbody.cc:76-88) ----
-template <bool ACC64, bool ACCEL_ONLY, typename ACC_T>
-__device__ __forceinline__ void finish_target(const F32Args& a, long i, ACC_T ax, ACC_T ay, ACC_T az, float xi,
-                                              float yi, float zi, float gmi) {
-    if (ACCEL_ONLY) {
-        if (ACC64) ((double4*)a.acc)[i] = make_double4((double)ax, (double)ay, (double)az, 0.0);
-        else ((float4*)a.acc)[i] = make_float4((float)ax, (float)ay, (float)az, 0.f);
-    } else if (ACC64) {
-        const double dt = (double)a.dt;
-        double4 v = a.vel64[i];
-        double4 p = a.pos64[i];
-        v.x += (double)ax * dt; v.y += (double)ay * dt; v.z += (double)az * dt;
-        p.x += v.x * dt; p.y += v.y * dt; p.z += v.z * dt;
-        a.vel64[i] = v;
-        a.pos64[i] = p;
-        a.out[a.tgt_off + i] = make_float4((float)p.x, (float)p.y, (float)p.z, gmi);
-    } else {
-        const float dt = a.dt;
-        float4 v = a.vel[i];
-        v.x = __builtin_fmaf((float)ax, dt, v.x);
-        v.y = __builtin_fmaf((float)ay, dt, v.y);
-        v.z = __builtin_fmaf((float)az, dt, v.z);
-        a.vel[i] = v;
-        a.out[a.tgt_off + i] = make_float4(__builtin_fmaf(v.x, dt, xi), __builtin_fmaf(v.y, dt, yi),
-                                           __builtin_fmaf(v.z, dt, zi), gmi);
-    }
-}
 
 constexpr int SGPR_BATCH = 8;  // bodies per scalar-load batch (32 SGPRs; two batches live = 64 of the ~100 SGPRs)
 
@@ -359,6 +326,7 @@ static int launch_p(const F32Args& a, int js, bool acc64, bool accel_only, hipSt
 
 // valid (source path, workgroup size, targets per lane) combinations; anything else is refused
 int launch_f32(const F32Args& a, const F32Plan& plan, bool acc64, bool accel_only, hipStream_t stream) {
+    if (plan.symmetric) return launch_f32_sym(a, plan.sym, acc64, accel_only ? 1 : 0, stream);  // K1s: every unordered pair once
     const int R = plan.targets_per_lane, js = plan.j_split, wg = plan.wg_size;
     if (!plan.sgpr_sources) {
         if (wg != 256) return (int)hipErrorInvalidValue;
@@ -379,6 +347,10 @@ const char* kernel_name_f32(const F32Plan& plan, bool acc64, bool accel_only) {
     static char buf[8][112];
     static int slot = 0;
     char* s = buf[slot++ & 7];
+    if (plan.symmetric) {
+        snprintf(s, 112, "nbody_force_sym_f32<%s>", acc64 ? "true" : "false");
+        return s;
+    }
     snprintf(s, 112, "nbody_force_f32<%d, %s, %s, %s, %s, %d>", plan.targets_per_lane / 2, acc64 ? "true" : "false",
              accel_only ? "true" : "false", plan.j_split > 1 ? "true" : "false", plan.sgpr_sources ? "true" : "false",
              plan.wg_size);

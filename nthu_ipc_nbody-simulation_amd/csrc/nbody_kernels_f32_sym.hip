@@ -1,0 +1,349 @@
+// nbody_kernels_f32_sym.hip — K1s: the all-pairs fp32 force with Newton's third law, hand-written for gfx950 (CDNA4,
+// wave64): every UNORDERED pair of bodies is evaluated once and serves both of them.
+//
+// The reference evaluates every ordered pair (samples/nbody.cc:57-73: for i, for j != i; hw5.cu:159-215: a thread per
+// (i,j)); so does K1 (nbody_kernels_f32.hip): 12 packed VALU + v_rsq_f32 per pair = 32 SIMD cycles per 64 pairs, an issue
+// ceiling of 62 % of the fp32 peak in the 20-flop convention, of which K1 reaches 96 %.  The distance, the rsqrt and the
+// inverse cube of a pair are the same for both bodies: evaluating the pair once costs
+//     3 sub, 3 fma (r2), v_rsq_f32, 2 mul (rinv^3), 2 mul (x G*m_j, x G*m_i), 3 fma (a_i), 3 fma (a_j)
+//   = 16 packed VALU + 2 v_rsq_f32 per two packed pairs = FOUR interactions  ->  20 SIMD cycles per 64 interactions.
+// The obstacle on a GPU is a_j: the partial sum of a source is spread over the lanes that hold its partners (the reference
+// throws atomics at it, hw5.cu:211-213).  Here it is solved systolically inside a wave, with no atomics anywhere:
+//   * a lane owns P = 4 packed pairs of TARGETS in registers (as in K1) and one packed pair of SOURCES that travels:
+//     {x,y,z,G*m} and the three accumulators of the travelling pair move one lane per step (v_mov_b32_dpp wave_ror:1 —
+//     14 moves per step against 8 x 16 packed ops), so after 64 steps every lane's 8 targets have met the wave's 128
+//     sources, and every source's accumulator is back in its home lane holding the sum over the wave's 512 targets;
+//   * per step and target pair two packed sets: (iA,j0),(iB,j1) and — the travelling pair's halves swapped by op_sel,
+//     which costs no instruction — (iA,j1),(iB,j0); the two sets advance stage by stage so that no packed result feeds
+//     the very next instruction (hot block of the gfx950 dump: 128 v_pk_*, 16 v_rsq_f32, 14 v_mov_b32_dpp, 2 s_nop);
+//   * a workgroup (8 waves) owns a SUPERBLOCK of SB = 4096 bodies.  It meets another superblock in 32 phases, wave w
+//     taking 128-source tile (phase + 4w) mod 32, and adds its travelling sums into an LDS image of that superblock's
+//     accelerations by plain read-modify-write: the tiles of one phase are distinct, phases are separated by a barrier,
+//     so the order of the additions — and with it every bit of the result — is fixed (bitwise reproducible, like K1);
+//   * superblock pairs: I-superblock b takes J = b + r (mod B) for r = 1 .. (B-1)/2, plus r = B/2 for b < B/2 when B is
+//     even — every unordered pair of superblocks once — and its own diagonal block without the symmetric half.  These
+//     1 + rounds work units are split evenly over `chunks` workgroups.  The LDS image of a finished pair goes to a slot of
+//     a partial-sum workspace, the workgroup's own sums (two-level: 128 contributions in fp32 registers, then Kahan /
+//     fp64 running sums, as in K1) to another; nbody_reduce_sym_f32 adds the slots of a body in a fixed order and runs
+//     the fused kick-drift epilogue (samples/nbody.cc:76-88), or hands the per-GPU partial force to the host's
+//     reduce-scatter when several GPUs share the pairs.
+//   * consecutive superblocks run on one XCD (workgroups are dealt to the XCDs round-robin, so the block index is
+//     remapped): at any time the 32 workgroups of an XCD read a window of 32 consecutive superblocks that slides by one
+//     per round — the source reads are L2 hits instead of fabric traffic.
+// Measured at N = 2^20 on one MI355X (bench/ubench/sym_force.hip, profiles/r04_sym_force_ubench.txt): 176.6 ms per step
+// = 6.2e12 pairs/s = 79 % of the 157.3 TFLOP/s peak at 20 flop per pair, against 234 ms = 59 % for K1; error against the
+// fp64 oracle 3.4e-8 * sum|a_ij| (K1: 2.8e-8).
+// MFMA stays unused (north star): the loop is rsqrt-bound packed-VALU work; nothing here is a dense contraction.
+#include <type_traits>
+
+#include "nbody_f32_common.h"
+
+namespace nbk {
+
+namespace {
+
+__device__ __forceinline__ v2f swp(v2f a) { return __builtin_shufflevector(a, a, 1, 0); }  // folds into op_sel
+__device__ __forceinline__ float rot1(float x) {  // lane l <- lane l-1, wave-wide
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x13C /* wave_ror:1 */, 0xf, 0xf, true));
+}
+__device__ __forceinline__ v2f rot(v2f v) { return (v2f){rot1(v.x), rot1(v.y)}; }
+
+__host__ __device__ inline int sym_rounds(int B, int b) { return (B - 1) / 2 + ((B % 2 == 0 && b < B / 2) ? 1 : 0); }
+
+}  // namespace
+
+constexpr int P = SYM_P, WGS = SYM_WGS, NW = WGS / 64, R = 2 * P, SB = SYM_SB, NT = SB / 128;
+static_assert(NT == NW * P && (NT & (NT - 1)) == 0, "tiles per superblock");
+
+template <bool ACC64>
+__global__ __launch_bounds__(WGS, 1) void nbody_force_sym_f32(F32Args a, F32SymShape sh) {
+    __shared__ float lds[3][SB];  // image of the J-superblock's accelerations (this workgroup's share of them)
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int B = sh.B;
+    // block -> (chunk, I-superblock): consecutive superblocks of one chunk share an XCD
+    const int G = (int)gridDim.x;
+    const int g = (G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    const int chunk = g / sh.nb, b = sh.b0 + g % sh.nb;
+    const long n = a.n_src;
+    const long ibase = (long)b * SB;
+    const float4 nobody = make_float4(0.f, 0.f, 0.f, 0.f);  // past the end: massless, adds exactly +0 (eps2 > 0)
+    auto body = [&](long i) -> float4 { return i < n ? a.src[i] : nobody; };
+
+    v2f xi[P], yi[P], zi[P], gi[P];
+    v2f ax[P], ay[P], az[P];      // sums over the tile in hand
+    v2f sx[P], sy[P], sz[P];      // NB_F32: running sums ...
+    v2f cx[P], cy[P], cz[P];      // ... and their Kahan compensation
+    double dax[R], day[R], daz[R];  // NB_F32_ACC64: running sums in fp64
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const float4 b0 = body(ibase + (long)(2 * p) * WGS + t), b1 = body(ibase + (long)(2 * p + 1) * WGS + t);
+        xi[p] = (v2f){b0.x, b1.x}; yi[p] = (v2f){b0.y, b1.y}; zi[p] = (v2f){b0.z, b1.z}; gi[p] = (v2f){b0.w, b1.w};
+        ax[p] = ay[p] = az[p] = sx[p] = sy[p] = sz[p] = cx[p] = cy[p] = cz[p] = splat(0.f);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) dax[r] = day[r] = daz[r] = 0.0;
+    const v2f eps2 = splat(a.eps2);
+
+    auto flush = [&]() {  // second summation level, as in K1
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            if (ACC64) {
+                dax[2 * p] += (double)ax[p].x; dax[2 * p + 1] += (double)ax[p].y;
+                day[2 * p] += (double)ay[p].x; day[2 * p + 1] += (double)ay[p].y;
+                daz[2 * p] += (double)az[p].x; daz[2 * p + 1] += (double)az[p].y;
+            } else {
+                v2f y, tt;
+                y = ax[p] - cx[p]; tt = sx[p] + y; cx[p] = (tt - sx[p]) - y; sx[p] = tt;
+                y = ay[p] - cy[p]; tt = sy[p] + y; cy[p] = (tt - sy[p]) - y; sy[p] = tt;
+                y = az[p] - cz[p]; tt = sz[p] + y; cz[p] = (tt - sz[p]) - y; sz[p] = tt;
+            }
+            ax[p] = ay[p] = az[p] = splat(0.f);
+        }
+    };
+
+    // one tile of 128 sources (j0 = this lane's body of the first 64, j1 of the second) against the lane's 8 targets:
+    // 64 rotation steps.  SYM: the travelling pair collects its half of every interaction too.
+    auto tile_pass = [&](const float4 j0, const float4 j1, auto sym, v2f& ajx, v2f& ajy, v2f& ajz) {
+        constexpr bool SYM = decltype(sym)::value;
+        v2f xj = (v2f){j0.x, j1.x}, yj = (v2f){j0.y, j1.y}, zj = (v2f){j0.z, j1.z}, gj = (v2f){j0.w, j1.w};
+        ajx = ajy = ajz = splat(0.f);
+#pragma unroll 1
+        for (int s = 0; s < 64; ++s) {
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                // g = 0: (iA, j0), (iB, j1)        g = 1: (iA, j1), (iB, j0)
+                v2f dx[2], dy[2], dz[2], r2[2], rinv[2], r3[2], si[2], sj[2];
+                dx[0] = xj - xi[p];      dx[1] = swp(xj) - xi[p];
+                dy[0] = yj - yi[p];      dy[1] = swp(yj) - yi[p];
+                dz[0] = zj - zi[p];      dz[1] = swp(zj) - zi[p];
+#define NB_ST(stmt) _Pragma("unroll") for (int g = 0; g < 2; ++g) { stmt; }
+                NB_ST(r2[g] = pk_fma(dx[g], dx[g], eps2))
+                NB_ST(r2[g] = pk_fma(dy[g], dy[g], r2[g]))
+                NB_ST(r2[g] = pk_fma(dz[g], dz[g], r2[g]))
+                NB_ST(rinv[g] = ((v2f){__builtin_amdgcn_rsqf(r2[g].x), __builtin_amdgcn_rsqf(r2[g].y)}))  // v_rsq_f32 x2
+                NB_ST(r3[g] = rinv[g] * rinv[g])
+                NB_ST(r3[g] = r3[g] * rinv[g])
+                si[0] = gj * r3[0];      si[1] = swp(gj) * r3[1];
+                if (SYM) { NB_ST(sj[g] = gi[p] * r3[g]) }
+                NB_ST(ax[p] = pk_fma(dx[g], si[g], ax[p]))
+                NB_ST(ay[p] = pk_fma(dy[g], si[g], ay[p]))
+                NB_ST(az[p] = pk_fma(dz[g], si[g], az[p]))
+                if (SYM) {  // reaction on the sources; sj[1].x belongs to pair (iA, j1): it goes to the accumulator's .y
+                    ajx = pk_fma(-dx[0], sj[0], ajx); ajy = pk_fma(-dy[0], sj[0], ajy); ajz = pk_fma(-dz[0], sj[0], ajz);
+                    ajx = pk_fma(-swp(dx[1]), swp(sj[1]), ajx); ajy = pk_fma(-swp(dy[1]), swp(sj[1]), ajy);
+                    ajz = pk_fma(-swp(dz[1]), swp(sj[1]), ajz);
+                }
+#undef NB_ST
+            }
+            xj = rot(xj); yj = rot(yj); zj = rot(zj); gj = rot(gj);
+            if (SYM) { ajx = rot(ajx); ajy = rot(ajy); ajz = rot(ajz); }
+        }
+    };
+    using Yes = std::true_type;
+    using No = std::false_type;
+
+    // this workgroup's share of the I-superblock's work units: unit 0 = the diagonal block, unit r = round r
+    const int units = 1 + sym_rounds(B, b);
+    const int u_lo = (int)((long)chunk * units / sh.chunks), u_hi = (int)((long)(chunk + 1) * units / sh.chunks);
+    v2f ajx, ajy, ajz;
+    bool lds_clean = false;
+    for (int u = u_lo; u < u_hi; ++u) {
+        if (u == 0) {  // the superblock against itself, without the symmetric half; the self pair adds exactly +0
+            float4 j0 = body(ibase + lane), j1 = body(ibase + 64 + lane);
+            for (int k = 0; k < NT; ++k) {
+                const long nb_ = ibase + (long)((k + 1) & (NT - 1)) * 128;
+                const float4 n0 = body(nb_ + lane), n1 = body(nb_ + 64 + lane);  // next tile, in flight during this one
+                tile_pass(j0, j1, No{}, ajx, ajy, ajz);
+                flush();
+                j0 = n0; j1 = n1;
+            }
+            continue;
+        }
+        if (!lds_clean) {
+#pragma unroll
+            for (int k = 0; k < R; ++k) lds[0][k * WGS + t] = lds[1][k * WGS + t] = lds[2][k * WGS + t] = 0.f;
+            __syncthreads();
+            lds_clean = true;
+        }
+        const int J = (b + u) % B;
+        const long jbase = (long)J * SB;
+        const int tile0 = (w * P) & (NT - 1);
+        float4 j0 = body(jbase + (long)tile0 * 128 + lane), j1 = body(jbase + (long)tile0 * 128 + 64 + lane);
+        for (int ph = 0; ph < NT; ++ph) {
+            const int tile = (ph + w * P) & (NT - 1);
+            const long nb_ = jbase + (long)((tile + 1) & (NT - 1)) * 128;
+            const float4 n0 = body(nb_ + lane), n1 = body(nb_ + 64 + lane);  // next phase's tile, in flight during this one
+            tile_pass(j0, j1, Yes{}, ajx, ajy, ajz);
+            flush();
+            const int e = tile * 128 + lane;  // distinct tiles per wave within a phase: plain read-modify-write
+            lds[0][e] += ajx.x; lds[0][e + 64] += ajx.y;
+            lds[1][e] += ajy.x; lds[1][e + 64] += ajy.y;
+            lds[2][e] += ajz.x; lds[2][e + 64] += ajz.y;
+            j0 = n0; j1 = n1;
+            __syncthreads();  // phases must not overlap: the next one touches tiles other waves have just updated
+        }
+        const int slot = sym_own_slots(sh, ACC64) + (sh.by_super ? b - sh.b0 : u - 1);
+        float4* out = (float4*)a.partial + (long)slot * sh.npad + jbase;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int e = k * WGS + t;
+            out[e] = make_float4(lds[0][e], lds[1][e], lds[2][e], 0.f);
+            lds[0][e] = lds[1][e] = lds[2][e] = 0.f;  // by the thread that wrote it out: clean for the next pair
+        }
+        __syncthreads();
+    }
+    // own sums -> slot `chunk` (fp64 sums: two records, the value split into two floats)
+    float4* own = (float4*)a.partial + ibase;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int p = r >> 1, h = r & 1;
+        const long i = (long)r * WGS + t;
+        if (ACC64) {
+            const float hx = (float)dax[r], hy = (float)day[r], hz = (float)daz[r];
+            own[(long)(2 * chunk) * sh.npad + i] = make_float4(hx, hy, hz, (float)(dax[r] - (double)hx));
+            own[(long)(2 * chunk + 1) * sh.npad + i] = make_float4((float)(day[r] - (double)hy), (float)(daz[r] - (double)hz), 0.f, 0.f);
+        } else {
+            own[(long)chunk * sh.npad + i] = make_float4(sx[p][h], sy[p][h], sz[p][h], 0.f);
+        }
+    }
+}
+
+// add the slots that hold a contribution of THIS launch for body i, in a fixed order, then the epilogue.
+// MODE 0: kick-drift; 1: accelerations out; 2: the launch's partial force out (float4 / double4 [n], for a reduce-scatter
+// over the GPUs that share the pairs)
+template <bool ACC64, int MODE>
+__global__ __launch_bounds__(WG) void nbody_reduce_sym_f32(F32Args a, F32SymShape sh) {
+    const long i = (long)blockIdx.x * WG + threadIdx.x;
+    if (i >= a.n_src) return;
+    const int B = sh.B, J = (int)(i / SB);
+    const float4* ws = (const float4*)a.partial;
+    const int own = sym_own_slots(sh, ACC64);
+    double dx = 0, dy = 0, dz = 0;                          // ACC64
+    float rx = 0, ry = 0, rz = 0, kx = 0, ky = 0, kz = 0;   // F32: Kahan
+    auto add = [&](float x, float y, float z) {
+        if (ACC64) { dx += (double)x; dy += (double)y; dz += (double)z; return; }
+        float u, v;
+        u = x - kx; v = rx + u; kx = (v - rx) - u; rx = v;
+        u = y - ky; v = ry + u; ky = (v - ry) - u; ry = v;
+        u = z - kz; v = rz + u; kz = (v - rz) - u; rz = v;
+    };
+    if (J >= sh.b0 && J < sh.b0 + sh.nb) {
+        for (int c = 0; c < sh.chunks; ++c) {
+            if (ACC64) {
+                const float4 hi = ws[(long)(2 * c) * sh.npad + i], lo = ws[(long)(2 * c + 1) * sh.npad + i];
+                dx += (double)hi.x + (double)hi.w; dy += (double)hi.y + (double)lo.x; dz += (double)hi.z + (double)lo.y;
+            } else {
+                const float4 p = ws[(long)c * sh.npad + i];
+                add(p.x, p.y, p.z);
+            }
+        }
+    }
+    if (sh.by_super) {  // a slot per producing I-superblock of this launch
+        for (int k = 0; k < sh.nb; ++k) {
+            const int b = sh.b0 + k;
+            const int r = ((J - b) % B + B) % B;
+            if (r >= 1 && r <= sym_rounds(B, b)) {
+                const float4 p = ws[(long)(own + k) * sh.npad + i];
+                add(p.x, p.y, p.z);
+            }
+        }
+    } else {  // a slot per round: producer b = J - r
+        for (int r = 1; r <= B / 2; ++r) {
+            const int b = ((J - r) % B + B) % B;
+            if (b >= sh.b0 && b < sh.b0 + sh.nb && r <= sym_rounds(B, b)) {
+                const float4 p = ws[(long)(own + r - 1) * sh.npad + i];
+                add(p.x, p.y, p.z);
+            }
+        }
+    }
+    if (MODE == 2) {
+        if (ACC64) ((double4*)a.acc)[i] = make_double4(dx, dy, dz, 0.0);
+        else ((float4*)a.acc)[i] = make_float4(rx, ry, rz, 0.f);
+        return;
+    }
+    const float4 me = a.src[i];
+    if (ACC64) finish_target<true, MODE == 1>(a, i, dx, dy, dz, me.x, me.y, me.z, me.w);
+    else finish_target<false, MODE == 1>(a, i, rx, ry, rz, me.x, me.y, me.z, me.w);
+}
+
+// kick-drift of targets [tgt_off, tgt_off + n_tgt) from finished accelerations a.acc[n_tgt] (float4, or double4 with
+// ACC64) — the epilogue of a step whose forces came out of a reduce-scatter over several GPUs
+template <bool ACC64>
+__global__ __launch_bounds__(WG) void nbody_kick_drift_f32(F32Args a) {
+    const long i = (long)blockIdx.x * WG + threadIdx.x;
+    if (i >= a.n_tgt) return;
+    const float4 me = a.src[a.tgt_off + i];
+    if (ACC64) {
+        const double4 f = ((const double4*)a.acc)[i];
+        finish_target<true, false>(a, i, f.x, f.y, f.z, me.x, me.y, me.z, me.w);
+    } else {
+        const float4 f = ((const float4*)a.acc)[i];
+        finish_target<false, false>(a, i, f.x, f.y, f.z, me.x, me.y, me.z, me.w);
+    }
+}
+
+bool plan_symmetric(F32Plan& p, long n_tgt, long n_src, bool whole, size_t workspace_bytes, bool acc64, int n_cus,
+                    int source_path, int force_chunks) {
+    if (source_path != 0 && source_path != 3) return false;
+    if (!whole || n_tgt != n_src || n_src < SYM_MIN_N) return false;
+    const F32SymShape s = sym_shape(n_src, n_cus, 0, 0, force_chunks);
+    const size_t need = sym_workspace_bytes(s, acc64);
+    if (need > SYM_MAX_WORKSPACE || workspace_bytes < need) return false;
+    p.symmetric = true;
+    p.sym = s;
+    p.targets_per_lane = 2 * SYM_P;
+    p.wg_size = SYM_WGS;
+    p.j_split = s.chunks;
+    p.sgpr_sources = false;
+    return true;
+}
+
+F32SymShape sym_shape(long n, int n_cus, int b0, int nb, int force_chunks) {
+    F32SymShape s{};
+    s.B = (int)((n + SB - 1) / SB);
+    s.npad = (long)s.B * SB;
+    if (nb <= 0) { b0 = 0; nb = s.B; }
+    s.b0 = b0;
+    s.nb = nb;
+    s.by_super = nb < s.B;  // several launches (GPUs) share the pairs: nb <= B/2 slots instead of B/2
+    // one 512-thread workgroup fits a CU (152 VGPRs): give every CU at least one
+    int c = force_chunks > 0 ? force_chunks : (n_cus + nb - 1) / nb;
+    const int units_min = 1 + (s.B - 1) / 2;
+    if (c > units_min) c = units_min;
+    if (c < 1) c = 1;
+    s.chunks = c;
+    return s;
+}
+
+size_t sym_workspace_bytes(const F32SymShape& s, bool acc64) {
+    return (size_t)sym_total_slots(s, acc64) * (size_t)s.npad * sizeof(float4);
+}
+
+int launch_f32_sym(const F32Args& a0, const F32SymShape& sh, bool acc64, int mode, hipStream_t stream) {
+    if (!a0.src || !a0.partial || a0.n_src <= 0 || sh.B <= 0 || sh.nb <= 0 || sh.chunks <= 0 || mode < 0 || mode > 2)
+        return (int)hipErrorInvalidValue;
+    if (sh.b0 < 0 || sh.b0 + sh.nb > sh.B) return (int)hipErrorInvalidValue;
+    if (mode != 2 && (sh.nb != sh.B || a0.tgt_off != 0 || a0.n_tgt != a0.n_src)) return (int)hipErrorInvalidValue;
+    F32Args a = a0;
+    a.tgt = a.src;
+    const unsigned G = (unsigned)sh.nb * (unsigned)sh.chunks;
+    const unsigned rb = (unsigned)((a.n_src + WG - 1) / WG);
+    if (acc64) hipLaunchKernelGGL(nbody_force_sym_f32<true>, dim3(G), dim3(WGS), 0, stream, a, sh);
+    else hipLaunchKernelGGL(nbody_force_sym_f32<false>, dim3(G), dim3(WGS), 0, stream, a, sh);
+    if (hipError_t e = hipGetLastError()) return (int)e;
+#define NB_RED(A, M) hipLaunchKernelGGL((nbody_reduce_sym_f32<A, M>), dim3(rb), dim3(WG), 0, stream, a, sh)
+    if (acc64) { if (mode == 0) NB_RED(true, 0); else if (mode == 1) NB_RED(true, 1); else NB_RED(true, 2); }
+    else { if (mode == 0) NB_RED(false, 0); else if (mode == 1) NB_RED(false, 1); else NB_RED(false, 2); }
+#undef NB_RED
+    return (int)hipGetLastError();
+}
+
+int launch_kick_drift_f32(const F32Args& a, bool acc64, hipStream_t stream) {
+    if (!a.src || !a.out || !a.acc || a.n_tgt <= 0) return (int)hipErrorInvalidValue;
+    const unsigned rb = (unsigned)((a.n_tgt + WG - 1) / WG);
+    if (acc64) hipLaunchKernelGGL(nbody_kick_drift_f32<true>, dim3(rb), dim3(WG), 0, stream, a);
+    else hipLaunchKernelGGL(nbody_kick_drift_f32<false>, dim3(rb), dim3(WG), 0, stream, a);
+    return (int)hipGetLastError();
+}
+
+}  // namespace nbk

@@ -94,6 +94,7 @@ struct Rank {
     double4* vel64 = nullptr;
     void* ws = nullptr;
     int ws_slots = 0;  // partial-sum slots of `ws` (>= 16; up to 64 when the plan cuts the sources into that many slices)
+    size_t ws_bytes = 0;
     ncclComm_t comm = nullptr;
 };
 
@@ -170,7 +171,9 @@ int launch_phase(nb_sharded* s, Rank& k, int64_t src_begin, int64_t src_end, int
     a.eps2 = (float)(s->eps * s->eps);
     a.dt = (float)s->dt;
     const long cover = (src_begin || src_end) ? (long)(src_end - src_begin) : (long)s->n;
-    const F32Plan plan = plan_f32(s->per, cover > 0 ? cover : 1, k.n_cus, 0, 0, k.ws != nullptr);
+    F32Plan plan = plan_f32(s->per, cover > 0 ? cover : 1, k.n_cus, 0, 0, k.ws != nullptr);
+    // one GPU holds the whole system: the symmetric kernel K1s, exactly as nb_step picks it
+    if (s->P == 1) (void)plan_symmetric(plan, s->per, s->n, phase == F32_PHASE_WHOLE, k.ws_bytes, acc64(s), k.n_cus, 0, 0);
     SH_HIP(s, (hipError_t)launch_f32(a, plan, acc64(s), false, k.stream));
     return NB_OK;
 }
@@ -353,8 +356,13 @@ int create_impl(nb_sharded** out, const int* devices, int n_devices, int64_t n, 
         // would slice, and always for overlap
         if (overlapped(s) || plan_f32(s->per, s->n, k.n_cus, 0, 0, true).j_split > 1) {
             k.ws_slots = workspace_slots(s, k.n_cus);
-            SH_HIP(s, hipMalloc(&k.ws, (size_t)workspace_bytes(s, k.ws_slots)));
+            k.ws_bytes = (size_t)workspace_bytes(s, k.ws_slots);
         }
+        if (n_devices == 1 && n >= SYM_MIN_N) {  // room for K1s' pair slots (as nb_create)
+            const size_t sym = sym_workspace_bytes(sym_shape(n, k.n_cus), acc64(s));
+            if (sym <= SYM_MAX_WORKSPACE) k.ws_bytes = std::max(k.ws_bytes, sym);
+        }
+        if (k.ws_bytes) SH_HIP(s, hipMalloc(&k.ws, k.ws_bytes));
     }
     if (copy_exchange(s)) {
         // direct xGMI copies between distinct GPUs; without peer access the runtime stages through the host, which is
@@ -603,7 +611,8 @@ int nb_sharded_info(const nb_sharded* s, int* n_devices, int64_t* targets_per_de
                     int* wg_size) {
     if (!s || s->rank.empty()) return NB_ERR_INVALID;
     const Rank& k = s->rank[0];
-    const F32Plan p = plan_f32(s->per, s->n, k.n_cus, 0, 0, k.ws != nullptr);
+    F32Plan p = plan_f32(s->per, s->n, k.n_cus, 0, 0, k.ws != nullptr);
+    if (s->P == 1) (void)plan_symmetric(p, s->per, s->n, true, k.ws_bytes, acc64(s), k.n_cus, 0, 0);
     if (n_devices) *n_devices = s->P;
     if (targets_per_device) *targets_per_device = s->per;
     if (targets_per_lane) *targets_per_lane = p.targets_per_lane;

@@ -51,7 +51,10 @@ def workspace_bytes(n_src, n_tgt, acc64=False, targets_per_lane=0, j_split=0, so
     _, js, _ = capi.plan_f32(n_src, n_tgt, acc64, targets_per_lane, j_split, base, source_path, wg_size)
     rec = base // 18
     slots = max(16, min(64, js, cap // rec - 2))
-    return (slots + 2) * rec
+    sliced = (slots + 2) * rec
+    if n_src == n_tgt and source_path in (0, 3):  # one rank holds the whole system: room for K1s' pair slots
+        return max(sliced, capi.workspace_bytes_sym_f32(n_src, acc64))
+    return sliced
 
 
 def hip_compute(acc64=False, targets_per_lane=0, j_split=0, source_path=0, wg_size=0):

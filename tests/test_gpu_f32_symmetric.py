@@ -1,0 +1,161 @@
+"""K1s — the fp32 force that evaluates every UNORDERED pair once (Newton's third law; csrc/nbody_kernels_f32_sym.hip) —
+against the fp64 oracle and against K1 (every ordered pair), through the C ABI.
+
+The reference sums a_i over every j != i (samples/nbody.cc:57-73); K1s produces the same sums from half the pair
+evaluations: the reaction on the source is accumulated in registers that travel through the wave.  Same tolerances as K1
+(tests/test_gpu_f32_parity.py): |a_gpu - a_ref|_inf <= 1e-5 * sum_j |a_ij| (fp32), 1e-6 (fp32 pair math, fp64 accumulation).
+"""
+import numpy as np
+import pytest
+
+from test_gpu_f32_parity import TOL_ACC64, TOL_F32, _check_step_rows, _oracle_rows
+
+pytestmark = pytest.mark.gpu
+
+SB = 4096  # superblock of the kernel
+
+
+def _launch(nb, torch, src, n, acc64, source_path, accel=None, j_split=0, out=None, vel=None, pos64=None, vel64=None, dt=None):
+    c, syn = nb.capi, nb.synthetic
+    need = c.workspace_bytes_sym_f32(n, acc64) if source_path == 3 else c.workspace_bytes_f32(n, acc64)
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device="cuda")
+    kw = dict(acc64=acc64, source_path=source_path, j_split=j_split, workspace_ptr=ws.data_ptr(), workspace_bytes=ws.numel())
+    stream = torch.cuda.current_stream().cuda_stream
+    if accel is not None:
+        c.launch_f32(src.data_ptr(), 0, n, 0, n, syn.EPS ** 2, syn.DT, stream, accel_only=True, acc_ptr=accel.data_ptr(), **kw)
+    else:
+        c.launch_f32(src.data_ptr(), out.data_ptr(), n, 0, n, syn.EPS ** 2, dt, stream,
+                     vel_ptr=vel.data_ptr() if vel is not None else 0, pos64_ptr=pos64.data_ptr() if pos64 is not None else 0,
+                     vel64_ptr=vel64.data_ptr() if vel64 is not None else 0, **kw)
+    torch.cuda.synchronize()
+    return ws
+
+
+@pytest.mark.parametrize("n,chunks", [(64 * SB, 0),          # B = 64: even, the half round B/2 for b < 32
+                                      (65 * SB + 77, 0),     # B = 66 with a ragged last superblock (4019 bodies missing)
+                                      (67 * SB, 3),          # B = 67: odd, no half round; three workgroups per superblock
+                                      (64 * SB + 1, 1)])     # B = 65: one body in the last superblock; one workgroup each
+@pytest.mark.parametrize("acc64", [False, True])
+def test_symmetric_accelerations_vs_oracle_and_k1(nb, oracle, n, chunks, acc64):
+    import torch
+    c, syn = nb.capi, nb.synthetic
+    pos, _ = syn.body4_f32(n)
+    src = torch.from_numpy(pos).cuda()
+    dt_acc = torch.float64 if acc64 else torch.float32
+    a_sym = torch.zeros((n, 4), dtype=dt_acc, device="cuda")
+    a_k1 = torch.zeros((n, 4), dtype=dt_acc, device="cuda")
+    ws_bytes = c.workspace_bytes_sym_f32(n, acc64)
+    assert ws_bytes >= ((n + SB - 1) // SB // 2 + 1) * n * 16
+    assert c.kernel_name_f32(n, n, acc64, workspace_bytes=ws_bytes, accel_only=True, source_path=3) == \
+        f"nbody_force_sym_f32<{'true' if acc64 else 'false'}>"
+    tpl, js, wg = c.plan_f32(n, n, acc64, 0, chunks, ws_bytes, 3)
+    assert (tpl, wg) == (8, 512) and (js == chunks if chunks else js >= 1)
+    _launch(nb, torch, src, n, acc64, 3, accel=a_sym, j_split=chunks)
+    _launch(nb, torch, src, n, acc64, 2, accel=a_k1)
+    a1, a2 = a_sym.cpu().numpy()[:, :3].astype(np.float64), a_k1.cpu().numpy()[:, :3].astype(np.float64)
+    assert np.isfinite(a1).all()
+    # rows of the first, a middle and the last superblock (its ragged end included), and of both halves of the round list
+    B = (n + SB - 1) // SB
+    rows = np.unique(np.clip(np.concatenate([np.arange(4), [SB - 1, SB, (B // 2) * SB - 1, (B // 2) * SB + 5,
+                                                              (B - 1) * SB - 1, (B - 1) * SB], n - 1 - np.arange(4),
+                                             np.arange(24) * (n // 24) + 11]), 0, n - 1))
+    ref, s = _oracle_rows(oracle, syn, pos, rows)
+    tol = TOL_ACC64 if acc64 else TOL_F32
+    err = (np.abs(a1[rows].T - ref).max(axis=0) / s).max()
+    assert err < tol, err
+    assert err < (5e-7 if not acc64 else 2e-7), err  # what it actually delivers, with room (measured 3e-8 / 1e-8 at 2^20)
+    # every body against K1 (every ordered pair): two summation orders of the same terms
+    scale = np.abs(a2).max()
+    assert np.abs(a1 - a2).max() < 2e-5 * scale, np.abs(a1 - a2).max() / scale
+    # Newton's third law holds pair by pair here: the total momentum rate cancels to rounding
+    gm = pos[:, 3].astype(np.float64)
+    p = (a1 * gm[:, None]).sum(axis=0)
+    assert np.all(np.abs(p) < 1e-5 * (np.abs(a1) * gm[:, None]).sum(axis=0)), p
+
+
+def test_symmetric_is_bitwise_reproducible_and_is_what_a_context_runs(nb, oracle):
+    """No atomics anywhere: two launches give identical bits; nb_accel / nb_step of a context with >= 262144 bodies pick
+    K1s by themselves (the workspace is sized for it at nb_create) and give exactly the raw launch's numbers."""
+    import torch
+    c, syn = nb.capi, nb.synthetic
+    n = 70 * SB + 5
+    pos, _ = syn.body4_f32(n)
+    src = torch.from_numpy(pos).cuda()
+    a = [torch.zeros((n, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+    for k in range(2):
+        _launch(nb, torch, src, n, False, 3, accel=a[k])
+    assert torch.equal(a[0], a[1])
+    q, v, m = syn.bodies(n)
+    with c.Context(n, c.NB_F32, 0, G=syn.G, eps=syn.EPS, dt=syn.DT) as ctx:
+        ctx.set_state(q, v, m)
+        a_ctx = ctx.accel(1)
+    assert np.array_equal(a_ctx.T.astype(np.float32), a[0].cpu().numpy()[:, :3])
+
+
+@pytest.mark.parametrize("acc64", [False, True])
+def test_symmetric_step_against_oracle(nb, oracle, acc64):
+    """One fused step (force, reducer, kick-drift epilogue): v' = v + a*dt, q' = q + v'*dt (samples/nbody.cc:76-88) on rows
+    of a ragged system, and nb_step of a context equals the raw launch bit for bit."""
+    import torch
+    c, syn = nb.capi, nb.synthetic
+    n, dt = 66 * SB + 1234, 1e-2
+    pos, vel_np = syn.body4_f32(n)
+    q, v, m = syn.bodies(n)
+    src = torch.from_numpy(pos).cuda()
+    out = torch.zeros_like(src)
+    rows = np.concatenate([np.arange(30) * (n // 30) + 7, [0, SB - 1, SB, n - 1235, n - 1]])
+    ref, s = _oracle_rows(oracle, syn, pos, rows)
+    if not acc64:
+        vel = torch.from_numpy(vel_np).cuda()
+        _launch(nb, torch, src, n, False, 3, out=out, vel=vel, dt=dt)
+        _check_step_rows(pos, vel_np, out.cpu().numpy(), vel.cpu().numpy(), rows, 0, ref, s, dt, TOL_F32)
+    else:
+        p64 = torch.from_numpy(np.ascontiguousarray(np.concatenate([q.T, (syn.G * m)[:, None]], axis=1))).cuda()
+        v64 = torch.from_numpy(np.ascontiguousarray(np.concatenate([v.T, np.zeros((n, 1))], axis=1))).cuda()
+        _launch(nb, torch, src, n, True, 3, out=out, pos64=p64, vel64=v64, dt=dt)
+        dt32 = np.float64(np.float32(dt))
+        v_new = v64.cpu().numpy()[rows, :3]
+        a_gpu = (v_new - v.T[rows]) / dt32
+        assert (np.abs(a_gpu.T - ref).max(axis=0) / s).max() < TOL_ACC64
+        assert np.all(np.abs(p64.cpu().numpy()[rows, :3] - (q.T[rows] + v_new * dt32)) <= 4e-16)
+        assert np.array_equal(out.cpu().numpy()[rows, :3], p64.cpu().numpy()[rows, :3].astype(np.float32))
+    with c.Context(n, c.NB_F32_ACC64 if acc64 else c.NB_F32, 0, G=syn.G, eps=syn.EPS, dt=dt) as ctx:
+        ctx.set_state(q, v, m)
+        ctx.step(1, 1)
+        qg, vg = ctx.get_state()
+    if acc64:
+        assert np.array_equal(qg.T, p64.cpu().numpy()[:, :3]) and np.array_equal(vg.T, v64.cpu().numpy()[:, :3])
+    else:
+        assert np.array_equal(qg.T.astype(np.float32), out.cpu().numpy()[:, :3])
+        assert np.array_equal(vg.T.astype(np.float32), vel.cpu().numpy()[:, :3])
+
+
+def test_symmetric_refusals_and_fallbacks(nb):
+    """source_path 3 is refused where K1s cannot run (a target window, too few bodies, too small a workspace, a phase);
+    auto silently takes K1 there."""
+    import torch
+    c, syn = nb.capi, nb.synthetic
+    n = 64 * SB
+    pos, _ = syn.body4_f32(n)
+    src = torch.from_numpy(pos).cuda()
+    acc = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    big = torch.empty(c.workspace_bytes_sym_f32(n), dtype=torch.uint8, device="cuda")
+    small = torch.empty(c.workspace_bytes_f32(n), dtype=torch.uint8, device="cuda")
+    assert c.workspace_bytes_sym_f32(SB * 63) == 0 and c.workspace_bytes_sym_f32(1 << 23) == 0  # too small / > 40 GiB of slots
+    for kw in (dict(workspace_ptr=small.data_ptr(), workspace_bytes=small.numel()),                      # workspace too small
+               dict(workspace_ptr=big.data_ptr(), workspace_bytes=big.numel(), src_begin=0, src_end=n // 2),  # a source range
+               dict(workspace_ptr=big.data_ptr(), workspace_bytes=big.numel(), tgt_ptr=src.data_ptr())):  # a target block
+        with pytest.raises(c.NBodyError, match="unordered pair") as e:
+            c.launch_f32(src.data_ptr(), 0, n, 0, n, syn.EPS ** 2, syn.DT, stream, accel_only=True, acc_ptr=acc.data_ptr(),
+                         source_path=3, **kw)
+        assert e.value.code == c.NB_ERR_INVALID
+    with pytest.raises(c.NBodyError):  # a window of the targets
+        c.launch_f32(src.data_ptr(), 0, n, 4096, n - 4096, syn.EPS ** 2, syn.DT, stream, accel_only=True,
+                     acc_ptr=acc.data_ptr(), source_path=3, workspace_ptr=big.data_ptr(), workspace_bytes=big.numel())
+    # auto: the small workspace gives K1, the big one K1s; a forced register blocking asks for K1
+    assert c.kernel_name_f32(n, n, workspace_bytes=small.numel()).startswith("nbody_force_f32<")
+    assert c.kernel_name_f32(n, n, workspace_bytes=big.numel()) == "nbody_force_sym_f32<false>"
+    assert c.kernel_name_f32(n, n, targets_per_lane=8, workspace_bytes=big.numel()).startswith("nbody_force_f32<")
+    assert c.kernel_name_f32(n, n, j_split=8, workspace_bytes=big.numel()).startswith("nbody_force_f32<")
+    assert c.kernel_name_f32(n, n, workspace_bytes=big.numel(), source_path=2).startswith("nbody_force_f32<")
