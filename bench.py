@@ -353,9 +353,9 @@ def step_kernels(kname):
 
 
 def roofline_block(achieved, kname, k_ms, tpl, jsp, wgs, acc64, traffic=None, traffic_source=None, live=None,
-                   valu_busy=None, reduce_share=None):
+                   valu_busy=None, reduce_share=None, shared_pairs=False):
     sym = kname.startswith("nbody_force_sym_f32")
-    reducer = (f"nbody_reduce_sym_f32<{'true' if acc64 else 'false'}, 0>" if sym else
+    reducer = (f"nbody_reduce_sym_f32<{'true' if acc64 else 'false'}, {2 if shared_pairs else 0}>" if sym else
                f"nbody_reduce_update_f32<{'true' if acc64 else 'false'}, false>")
     ceiling = ISSUE_CEILING_FRAC_SYM if sym else ISSUE_CEILING_FRAC
     detail = ("every UNORDERED pair once (Newton's third law; `value` counts the N(N-1) ordered interactions the reference "
@@ -419,13 +419,16 @@ def main_native(args):
     prec = capi.NB_F32_ACC64 if acc64 else capi.NB_F32
     kw = dict(G=synthetic.G, eps=synthetic.EPS, dt=synthetic.DT)
     try:
-        sh = capi.Sharded(n, devices, prec, overlap=args.overlap, exchange="rccl" if exchange == "rccl" else "copy", **kw)
+        sh = capi.Sharded(n, devices, prec, overlap=args.overlap, exchange="rccl" if exchange == "rccl" else "copy",
+                          ordered_pairs=args.ordered_pairs, **kw)
     except capi.NBodyError as e:  # no GPU (NB_ERR_NO_DEVICE), fewer than P GPUs, RCCL missing: fail loudly, no fallback
         raise SystemExit(f"bench.py --gpus {P} (native host, devices {devices}): {e}")
     q, v, m = synthetic.bodies(n)
     sh.set_state(q, v, m)
     del q, v
     info = sh.info()
+    kname = sh.kernel_name()
+    sym = kname.startswith("nbody_force_sym_f32")
     ranks = [sh.rank_info(r) for r in range(P)]
     if args.warmup:
         sh.step(args.warmup)
@@ -451,8 +454,6 @@ def main_native(args):
     per = info["targets_per_device"]
     k_ms = max(kern)  # the slowest rank prices the roofline
     achieved = FLOP_PER_PAIR * per * (n - 1) / (k_ms * 1e-3) / 1e12
-    ws_bytes = capi.workspace_bytes_f32(per, acc64)
-    kname = capi.kernel_name_f32(n, per, acc64, 0, 0, ws_bytes)
     out = {
         "metric": "body-pair interactions/sec",
         "value": n * (n - 1) * steps_done / wall,
@@ -466,20 +467,25 @@ def main_native(args):
         "vs_baseline": None,
         "dtype": "f32" if not acc64 else "f32 pair math / f64 accumulate",
         "data": "synthetic",
-        "config": workload_config(n, P, f"index-sharded x{P}, one process, 1 in-place "
-                                  f"{'ncclAllGather' if exchange == 'rccl' else 'copy-engine all-gather'} of float4 positions/step"),
+        "config": workload_config(n, P, f"index-sharded x{P}, one process, "
+                                  + (f"unordered pairs shared by the GPUs, 1 {'ncclReduceScatter' if exchange == 'rccl' else 'copy-engine reduce-scatter'} "
+                                     f"of partial forces + " if sym else "")
+                                  + f"1 in-place {'ncclAllGather' if exchange == 'rccl' else 'copy-engine all-gather'} of float4 positions/step"),
         "host": "native",
         "host_detail": "nb_sharded_* (csrc/nbody_sharded.cpp): ONE process, one stream per GPU, "
                        + ("ncclCommInitAll + one in-place ncclAllGather per GPU per step (RCCL over xGMI)" if exchange == "rccl"
                           else "P-1 peer copies per GPU per step on the copy engines (NB_SHARDED_COPY_EXCHANGE)"),
         "exchange": exchange,
         "overlap": bool(args.overlap),
+        "pairs": ("every unordered pair once, shared by the GPUs (K1s); every GPU's partial force on all bodies is "
+                  "reduce-scattered to the shard owners") if sym else "every ordered pair of a GPU's own targets (K1)",
         "ranks": {"count": P, "distinct_devices": len({r["uuid"] for r in ranks}),
                   "exchange": ranks[0]["exchange"],
                   "comm_ranks_seen_by_every_rank": sorted({r["comm_ranks"] for r in ranks}),
                   "per_rank": [{k: r[k] for k in ("rank", "device", "comm_rank", "comm_device", "pci_bus_id", "uuid",
                                                   "name", "compute_units", "first_target", "targets")} for r in ranks]},
-        "roofline": roofline_block(achieved, kname, k_ms, info["targets_per_lane"], info["j_split"], info["wg_size"], acc64),
+        "roofline": roofline_block(achieved, kname, k_ms, info["targets_per_lane"], info["j_split"], info["wg_size"], acc64,
+                                   shared_pairs=sym and P > 1),
         "kernel_ms_per_rank": kern,
         "non_kernel_ms_per_step": wall / steps_done * 1e3 - k_ms,
     }
@@ -521,18 +527,23 @@ def main_native(args):
         # the other settings of the same run, each as a bounded child: overlap toggled, the other exchange
         base = ["--gpus", str(P), "--bodies", str(n), "--precision", args.precision, "--steps", str(min(5, max(2, args.steps))),
                 "--warmup", "1", "--no-diagnostics", "--no-parity-spot"]
+        keep = (["--overlap"] if args.overlap else []) + (["--ordered-pairs"] if args.ordered_pairs else [])
         ab = {}
         for name, extra in (("overlap_" + ("off" if args.overlap else "on"), ["--exchange", exchange] + ([] if args.overlap else ["--overlap"])),
                             ("exchange_" + ("copy" if exchange == "rccl" else "rccl"),
-                             ["--exchange", "copy" if exchange == "rccl" else "rccl"] + (["--overlap"] if args.overlap else []))):
+                             ["--exchange", "copy" if exchange == "rccl" else "rccl"] + keep),
+                            ("pairs_" + ("unordered" if args.ordered_pairs else "ordered"),
+                             ["--exchange", exchange] + (["--overlap"] if args.overlap else []) + ([] if args.ordered_pairs else ["--ordered-pairs"]))):
             if name == "exchange_rccl" and exchange == "copy-one-gpu":
                 continue  # RCCL takes one rank per GPU
             if name.startswith("overlap") and per % 256:
                 continue
             r = run_bench_child(base + extra, timeout=240)
             ab[name] = ({"ms_per_step": r["ms_per_step"], "kernel_ms_per_rank": r.get("kernel_ms_per_rank"),
-                         "non_kernel_ms_per_step": r.get("non_kernel_ms_per_step")} if "error" not in r else r)
-        out["variants"] = {"this_run": {"ms_per_step": out["ms_per_step"], "overlap": bool(args.overlap), "exchange": exchange},
+                         "non_kernel_ms_per_step": r.get("non_kernel_ms_per_step"),
+                         "kernel": r.get("roofline", {}).get("kernel")} if "error" not in r else r)
+        out["variants"] = {"this_run": {"ms_per_step": out["ms_per_step"], "overlap": bool(args.overlap), "exchange": exchange,
+                                        "kernel": kname},
                            **ab, "note": "same system, few steps, each variant its own child process after the timed region"}
         out["replicas"] = replicas_check(devices)
     print(json.dumps(out), flush=True)
@@ -589,6 +600,8 @@ def main():
     ap.add_argument("--host", choices=["auto", "native", "torch"], default="auto", help="auto: the torch host under "
                     "torch.distributed.run (WORLD_SIZE > 1) or with one GPU, the native C-ABI host (nb_sharded_*, one "
                     "process for all GPUs) when --gpus > 1 is typed without a launcher")
+    ap.add_argument("--ordered-pairs", action="store_true", help="multi-GPU: every GPU evaluates every ordered pair of its own "
+                    "targets (K1) even where the GPUs could share the unordered pairs of the system (K1s + reduce-scatter)")
     ap.add_argument("--no-diagnostics", action="store_true", help="multi-GPU: skip the untimed diagnostics after the timed "
                     "region (agreement check, overlap / exchange variants, native-host child, hw5 replicas)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -672,7 +685,8 @@ def main():
         pos, vel = synthetic.body4_f32(n, lo, hi)
     compute = hip_compute(acc64, args.targets_per_lane, args.j_split, args.source_path, args.wg_size)
     sysm = ShardedSystem(n, torch.from_numpy(pos), torch.from_numpy(vel), synthetic.EPS, synthetic.DT, device,
-                         compute=compute, acc64=acc64, overlap=args.overlap, exchange=args.exchange)
+                         compute=compute, acc64=acc64, overlap=args.overlap, exchange=args.exchange,
+                         shared_pairs=False if args.ordered_pairs else None)
 
     # --- kernel-only timing: HIP events on the stream the kernel is launched on (torch's current stream), recorded by
     #     ShardedSystem.step() around its launches
@@ -818,15 +832,18 @@ def main():
             check = sharded_check(torch, dist, world, rank, device, dev_index, args.backend)
         except Exception as e:  # noqa: BLE001
             diag_errors.append(f"sharded_check: {type(e).__name__}: {e}")
-        # the same system stepped with the other setting of --overlap, a few steps, wall clock (max over ranks)
+        # the same system stepped in its other forms, a few steps each, wall clock (max over ranks): every rank its own
+        # ORDERED pairs (K1) plain ("off") and with the two-phase step that hides the all-gather ("on"); and, where the timed
+        # run used it, the ranks sharing the unordered pairs (K1s + reduce-scatter, "shared")
         try:
             ab = {}
             k_ab = min(5, max(2, args.steps))
-            for mode in (False, True):
-                if (mode and sysm.n_tgt % 256) or sysm.ring:
+            was_shared = sysm.shared_pairs
+            for name, shared, mode in (("shared", True, False), ("off", False, False), ("on", False, True)):
+                if (mode and sysm.n_tgt % 256) or sysm.ring or (shared and not was_shared):
                     continue
                 sysm._wait_gather()
-                sysm.overlap = mode
+                sysm.shared_pairs, sysm.overlap = shared, mode
                 sysm.step()
                 barrier()
                 t1 = time.perf_counter()
@@ -836,8 +853,10 @@ def main():
                 w = torch.tensor([(time.perf_counter() - t1) / k_ab], dtype=torch.float64,
                                  device=device if args.backend == "nccl" else "cpu")
                 dist.all_reduce(w, op=dist.ReduceOp.MAX)
-                ab["on" if mode else "off"] = float(w.item()) * 1e3
+                ab[name] = float(w.item()) * 1e3
             overlap_ab = ab
+            sysm._wait_gather()
+            sysm.shared_pairs = was_shared
         except Exception as e:  # noqa: BLE001
             diag_errors.append(f"overlap_ab: {type(e).__name__}: {e}")
         try:
@@ -874,6 +893,9 @@ def main():
                                      source_path=args.source_path, wg_size=args.wg_size)
         tpl, jsp, wgs = capi.plan_f32(n_cover, sysm.n_tgt, acc64, args.targets_per_lane, args.j_split, ws_bytes,
                                       args.source_path, args.wg_size)
+        if getattr(sysm, "shared_pairs", False):  # the ranks share the unordered pairs: K1s, 8 targets per lane, 512 threads
+            kname, tpl, wgs = f"nbody_force_sym_f32<{'true' if acc64 else 'false'}>", 8, 512
+            jsp = max(1, -(-256 // max(1, sysm.n_tgt // 4096)))  # workgroups per superblock (csrc: sym_shape)
         traffic, reduce_share, valu_busy, pmc_tag = load_traffic(n, world, kname, jsp)
         traffic_source = (f"profiles/pmc_traffic.json ({pmc_tag}: builder's rocprofv3 PMC passes on this kernel, N and source "
                           f"split; not measured by this run)") if traffic else None
@@ -902,11 +924,14 @@ def main():
             "dtype": "f32" if not acc64 else "f32 pair math / f64 accumulate",
             "data": "synthetic",
             "config": workload_config(n, world, f"index-sharded x{world}, ring pass of float4 position blocks" if sysm.ring
-                                      else f"index-sharded x{world}, 1 RCCL all-gather of float4 positions/step"),
+                                      else f"index-sharded x{world}, "
+                                      + ("unordered pairs shared by the ranks, 1 RCCL reduce-scatter of partial forces + "
+                                         if getattr(sysm, "shared_pairs", False) else "")
+                                      + "1 RCCL all-gather of float4 positions/step"),
             "host": "torch" if world > 1 else "single",
             "exchange": sysm.exchange_mode,
             "roofline": roofline_block(achieved, kname, k_ms, tpl, jsp, wgs, acc64, traffic, traffic_source, live,
-                                       valu_busy, reduce_share),
+                                       valu_busy, reduce_share, shared_pairs=bool(getattr(sysm, "shared_pairs", False))),
         }
         if out["roofline"]["traffic_detail"]:
             out["roofline"]["traffic_detail"]["algorithmic"] = 56 * n  # 16N + 12N read, 12N + 16N written
@@ -931,8 +956,9 @@ def main():
             out["diagnostics_errors"] = diag_errors
         if overlap_ab:
             out["overlap"] = bool(args.overlap)
-            out["overlap_ab"] = {"ms_per_step": overlap_ab, "note": "two-phase step (own-shard sources during the "
-                                 "all-gather) on vs off, same system, untimed diagnostic after the timed region"}
+            out["overlap_ab"] = {"ms_per_step": overlap_ab, "note": "same system, untimed diagnostic after the timed region: every "
+                                 "rank its own ordered pairs (K1) without / with the two-phase step that hides the all-gather "
+                                 "(off / on); shared = the ranks share the unordered pairs (K1s + reduce-scatter of forces)"}
         if native is not None:
             keep = ("value", "ms_per_step", "n_gpus", "steps", "host", "exchange", "ranks", "kernel_ms_per_rank",
                     "non_kernel_ms_per_step", "parity_spot", "error", "stderr_tail")

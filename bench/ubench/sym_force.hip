@@ -17,7 +17,7 @@
 //   * superblock pairs: workgroup b takes (b, b+r mod B) for r = 1 .. (B-1)/2, plus r = B/2 for b < B/2 when B is even:
 //     every unordered pair of superblocks once; the LDS image goes to slot r of a partial-sum workspace, the workgroup's own
 //     sums (including the diagonal block, done without the symmetric half) to slot 0; a reducer adds the slots.
-// Usage: sym_force [n=1048576] [reps=3] [P=4] [WGS=512]
+// Usage: sym_force [n=1048576] [reps=3] [P=4] [WGS=512] [variant=0] [chunks=1]
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o sym_force sym_force.hip
 #include <hip/hip_runtime.h>
 
@@ -40,6 +40,10 @@ __device__ __forceinline__ float rot1(float x) {  // lane l <- lane l-1 (wave-wi
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x13C, 0xf, 0xf, true));
 }
 __device__ __forceinline__ v2f rot(v2f v) { return (v2f){rot1(v.x), rot1(v.y)}; }
+__device__ __forceinline__ float rowrot1(float x) {  // within 16-lane rows only (timing experiment V = 3: WRONG results)
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x121, 0xf, 0xf, true));
+}
+__device__ __forceinline__ v2f rowrot(v2f v) { return (v2f){rowrot1(v.x), rowrot1(v.y)}; }
 
 struct SymArgs {
     const float4* src;  // [n] {x,y,z,G*m}
@@ -49,17 +53,24 @@ struct SymArgs {
     float eps2;
 };
 
-template <int P, int WGS>
-__global__ __launch_bounds__(WGS, 1) void sym_force(SymArgs a) {
+// V = 0: as the product kernel.  V = 1: the travelling POSITIONS come from an LDS copy of the wave's tile (two ds_read_b128
+// per step, issued one step ahead) instead of 8 of the 14 DPP moves; the accumulators still rotate.  V = 2: no second
+// summation level (sums stay in the tile registers) and compiled for two workgroups per CU — not a product candidate
+// (accuracy), the upper bound of what 4 waves per SIMD would buy.
+template <int P, int WGS, int V>
+__global__ __launch_bounds__(WGS, V == 2 ? 4 : 1) void sym_force(SymArgs a) {
     constexpr int NW = WGS / 64, R = 2 * P, SB = WGS * R, NT = SB / 128;
     static_assert(NT == NW * P, "tiles per superblock");
     __shared__ float lds[3][SB];
+    __shared__ float4 jt[V == 1 ? NW : 1][128];  // V = 1: this wave's tile
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int B = a.B;
     // consecutive superblocks on one XCD (workgroups go to the XCDs round-robin): at round r the 32 workgroups of an XCD
     // read a window of 32 consecutive superblocks that slides by one per round — L2 hits instead of fabric reads
     const int nx = 8;
-    const int b = (B % nx == 0) ? (int)(blockIdx.x % nx) * (B / nx) + (int)(blockIdx.x / nx) : (int)blockIdx.x;
+    const int G = (int)gridDim.x, C = G / B;
+    const int g = (G % nx == 0) ? (int)(blockIdx.x % nx) * (G / nx) + (int)(blockIdx.x / nx) : (int)blockIdx.x;
+    const int chunk = g / B, b = g % B;
     const long ibase = (long)b * SB;
 
     v2f xi[P], yi[P], zi[P], gi[P];
@@ -72,6 +83,7 @@ __global__ __launch_bounds__(WGS, 1) void sym_force(SymArgs a) {
     }
     const v2f eps2 = splat(a.eps2);
     auto flush = [&]() {
+        if (V == 2) return;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             v2f y, tt;
@@ -87,8 +99,16 @@ __global__ __launch_bounds__(WGS, 1) void sym_force(SymArgs a) {
         constexpr bool SYM = decltype(sym)::value;
         v2f xj = (v2f){j0.x, j1.x}, yj = (v2f){j0.y, j1.y}, zj = (v2f){j0.z, j1.z}, gj = (v2f){j0.w, j1.w};
         ajx = ajy = ajz = splat(0.f);
+        float4 n0 = j0, n1 = j1;
+        if (V == 1) {  // (wave-private rows of jt: no barrier, the wave runs in lock step)
+            jt[w][lane] = j0; jt[w][64 + lane] = j1;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            n0 = jt[w][(lane - 1) & 63]; n1 = jt[w][64 + ((lane - 1) & 63)];
+        }
 #pragma unroll 1
         for (int s = 0; s < 64; ++s) {
+            float4 m0 = n0, m1 = n1;
+            if (V == 1) { m0 = jt[w][(lane - s - 2) & 63]; m1 = jt[w][64 + ((lane - s - 2) & 63)]; }  // for step s + 2
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 // two packed sets advanced stage by stage so that no packed result feeds the very next VALU instruction:
@@ -116,8 +136,17 @@ __global__ __launch_bounds__(WGS, 1) void sym_force(SymArgs a) {
                 }
 #undef ST
             }
-            xj = rot(xj); yj = rot(yj); zj = rot(zj); gj = rot(gj);
-            if (SYM) { ajx = rot(ajx); ajy = rot(ajy); ajz = rot(ajz); }
+            if (V == 1) {
+                xj = (v2f){n0.x, n1.x}; yj = (v2f){n0.y, n1.y}; zj = (v2f){n0.z, n1.z}; gj = (v2f){n0.w, n1.w};
+                n0 = m0; n1 = m1;
+            } else if (V == 3) {
+                xj = rowrot(xj); yj = rowrot(yj); zj = rowrot(zj); gj = rowrot(gj);
+            } else if (V == 4) {  // no rotation at all (timing experiment: WRONG results)
+            } else {
+                xj = rot(xj); yj = rot(yj); zj = rot(zj); gj = rot(gj);
+            }
+            if (SYM && V == 3) { ajx = rowrot(ajx); ajy = rowrot(ajy); ajz = rowrot(ajz); }
+            else if (SYM && V != 4) { ajx = rot(ajx); ajy = rot(ajy); ajz = rot(ajz); }
         }
     };
 
@@ -126,7 +155,7 @@ __global__ __launch_bounds__(WGS, 1) void sym_force(SymArgs a) {
     v2f ajx, ajy, ajz;
 
     // diagonal block: the superblock against itself, without the symmetric half (the self pair adds exactly +0: eps2 > 0)
-    for (int k = 0; k < NT; ++k) {
+    for (int k = 0; k < (chunk == 0 ? NT : 0); ++k) {
         const long jb = ibase + (long)k * 128;
         tile_pass(a.src[jb + lane], a.src[jb + 64 + lane], F{}, ajx, ajy, ajz);
         flush();
@@ -136,7 +165,7 @@ __global__ __launch_bounds__(WGS, 1) void sym_force(SymArgs a) {
 #pragma unroll
     for (int k = 0; k < R; ++k) lds[0][k * WGS + t] = lds[1][k * WGS + t] = lds[2][k * WGS + t] = 0.f;
     __syncthreads();
-    for (int r = 1; r <= rounds; ++r) {
+    for (int r = 1 + chunk * rounds / C; r <= (chunk + 1) * rounds / C; ++r) {
         const int J = (b + r) % B;
         const long jbase = (long)J * SB;
         for (int ph = 0; ph < NT; ++ph) {
@@ -159,15 +188,17 @@ __global__ __launch_bounds__(WGS, 1) void sym_force(SymArgs a) {
         }
         __syncthreads();
     }
+    float4* own = a.partial + (long)(chunk == 0 ? 0 : B / 2 + chunk) * a.n;  // chunk 0: slot 0, the others behind the rounds
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        a.partial[ibase + (long)(2 * p) * WGS + t] = make_float4(sx[p].x, sy[p].x, sz[p].x, 0.f);
-        a.partial[ibase + (long)(2 * p + 1) * WGS + t] = make_float4(sx[p].y, sy[p].y, sz[p].y, 0.f);
+        if (V == 2) { sx[p] = ax[p]; sy[p] = ay[p]; sz[p] = az[p]; }
+        own[ibase + (long)(2 * p) * WGS + t] = make_float4(sx[p].x, sy[p].x, sz[p].x, 0.f);
+        own[ibase + (long)(2 * p + 1) * WGS + t] = make_float4(sx[p].y, sy[p].y, sz[p].y, 0.f);
     }
 }
 
 // a[i] = sum of the slots that hold a contribution for body i (compensated)
-__global__ void sym_reduce(const float4* partial, float4* acc, long n, int B, int SB) {
+__global__ void sym_reduce(const float4* partial, float4* acc, long n, int B, int SB, int C) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int J = (int)(i / SB);
@@ -181,6 +212,10 @@ __global__ void sym_reduce(const float4* partial, float4* acc, long n, int B, in
         y = p.y - c.y; t = run.y + y; c.y = (t - run.y) - y; run.y = t;
         y = p.z - c.z; t = run.z + y; c.z = (t - run.z) - y; run.z = t;
     }
+    for (int k = 1; k < C; ++k) {  // own sums of the other chunks
+        const float4 p = partial[(long)(B / 2 + k) * n + i];
+        run.x += p.x; run.y += p.y; run.z += p.z;
+    }
     acc[i] = run;
 }
 
@@ -193,12 +228,12 @@ static inline uint64_t splitmix64(uint64_t x) {
 }
 static inline double u01(uint64_t i, int k) { return (double)(splitmix64(42 + 7 * i + (uint64_t)k) >> 11) * (1.0 / 9007199254740992.0); }
 
-template <int P, int WGS>
-static void run(long n, int reps) {
+template <int P, int WGS, int V>
+static void run(long n, int reps, int C) {
     constexpr int SB = WGS * 2 * P;
     if (n % SB) { fprintf(stderr, "n must be a multiple of %d\n", SB); exit(2); }
     const int B = (int)(n / SB);
-    const int nslots = B / 2 + 1;
+    const int nslots = B / 2 + 1 + C;
     std::vector<float4> h(n);
     const double G = 6.674e-11;
     for (long i = 0; i < n; ++i) {
@@ -217,9 +252,9 @@ static void run(long n, int reps) {
     float best = 1e30f, best_red = 0;
     for (int k = 0; k < reps; ++k) {
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL((sym_force<P, WGS>), dim3(B), dim3(WGS), 0, 0, a);
+        hipLaunchKernelGGL((sym_force<P, WGS, V>), dim3(B * C), dim3(WGS), 0, 0, a);
         CK(hipEventRecord(e1));
-        hipLaunchKernelGGL(sym_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, partial, acc, n, B, SB);
+        hipLaunchKernelGGL(sym_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, partial, acc, n, B, SB, C);
         CK(hipEventRecord(e2));
         CK(hipEventSynchronize(e2));
         float ms = 0, ms2 = 0;
@@ -229,8 +264,8 @@ static void run(long n, int reps) {
         printf("  rep %d: force %.3f ms, reduce %.3f ms\n", k, ms, ms2);
     }
     const double pairs = (double)n * (double)(n - 1);
-    printf("P=%d WGS=%d SB=%d B=%d slots=%d (workspace %.2f GB): force %.3f ms + reduce %.3f ms -> %.4e pairs/s = %.3f of 157.3 TF at 20 flop/pair\n",
-           P, WGS, SB, B, nslots, (double)nslots * n * 16 / 1e9, best, best_red, pairs / ((best + best_red) * 1e-3),
+    printf("V=%d C=%d P=%d WGS=%d SB=%d B=%d slots=%d (workspace %.2f GB): force %.3f ms + reduce %.3f ms -> %.4e pairs/s = %.3f of 157.3 TF at 20 flop/pair\n",
+           V, C, P, WGS, SB, B, nslots, (double)nslots * n * 16 / 1e9, best, best_red, pairs / ((best + best_red) * 1e-3),
            pairs * 20 / ((best + best_red) * 1e-3) / 157.3e12);
     // check 16 rows against fp64 on the host
     std::vector<float4> out(n);
@@ -259,11 +294,16 @@ int main(int argc, char** argv) {
     const int reps = argc > 2 ? atoi(argv[2]) : 3;
     const int P = argc > 3 ? atoi(argv[3]) : 4;
     const int wgs = argc > 4 ? atoi(argv[4]) : 512;
-    if (P == 4 && wgs == 512) run<4, 512>(n, reps);
-    else if (P == 4 && wgs == 256) run<4, 256>(n, reps);
-    else if (P == 2 && wgs == 512) run<2, 512>(n, reps);
-    else if (P == 2 && wgs == 1024) run<2, 1024>(n, reps);
-    else if (P == 4 && wgs == 1024) run<4, 1024>(n, reps);
-    else { fprintf(stderr, "unsupported P/WGS\n"); return 2; }
+    const int V = argc > 5 ? atoi(argv[5]) : 0;
+    const int C = argc > 6 ? atoi(argv[6]) : 1;
+    if (P == 4 && wgs == 512 && V == 0) run<4, 512, 0>(n, reps, C);
+    else if (P == 4 && wgs == 512 && V == 1) run<4, 512, 1>(n, reps, C);
+    else if (P == 4 && wgs == 512 && V == 2) run<4, 512, 2>(n, reps, C);
+    else if (P == 4 && wgs == 512 && V == 3) run<4, 512, 3>(n, reps, C);
+    else if (P == 4 && wgs == 512 && V == 4) run<4, 512, 4>(n, reps, C);
+    else if (P == 4 && wgs == 256 && V == 0) run<4, 256, 0>(n, reps, C);
+    else if (P == 2 && wgs == 512 && V == 0) run<2, 512, 0>(n, reps, C);
+    else if (P == 2 && wgs == 1024 && V == 0) run<2, 1024, 0>(n, reps, C);
+    else { fprintf(stderr, "unsupported P/WGS/V\n"); return 2; }
     return 0;
 }

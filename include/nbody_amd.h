@@ -276,9 +276,25 @@ int nb_plan_f32(const nb_launch_f32* a, int* targets_per_lane, int* j_split, int
 /* workspace size that allows source slicing for n_tgt targets: 18 records per target (2 + 16 slots) */
 int64_t nb_workspace_bytes_f32(int64_t n_tgt, int acc64);
 /* workspace size that lets a whole-system launch of n bodies use K1s (source_path 3): one float4 record per body and
- * superblock round, n/8192 + 1 records per body — 2.2 GB at n = 2^20, 34 GB at 2^22; 0 = K1s does not apply to this n
+ * superblock round plus one (two with acc64) per workgroup of a superblock — n/8192 + 8 records per body: 2.3 GB at
+ * n = 2^20, 34 GB at 2^22; 0 = K1s does not apply to this n
  * (fewer than 262144 bodies, or more than 40 GiB of slots) */
 int64_t nb_workspace_bytes_sym_f32(int64_t n, int acc64);
+
+/* ---- K1s over several GPUs, for hosts that own the collectives themselves (one process per GPU: nbody_amd.distributed).
+ * The GPUs share the UNORDERED pairs of the system: rank r = tgt_off / n_tgt of P = n_src / n_tgt takes the 4096-body
+ * superblocks of its shard against the half of the system behind each.  Needs whole superblocks per shard
+ * (n_src % (P * 4096) == 0) and n_src >= 262144: nb_workspace_bytes_shared_pairs_f32 answers 0 otherwise (use the ordered
+ * launches above).  Per step and rank:
+ *   nb_launch_pair_forces_f32   a->acc = float4[n_src] (double4 with acc64): this rank's partial force on ALL bodies
+ *   reduce-scatter (sum) of a->acc over the ranks -> the force on the rank's own shard
+ *   nb_launch_kick_drift_f32    a->acc = that force as float4[parts][n_tgt] (double4 with acc64), the pieces added in order
+ *                               (1 after a reduce-scatter; P when the host gathered the ranks' pieces itself); kick + drift
+ *                               of [tgt_off, tgt_off + n_tgt) into a->out / a->vel (pos64 / vel64), as nb_launch_step_f32 does
+ *   all-gather of the positions, as with the ordered launches */
+int nb_launch_pair_forces_f32(const nb_launch_f32* a, void* hip_stream);
+int nb_launch_kick_drift_f32(const nb_launch_f32* a, int parts, void* hip_stream);
+int64_t nb_workspace_bytes_shared_pairs_f32(int64_t n_src, int ranks, int acc64);
 
 /* ---- index-sharded multi-GPU stepping: ONE process, P GPUs of a node, RCCL over xGMI (csrc/nbody_sharded.cpp) ----
  * The reference's only multi-GPU use is task parallelism (hw5.cu:564-567,587-588); this is the data-parallel scheme of
@@ -296,6 +312,12 @@ typedef struct nb_sharded nb_sharded;
                                 ncclAllGather.  The only exchange that accepts an ordinal more than once in `devices` — ranks
                                 sharing a GPU, each with its own streams and arrays — which is how a one-GPU box executes the
                                 P > 1 host logic (tests/test_gpu_sharded_native.py) */
+#define NB_SHARDED_ORDERED_PAIRS 4 /* every GPU evaluates every ordered pair of its targets (kernel K1) even where the default
+                                applies: when every shard is a whole number of 4096-body superblocks, n >= 262144 and the step is
+                                not overlapped, the GPUs share the UNORDERED pairs of the system instead (kernel K1s: GPU r takes
+                                the superblocks of its shard against the half of the system behind each), which leaves every GPU
+                                with a partial force on all n bodies — one reduce-scatter per step (ncclReduceScatter, or peer
+                                copies + an ordered sum with NB_SHARDED_COPY_EXCHANGE) in front of the kick-drift and the all-gather */
 int nb_sharded_create(nb_sharded** out, const int* devices, int n_devices, int64_t n, int precision, double G,
                       double eps, double dt, int flags);
 int nb_sharded_destroy(nb_sharded* s);
@@ -315,6 +337,8 @@ int nb_sharded_step_profiled(nb_sharded* s, int count, double* wall_ms_per_step,
 /* shard size and the launch plan each GPU uses for a whole step (any pointer may be NULL) */
 int nb_sharded_info(const nb_sharded* s, int* n_devices, int64_t* targets_per_device, int* targets_per_lane,
                     int* j_split, int* wg_size);
+/* symbol name of the force kernel a rank's step launches (for matching rocprofv3 rows, like nb_kernel_name_f32) */
+const char* nb_sharded_kernel_name(const nb_sharded* s);
 /* who rank `rank` is: which GPU it drives (ordinal, PCI bus id, UUID, name), which targets it owns, and what its exchange
  * is — for RCCL straight from the rank's communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice), so that
  * "the collective ran over N ranks on N distinct GPUs" is a fact read back from RCCL, not an echo of the arguments */

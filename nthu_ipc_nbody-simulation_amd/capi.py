@@ -99,6 +99,9 @@ SYMBOLS = {
     "nb_plan_f32": (C.c_int, [C.POINTER(NbLaunchF32), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "nb_workspace_bytes_f32": (C.c_int64, [C.c_int64, C.c_int]),
     "nb_workspace_bytes_sym_f32": (C.c_int64, [C.c_int64, C.c_int]),
+    "nb_launch_pair_forces_f32": (C.c_int, [C.POINTER(NbLaunchF32), C.c_void_p]),
+    "nb_launch_kick_drift_f32": (C.c_int, [C.POINTER(NbLaunchF32), C.c_int, C.c_void_p]),
+    "nb_workspace_bytes_shared_pairs_f32": (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
     "nb_sharded_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int64, C.c_int, C.c_double,
                                    C.c_double, C.c_double, C.c_int]),
     "nb_sharded_destroy": (C.c_int, [C.c_void_p]),
@@ -111,6 +114,7 @@ SYMBOLS = {
     "nb_sharded_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int),
                                  C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "nb_sharded_rank_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(NbShardedRank)]),
+    "nb_sharded_kernel_name": (C.c_char_p, [C.c_void_p]),
 }
 # include/nbody_amd_debug.h: exported by the instrumented build (libnbody_amd_stamps.so) only
 DEBUG_SYMBOLS = {
@@ -123,6 +127,7 @@ NB_SHARDED_OVERLAP = 1
 NB_CU_ALL, NB_CU_LOW, NB_CU_HIGH, NB_CU_EVEN, NB_CU_ODD = 0, 1, 2, 3, 4
 NB_HANDOFF_AUTO, NB_HANDOFF_HOST_STAGED = 0, 1
 NB_SHARDED_COPY_EXCHANGE = 2
+NB_SHARDED_ORDERED_PAIRS = 4
 
 
 class NBodyError(RuntimeError):
@@ -446,14 +451,15 @@ class Sharded:
     engines — the form that lets several ranks share one GPU)."""
 
     def __init__(self, n, devices=(0,), precision=NB_F32, G=6.674e-11, eps=1e-3, dt=60.0, overlap=False,
-                 exchange="rccl"):
+                 exchange="rccl", ordered_pairs=False):
         if exchange not in ("rccl", "copy"):
             raise ValueError("exchange must be 'rccl' or 'copy'")
         self.n = n
         self.devices = list(devices)
         self._h = C.c_void_p()
         devs = (C.c_int * len(devices))(*devices)
-        flags = (NB_SHARDED_OVERLAP if overlap else 0) | (NB_SHARDED_COPY_EXCHANGE if exchange == "copy" else 0)
+        flags = (NB_SHARDED_OVERLAP if overlap else 0) | (NB_SHARDED_COPY_EXCHANGE if exchange == "copy" else 0) | \
+            (NB_SHARDED_ORDERED_PAIRS if ordered_pairs else 0)
         rc = lib().nb_sharded_create(C.byref(self._h), devs, len(devices), n, precision, G, eps, dt, flags)
         if rc != NB_OK:
             h, self._h = self._h, C.c_void_p()
@@ -516,6 +522,9 @@ class Sharded:
                     comm_ranks=r.comm_ranks, comm_rank=r.comm_rank, comm_device=r.comm_device,
                     pci_bus_id=r.pci_bus_id.decode(), uuid=r.uuid.decode(), name=r.name.decode())
 
+    def kernel_name(self):
+        return lib().nb_sharded_kernel_name(self._h).decode()
+
     def info(self):
         p, per, r, j, w = C.c_int(), C.c_int64(), C.c_int(), C.c_int(), C.c_int()
         self._check(lib().nb_sharded_info(self._h, C.byref(p), C.byref(per), C.byref(r), C.byref(j), C.byref(w)),
@@ -540,6 +549,26 @@ def launch_f32(src_ptr, out_ptr, n_src, tgt_off, n_tgt, eps2, dt, stream, accel_
     a = _launch_struct(src_ptr, out_ptr, n_src, tgt_off, n_tgt, eps2, dt, **kw)
     f = lib().nb_launch_accel_f32 if accel_only else lib().nb_launch_step_f32
     _check(f(C.byref(a), C.c_void_p(stream)), "nb_launch_accel_f32" if accel_only else "nb_launch_step_f32")
+
+
+def launch_pair_forces_f32(src_ptr, n_src, tgt_off, n_tgt, eps2, stream, acc_ptr, workspace_ptr, workspace_bytes, acc64=False):
+    """Several GPUs sharing the unordered pairs: this rank's partial force on ALL n_src bodies -> acc (float4 / double4)."""
+    a = _launch_struct(src_ptr, 0, n_src, tgt_off, n_tgt, eps2, 0.0, acc_ptr=acc_ptr, acc64=acc64,
+                       workspace_ptr=workspace_ptr, workspace_bytes=workspace_bytes)
+    _check(lib().nb_launch_pair_forces_f32(C.byref(a), C.c_void_p(stream)), "nb_launch_pair_forces_f32")
+
+
+def launch_kick_drift_f32(src_ptr, out_ptr, n_src, tgt_off, n_tgt, dt, stream, acc_ptr, parts=1, vel_ptr=0, pos64_ptr=0,
+                          vel64_ptr=0, acc64=False):
+    """Kick + drift of the rank's shard from the summed force acc[parts][n_tgt]."""
+    a = _launch_struct(src_ptr, out_ptr, n_src, tgt_off, n_tgt, 1.0, dt, vel_ptr=vel_ptr, pos64_ptr=pos64_ptr,
+                       vel64_ptr=vel64_ptr, acc_ptr=acc_ptr, acc64=acc64)
+    _check(lib().nb_launch_kick_drift_f32(C.byref(a), parts, C.c_void_p(stream)), "nb_launch_kick_drift_f32")
+
+
+def workspace_bytes_shared_pairs_f32(n_src, ranks, acc64=False):
+    """Workspace of nb_launch_pair_forces_f32; 0 = the ranks cannot share the unordered pairs of this system."""
+    return lib().nb_workspace_bytes_shared_pairs_f32(n_src, ranks, int(acc64))
 
 
 def plan_f32(n_src, n_tgt, acc64=False, targets_per_lane=0, j_split=0, workspace_bytes=0, source_path=0, wg_size=0):

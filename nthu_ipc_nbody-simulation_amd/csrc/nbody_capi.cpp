@@ -662,11 +662,54 @@ int nb_plan_f32(const nb_launch_f32* a, int* targets_per_lane, int* j_split, int
     return NB_OK;
 }
 
+// ---- several GPUs sharing the unordered pairs of one system (hosts that own the collectives: nbody_amd.distributed)
+static bool shared_pairs_shape(const nb_launch_f32* a, F32SymShape* sh) {
+    if (!a || a->n_tgt <= 0 || a->n_src <= 0 || a->n_src % a->n_tgt || a->tgt_off % a->n_tgt) return false;
+    const int P = (int)(a->n_src / a->n_tgt), rank = (int)(a->tgt_off / a->n_tgt);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (rank >= P || !sym_sharded_ok(a->n_src, P, cus, a->acc64 != 0, sh)) return false;
+    sh->b0 = rank * sh->nb;
+    return true;
+}
+
+int nb_launch_pair_forces_f32(const nb_launch_f32* a, void* hip_stream) {
+    F32SymShape sh{};
+    if (!a || !a->src || !a->acc || !a->workspace || !(a->eps2 > 0.f) || a->tgt || a->phase != NB_PHASE_WHOLE || a->src_begin ||
+        a->src_end || !shared_pairs_shape(a, &sh))
+        return set_error(NB_ERR_INVALID, "nb_launch_pair_forces_f32: the shard must be whole 4096-body superblocks of a system of "
+                         ">= 262144 bodies (n_src = ranks * n_tgt, tgt_off = rank * n_tgt), with acc and a workspace");
+    if ((size_t)a->workspace_bytes < sym_workspace_bytes(sh, a->acc64 != 0))
+        return set_error(NB_ERR_INVALID, "nb_launch_pair_forces_f32: workspace smaller than nb_workspace_bytes_shared_pairs_f32");
+    hipError_t e = (hipError_t)launch_f32_sym(to_args(a), sh, a->acc64 != 0, 2, (hipStream_t)hip_stream);
+    return e == hipSuccess ? NB_OK : fail_hip(nullptr, e, "nb_launch_pair_forces_f32");
+}
+
+int nb_launch_kick_drift_f32(const nb_launch_f32* a, int parts, void* hip_stream) {
+    if (!a || !a->src || !a->out || !a->acc || a->n_tgt <= 0 || a->tgt_off < 0 || a->tgt_off + a->n_tgt > a->n_src || parts < 1 ||
+        (a->acc64 ? (!a->pos64 || !a->vel64) : !a->vel))
+        return NB_ERR_INVALID;
+    hipError_t e = (hipError_t)launch_kick_drift_f32(to_args(a), a->acc64 != 0, parts, (hipStream_t)hip_stream);
+    return e == hipSuccess ? NB_OK : fail_hip(nullptr, e, "nb_launch_kick_drift_f32");
+}
+
+int64_t nb_workspace_bytes_shared_pairs_f32(int64_t n_src, int ranks, int acc64) {
+    if (ranks < 2 || n_src <= 0 || n_src % ranks) return 0;
+    nb_launch_f32 a{};
+    a.n_src = n_src;
+    a.n_tgt = n_src / ranks;
+    a.acc64 = acc64;
+    F32SymShape sh{};
+    return shared_pairs_shape(&a, &sh) ? (int64_t)sym_workspace_bytes(sh, acc64 != 0) : 0;
+}
+
 int64_t nb_workspace_bytes_sym_f32(int64_t n, int acc64) {
     if (n < SYM_MIN_N) return 0;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const size_t b = sym_workspace_bytes(sym_shape(n, cus), acc64 != 0);
+    F32SymShape sh = sym_shape(n, cus);
+    sh.chunks = std::max(sh.chunks, 8);  // room for up to 8 workgroups per superblock (j_split with source_path 3)
+    const size_t b = sym_workspace_bytes(sh, acc64 != 0);
     return b <= SYM_MAX_WORKSPACE ? (int64_t)b : 0;
 }
 

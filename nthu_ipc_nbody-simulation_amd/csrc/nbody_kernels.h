@@ -68,8 +68,11 @@ size_t sym_workspace_bytes(const F32SymShape& s, bool acc64);
 // mode 0: force + kick-drift of the whole system; 1: accelerations out; 2: this launch's partial force out (a.acc:
 // float4[n] / double4[n]) for the reduce-scatter of a multi-GPU step.  a.partial = the slot workspace.
 int launch_f32_sym(const F32Args& a, const F32SymShape& s, bool acc64, int mode, hipStream_t stream);  // hipError_t
-// kick-drift of targets [tgt_off, tgt_off + n_tgt) from finished accelerations a.acc[n_tgt]
-int launch_kick_drift_f32(const F32Args& a, bool acc64, hipStream_t stream);
+// kick-drift of targets [tgt_off, tgt_off + n_tgt) from accelerations arriving as a.acc[parts][n_tgt], added in order
+int launch_kick_drift_f32(const F32Args& a, bool acc64, int parts, hipStream_t stream);
+// several GPUs sharing the pairs of one system: every GPU owns whole superblocks (n % (P * SYM_SB) == 0), n >= SYM_MIN_N,
+// slot workspace within SYM_MAX_WORKSPACE; *shape_of_rank0 = the launch shape of rank 0 (rank r: b0 = r * nb)
+bool sym_sharded_ok(long n, int P, int n_cus, bool acc64, F32SymShape* shape_of_rank0);
 
 struct F32Plan {
     int targets_per_lane = 4;  // 2, 4 or 8 (one, two or four packed pairs per lane)

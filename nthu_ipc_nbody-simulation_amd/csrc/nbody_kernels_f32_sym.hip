@@ -266,19 +266,31 @@ __global__ __launch_bounds__(WG) void nbody_reduce_sym_f32(F32Args a, F32SymShap
     else finish_target<false, MODE == 1>(a, i, rx, ry, rz, me.x, me.y, me.z, me.w);
 }
 
-// kick-drift of targets [tgt_off, tgt_off + n_tgt) from finished accelerations a.acc[n_tgt] (float4, or double4 with
-// ACC64) — the epilogue of a step whose forces came out of a reduce-scatter over several GPUs
+// kick-drift of targets [tgt_off, tgt_off + n_tgt) from accelerations that arrive in `parts` pieces — a.acc[parts][n_tgt]
+// (float4, or double4 with ACC64), added in index order: one piece after an RCCL reduce-scatter, one per GPU when the host
+// gathered the GPUs' partial forces with peer copies.  The epilogue of a step whose pairs were shared by several GPUs.
 template <bool ACC64>
-__global__ __launch_bounds__(WG) void nbody_kick_drift_f32(F32Args a) {
+__global__ __launch_bounds__(WG) void nbody_kick_drift_f32(F32Args a, int parts) {
     const long i = (long)blockIdx.x * WG + threadIdx.x;
     if (i >= a.n_tgt) return;
     const float4 me = a.src[a.tgt_off + i];
     if (ACC64) {
-        const double4 f = ((const double4*)a.acc)[i];
-        finish_target<true, false>(a, i, f.x, f.y, f.z, me.x, me.y, me.z, me.w);
+        double x = 0, y = 0, z = 0;
+        for (int q = 0; q < parts; ++q) {
+            const double4 f = ((const double4*)a.acc)[(long)q * a.n_tgt + i];
+            x += f.x; y += f.y; z += f.z;
+        }
+        finish_target<true, false>(a, i, x, y, z, me.x, me.y, me.z, me.w);
     } else {
-        const float4 f = ((const float4*)a.acc)[i];
-        finish_target<false, false>(a, i, f.x, f.y, f.z, me.x, me.y, me.z, me.w);
+        float rx = 0, ry = 0, rz = 0, kx = 0, ky = 0, kz = 0;  // Kahan, like every other second-level sum of the fp32 mode
+        for (int q = 0; q < parts; ++q) {
+            const float4 f = ((const float4*)a.acc)[(long)q * a.n_tgt + i];
+            float u, v;
+            u = f.x - kx; v = rx + u; kx = (v - rx) - u; rx = v;
+            u = f.y - ky; v = ry + u; ky = (v - ry) - u; ry = v;
+            u = f.z - kz; v = rz + u; kz = (v - rz) - u; rz = v;
+        }
+        finish_target<false, false>(a, i, rx, ry, rz, me.x, me.y, me.z, me.w);
     }
 }
 
@@ -338,12 +350,22 @@ int launch_f32_sym(const F32Args& a0, const F32SymShape& sh, bool acc64, int mod
     return (int)hipGetLastError();
 }
 
-int launch_kick_drift_f32(const F32Args& a, bool acc64, hipStream_t stream) {
-    if (!a.src || !a.out || !a.acc || a.n_tgt <= 0) return (int)hipErrorInvalidValue;
+int launch_kick_drift_f32(const F32Args& a, bool acc64, int parts, hipStream_t stream) {
+    if (!a.src || !a.out || !a.acc || a.n_tgt <= 0 || parts < 1) return (int)hipErrorInvalidValue;
     const unsigned rb = (unsigned)((a.n_tgt + WG - 1) / WG);
-    if (acc64) hipLaunchKernelGGL(nbody_kick_drift_f32<true>, dim3(rb), dim3(WG), 0, stream, a);
-    else hipLaunchKernelGGL(nbody_kick_drift_f32<false>, dim3(rb), dim3(WG), 0, stream, a);
+    if (acc64) hipLaunchKernelGGL(nbody_kick_drift_f32<true>, dim3(rb), dim3(WG), 0, stream, a, parts);
+    else hipLaunchKernelGGL(nbody_kick_drift_f32<false>, dim3(rb), dim3(WG), 0, stream, a, parts);
     return (int)hipGetLastError();
+}
+
+// do `n` bodies split over `P` GPUs by index let every GPU own whole superblocks, and is the slot workspace affordable?
+bool sym_sharded_ok(long n, int P, int n_cus, bool acc64, F32SymShape* shape_of_rank0) {
+    if (P < 2 || n < SYM_MIN_N || n % ((long)P * SYM_SB)) return false;
+    const int B = (int)(n / SYM_SB);
+    const F32SymShape s = sym_shape(n, n_cus, 0, B / P, 0);
+    if (sym_workspace_bytes(s, acc64) > SYM_MAX_WORKSPACE) return false;
+    if (shape_of_rank0) *shape_of_rank0 = s;
+    return true;
 }
 
 }  // namespace nbk

@@ -45,6 +45,7 @@ struct RcclApi {
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclReduceScatter) ReduceScatter = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
@@ -67,6 +68,7 @@ const RcclApi* rccl(char* err, size_t errlen) {
             api.CommInitAll = (decltype(api.CommInitAll))dlsym(api.handle, "ncclCommInitAll");
             api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.handle, "ncclCommDestroy");
             api.AllGather = (decltype(api.AllGather))dlsym(api.handle, "ncclAllGather");
+            api.ReduceScatter = (decltype(api.ReduceScatter))dlsym(api.handle, "ncclReduceScatter");
             api.GroupStart = (decltype(api.GroupStart))dlsym(api.handle, "ncclGroupStart");
             api.GroupEnd = (decltype(api.GroupEnd))dlsym(api.handle, "ncclGroupEnd");
             api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.handle, "ncclGetErrorString");
@@ -75,7 +77,7 @@ const RcclApi* rccl(char* err, size_t errlen) {
             api.CommCuDevice = (decltype(api.CommCuDevice))dlsym(api.handle, "ncclCommCuDevice");
         }
     }
-    if (!api.handle || !api.CommInitAll || !api.CommDestroy || !api.AllGather || !api.GroupStart || !api.GroupEnd ||
+    if (!api.handle || !api.CommInitAll || !api.CommDestroy || !api.AllGather || !api.ReduceScatter || !api.GroupStart || !api.GroupEnd ||
         !api.GetErrorString || !api.CommCount || !api.CommUserRank || !api.CommCuDevice) {
         snprintf(err, errlen, "cannot load RCCL (librccl.so.1): %s", api.handle ? "missing symbol" : dlerror());
         return nullptr;
@@ -95,6 +97,11 @@ struct Rank {
     void* ws = nullptr;
     int ws_slots = 0;  // partial-sum slots of `ws` (>= 16; up to 64 when the plan cuts the sources into that many slices)
     size_t ws_bytes = 0;
+    // symmetric step (K1s, several GPUs share the pairs): this GPU's partial force on ALL n bodies, and the pieces of the
+    // force on its own shard as they arrive from the reduce-scatter (one piece) or from the peers' copies (P pieces)
+    void* fpart = nullptr;
+    void* facc = nullptr;
+    hipEvent_t forced = nullptr;  // copy exchange: fpart is complete
     ncclComm_t comm = nullptr;
 };
 
@@ -110,6 +117,8 @@ struct nb_sharded {
     int cur = 0;
     bool have_state = false;
     bool gather_pending = false;  // overlap: the all-gather of pos[cur] is still in flight on the comm streams
+    bool sym = false;    // every unordered pair once: K1s on every GPU + a reduce-scatter of the partial forces per step
+    F32SymShape shape{};  // of rank 0 (rank r: b0 = r * nb)
     bool ready = false;  // creation went through: streams, buffers and (RCCL) communicators exist
     const RcclApi* api = nullptr;  // null with NB_SHARDED_COPY_EXCHANGE
     char err[512] = {0};
@@ -138,6 +147,7 @@ int fail(nb_sharded* s, int code, const char* what, const char* detail) {
 bool acc64(const nb_sharded* s) { return s->precision == NB_F32_ACC64; }
 bool overlapped(const nb_sharded* s) { return (s->flags & NB_SHARDED_OVERLAP) && s->P > 1; }
 bool copy_exchange(const nb_sharded* s) { return (s->flags & NB_SHARDED_COPY_EXCHANGE) != 0; }
+size_t force_rec(const nb_sharded* s) { return acc64(s) ? sizeof(double4) : sizeof(float4); }
 
 // slots of the source-slice workspace: the documented minimum of 16, or as many as the whole-step plan has slices (up to
 // 64) so that a step is ONE force launch + ONE reducer per phase instead of js/16 of each — N = 2^20 over 8 ranks
@@ -173,7 +183,8 @@ int launch_phase(nb_sharded* s, Rank& k, int64_t src_begin, int64_t src_end, int
     const long cover = (src_begin || src_end) ? (long)(src_end - src_begin) : (long)s->n;
     F32Plan plan = plan_f32(s->per, cover > 0 ? cover : 1, k.n_cus, 0, 0, k.ws != nullptr);
     // one GPU holds the whole system: the symmetric kernel K1s, exactly as nb_step picks it
-    if (s->P == 1) (void)plan_symmetric(plan, s->per, s->n, phase == F32_PHASE_WHOLE, k.ws_bytes, acc64(s), k.n_cus, 0, 0);
+    if (s->P == 1 && !(s->flags & NB_SHARDED_ORDERED_PAIRS))
+        (void)plan_symmetric(plan, s->per, s->n, phase == F32_PHASE_WHOLE, k.ws_bytes, acc64(s), k.n_cus, 0, 0);
     SH_HIP(s, (hipError_t)launch_f32(a, plan, acc64(s), false, k.stream));
     return NB_OK;
 }
@@ -236,6 +247,83 @@ int exchange_copy(nb_sharded* s, int nxt, bool ov) {
     return NB_OK;
 }
 
+// ---- symmetric step: the unordered pairs of the whole system are shared by the GPUs (GPU r owns the I-superblocks of its
+// shard and meets the B/2 superblocks behind each of them, K1s); every GPU ends up with a partial force on ALL n bodies;
+// a reduce-scatter hands every shard the sum; the owner kicks and drifts; then the all-gather of positions as always.
+int launch_rank_sym(nb_sharded* s, Rank& k, int r) {
+    F32Args a{};
+    a.src = k.pos[s->cur];
+    a.partial = k.ws;
+    a.acc = k.fpart;
+    a.n_src = s->n;
+    a.tgt_off = k.lo;
+    a.n_tgt = s->per;
+    a.eps2 = (float)(s->eps * s->eps);
+    F32SymShape sh = s->shape;
+    sh.b0 = r * sh.nb;
+    SH_HIP(s, (hipError_t)launch_f32_sym(a, sh, acc64(s), 2, k.stream));
+    return NB_OK;
+}
+
+int kick_drift_rank(nb_sharded* s, Rank& k, int parts) {
+    F32Args a{};
+    a.src = k.pos[s->cur];
+    a.out = k.pos[s->cur ^ 1];
+    a.vel = k.vel;
+    a.pos64 = k.pos64;
+    a.vel64 = k.vel64;
+    a.acc = k.facc;
+    a.n_src = s->n;
+    a.tgt_off = k.lo;
+    a.n_tgt = s->per;
+    a.dt = (float)s->dt;
+    SH_HIP(s, (hipError_t)launch_kick_drift_f32(a, acc64(s), parts, k.stream));
+    return NB_OK;
+}
+
+// the partial forces of all GPUs -> the force on every GPU's own shard
+int exchange_forces(nb_sharded* s) {
+    const size_t rec = force_rec(s);
+    if (!copy_exchange(s)) {
+        SH_NCCL(s, s->api->GroupStart());
+        for (Rank& k : s->rank) {
+            ncclResult_t r = s->api->ReduceScatter(k.fpart, k.facc, (size_t)(4 * s->per), acc64(s) ? ncclDouble : ncclFloat,
+                                                   ncclSum, k.comm, k.stream);
+            if (r != ncclSuccess) {
+                (void)s->api->GroupEnd();
+                return fail(s, NB_ERR_HIP, "ncclReduceScatter", s->api->GetErrorString(r));
+            }
+        }
+        SH_NCCL(s, s->api->GroupEnd());
+        for (Rank& k : s->rank) {
+            SH_HIP(s, hipSetDevice(k.device));
+            if (int rc = kick_drift_rank(s, k, 1)) return rc;
+        }
+        return NB_OK;
+    }
+    // copy engines: destination q pulls its shard of every GPU's partial force (its own included) into P pieces, which the
+    // kick-drift kernel adds in rank order.  fpart of rank r is rewritten by r's next force reducer, which r's stream reaches
+    // only behind the position exchange that waits for q's `stepped` — recorded after these copies.
+    for (Rank& k : s->rank) {
+        SH_HIP(s, hipSetDevice(k.device));
+        SH_HIP(s, hipEventRecord(k.forced, k.stream));
+    }
+    const size_t bytes = (size_t)s->per * rec;
+    for (Rank& q : s->rank) {
+        SH_HIP(s, hipSetDevice(q.device));
+        for (size_t r = 0; r < s->rank.size(); ++r) {
+            Rank& src = s->rank[r];
+            if (&src != &q) SH_HIP(s, hipStreamWaitEvent(q.stream, src.forced, 0));
+            char* dst = (char*)q.facc + r * bytes;
+            const char* from = (const char*)src.fpart + (size_t)q.lo * rec;
+            if (src.device == q.device) SH_HIP(s, hipMemcpyAsync(dst, from, bytes, hipMemcpyDeviceToDevice, q.stream));
+            else SH_HIP(s, hipMemcpyPeerAsync(dst, q.device, from, src.device, bytes, q.stream));
+        }
+        if (int rc = kick_drift_rank(s, q, s->P)) return rc;
+    }
+    return NB_OK;
+}
+
 // nb_sharded_step_profiled: per rank one pair of timing events around the launch sequence of every step
 struct StepEvents {
     std::vector<std::vector<hipEvent_t>> begin, end;  // [rank][step]
@@ -261,9 +349,11 @@ int step_once(nb_sharded* s, StepEvents* ev = nullptr, size_t step = 0) {
         Rank& k = s->rank[r];
         SH_HIP(s, hipSetDevice(k.device));
         if (ev) SH_HIP(s, hipEventRecord(ev->begin[r][step], k.stream));
-        if (int rc = launch_rank(s, k, ov)) return rc;
+        if (int rc = s->sym ? launch_rank_sym(s, k, (int)r) : launch_rank(s, k, ov)) return rc;
         if (ev) SH_HIP(s, hipEventRecord(ev->end[r][step], k.stream));
     }
+    if (s->sym)
+        if (int rc = exchange_forces(s)) return rc;
     // exchange: every GPU contributes its own slot of the array its kernels have just written
     const int nxt = s->cur ^ 1;
     if (int rc = copy_exchange(s) ? exchange_copy(s, nxt, ov) : exchange_rccl(s, nxt, ov)) return rc;
@@ -288,8 +378,9 @@ void release(nb_sharded* s) {
         if (k.stream) (void)hipStreamSynchronize(k.stream);
         if (k.comm_stream) (void)hipStreamSynchronize(k.comm_stream);
         if (k.comm && s->api) (void)s->api->CommDestroy(k.comm);
-        for (void* p : {(void*)k.pos[0], (void*)k.pos[1], (void*)k.vel, (void*)k.pos64, (void*)k.vel64, k.ws})
+        for (void* p : {(void*)k.pos[0], (void*)k.pos[1], (void*)k.vel, (void*)k.pos64, (void*)k.vel64, k.ws, k.fpart, k.facc})
             if (p) (void)hipFree(p);
+        if (k.forced) (void)hipEventDestroy(k.forced);
         if (k.stepped) (void)hipEventDestroy(k.stepped);
         if (k.gathered) (void)hipEventDestroy(k.gathered);
         if (k.stream) (void)hipStreamDestroy(k.stream);
@@ -333,6 +424,12 @@ int create_impl(nb_sharded** out, const int* devices, int n_devices, int64_t n, 
     }
     s->rank.resize((size_t)n_devices);
     const size_t N = (size_t)n, per = (size_t)s->per;
+    {   // every unordered pair once when the shards are whole superblocks (and nobody asked for the ordered-pair kernel
+        // or the two-phase step, which cuts the sources of K1 into ranges)
+        int cus0 = 256;
+        if (hipDeviceGetAttribute(&cus0, hipDeviceAttributeMultiprocessorCount, devices[0]) != hipSuccess) cus0 = 256;
+        s->sym = !(flags & NB_SHARDED_ORDERED_PAIRS) && !overlapped(s) && sym_sharded_ok(n, n_devices, cus0, acc64(s), &s->shape);
+    }
     for (int r = 0; r < n_devices; ++r) {
         Rank& k = s->rank[(size_t)r];
         k.device = devices[r];
@@ -358,9 +455,15 @@ int create_impl(nb_sharded** out, const int* devices, int n_devices, int64_t n, 
             k.ws_slots = workspace_slots(s, k.n_cus);
             k.ws_bytes = (size_t)workspace_bytes(s, k.ws_slots);
         }
-        if (n_devices == 1 && n >= SYM_MIN_N) {  // room for K1s' pair slots (as nb_create)
+        if (n_devices == 1 && n >= SYM_MIN_N && !(flags & NB_SHARDED_ORDERED_PAIRS)) {  // room for K1s' pair slots (as nb_create)
             const size_t sym = sym_workspace_bytes(sym_shape(n, k.n_cus), acc64(s));
             if (sym <= SYM_MAX_WORKSPACE) k.ws_bytes = std::max(k.ws_bytes, sym);
+        }
+        if (s->sym) {
+            k.ws_bytes = std::max(k.ws_bytes, sym_workspace_bytes(s->shape, acc64(s)));
+            SH_HIP(s, hipMalloc(&k.fpart, N * force_rec(s)));
+            SH_HIP(s, hipMalloc(&k.facc, (copy_exchange(s) ? (size_t)n_devices : 1) * per * force_rec(s)));
+            if (copy_exchange(s)) SH_HIP(s, hipEventCreateWithFlags(&k.forced, hipEventDisableTiming));
         }
         if (k.ws_bytes) SH_HIP(s, hipMalloc(&k.ws, k.ws_bytes));
     }
@@ -607,12 +710,30 @@ int nb_sharded_rank_info(const nb_sharded* cs, int rank, nb_sharded_rank* out) {
     return NB_OK;
 }
 
+const char* nb_sharded_kernel_name(const nb_sharded* s) {
+    if (!s || s->rank.empty()) return "";
+    const Rank& k = s->rank[0];
+    F32Plan p = plan_f32(s->per, s->n, k.n_cus, 0, 0, k.ws != nullptr);
+    if (s->P == 1 && !(s->flags & NB_SHARDED_ORDERED_PAIRS))
+        (void)plan_symmetric(p, s->per, s->n, true, k.ws_bytes, acc64(s), k.n_cus, 0, 0);
+    if (s->sym) p.symmetric = true;
+    return kernel_name_f32(p, acc64(s), false);
+}
+
 int nb_sharded_info(const nb_sharded* s, int* n_devices, int64_t* targets_per_device, int* targets_per_lane, int* j_split,
                     int* wg_size) {
     if (!s || s->rank.empty()) return NB_ERR_INVALID;
     const Rank& k = s->rank[0];
     F32Plan p = plan_f32(s->per, s->n, k.n_cus, 0, 0, k.ws != nullptr);
-    if (s->P == 1) (void)plan_symmetric(p, s->per, s->n, true, k.ws_bytes, acc64(s), k.n_cus, 0, 0);
+    if (s->P == 1 && !(s->flags & NB_SHARDED_ORDERED_PAIRS))
+        (void)plan_symmetric(p, s->per, s->n, true, k.ws_bytes, acc64(s), k.n_cus, 0, 0);
+    if (s->sym) {
+        p.symmetric = true;
+        p.sym = s->shape;
+        p.targets_per_lane = 2 * SYM_P;
+        p.wg_size = SYM_WGS;
+        p.j_split = s->shape.chunks;
+    }
     if (n_devices) *n_devices = s->P;
     if (targets_per_device) *targets_per_device = s->per;
     if (targets_per_lane) *targets_per_lane = p.targets_per_lane;

@@ -23,6 +23,13 @@ on its way to rank r+1 — so the footprint is 4·N/P records instead of 2·N an
 288 GB per GPU the all-gather form never needs it at the BASELINE sizes (256 MiB at N = 2^24); it is here for systems
 whose positions do not fit twice on one device, parity-tested against the all-gather form.
 
+`shared_pairs` (default: on whenever it applies): the ranks share the UNORDERED pairs of the system instead — every pair is
+evaluated once, by the rank that owns the earlier of its two 4096-body superblocks (cyclically), with the symmetric kernel
+K1s (capi.launch_pair_forces_f32).  A rank then holds a partial force on ALL N bodies: per step ONE reduce-scatter (sum) of
+float4[N] hands every shard owner its total, the owner kicks and drifts (capi.launch_kick_drift_f32), and the all-gather of
+positions follows as before.  Needs whole superblocks per shard (N % (4096 P) == 0) and N >= 262144; K1s reaches ~0.79 of
+the fp32 peak per GPU where the ordered-pair kernel K1 reaches ~0.59.
+
 torch is used for device memory, the stream and the collective only; the arithmetic is the HIP kernel behind
 `capi.launch_f32`.  `compute` is injectable so the sharding/exchange logic can be exercised on CPU with gloo
 (tests/test_distributed_gloo.py passes the oracle there — test infrastructure, not a product fallback).
@@ -83,6 +90,8 @@ def hip_compute(acc64=False, targets_per_lane=0, j_split=0, source_path=0, wg_si
                         src_begin=src_range[0] if src_range else 0, src_end=src_range[1] if src_range else 0,
                         tgt_ptr=tgt.data_ptr() if tgt is not None else 0)
 
+    compute.is_hip_compute = True
+    compute.forced = bool(targets_per_lane or j_split or wg_size or source_path in (1, 2))  # asks for the ordered kernel K1
     return compute
 
 
@@ -102,7 +111,7 @@ class ShardedSystem:
     """N bodies sharded by index over the ranks of the default process group (or unsharded when world == 1)."""
 
     def __init__(self, n, pos_shard, vel_shard, eps, dt, device, compute=None, acc64=False, group=None, trace=False,
-                 exchange="in_place", overlap=False):
+                 exchange="in_place", overlap=False, shared_pairs=None):
         self.dist_on = dist.is_initialized()  # a one-rank group still runs the collective (tests the in-place call)
         self.world = dist.get_world_size(group) if self.dist_on else 1
         self.rank = dist.get_rank(group) if self.dist_on else 0
@@ -126,6 +135,17 @@ class ShardedSystem:
         self.trace = trace and torch.cuda.is_available()  # roctx ranges (torch.cuda.nvtx -> roctx on ROCm) for rocprofv3
         self.compute = compute or hip_compute(acc64)
         self.vel = vel_shard.to(device=device, dtype=torch.float32).contiguous()
+        # share the unordered pairs of the system among the ranks (K1s + reduce-scatter of partial forces)?  Default: yes
+        # where it applies — several ranks, the all-gather form, no two-phase step, the product's HIP compute (an injected
+        # `compute`, as the CPU tests use, keeps the ordered form), device tensors, whole superblocks per shard
+        can = (self.world > 1 and not self.ring and not self.overlap and torch.device(device).type == "cuda"
+               and (compute is None or (getattr(compute, "is_hip_compute", False) and not compute.forced))
+               and capi.workspace_bytes_shared_pairs_f32(n, self.world, acc64) > 0)
+        if shared_pairs and not can:
+            raise ValueError("shared_pairs needs >= 2 ranks, HIP tensors, the all-gather exchange without overlap, "
+                             "n % (4096 * world) == 0 and n >= 262144")
+        self.shared_pairs = can if shared_pairs is None else bool(shared_pairs)
+        self._fpart = self._facc = self._pair_ws = None
         if self.ring:
             if overlap:
                 raise ValueError("the ring pass overlaps every transfer by construction: overlap=True has no meaning")
@@ -227,6 +247,10 @@ class ShardedSystem:
                 self.kernel_events.append((e0, e1))
             return
         src, out = self.pos[self.cur], self.pos[self.cur ^ 1]
+        if self.shared_pairs:
+            self._step_shared_pairs(src, out)
+            self.cur ^= 1
+            return
         args = (src, out, self.vel, self.lo, self.n_tgt, self.eps2, self.dt, self.pos64, self.vel64)
         if self.trace:
             torch.cuda.nvtx.range_push("nbody.force_kick_drift")
@@ -257,6 +281,36 @@ class ShardedSystem:
         if self.trace:
             torch.cuda.nvtx.range_pop()
         self.cur ^= 1
+
+    def _step_shared_pairs(self, src, out):
+        """K1s on this rank's share of the unordered pairs -> partial force on all N bodies -> reduce-scatter -> kick-drift
+        of the own shard -> all-gather of the positions."""
+        dev, fdt = src.device, (torch.float64 if self.acc64 else torch.float32)
+        if self._fpart is None:
+            self._fpart = torch.empty((self.n, 4), dtype=fdt, device=dev)
+            self._facc = torch.empty((self.n_tgt, 4), dtype=fdt, device=dev)
+            self._pair_ws = torch.empty(capi.workspace_bytes_shared_pairs_f32(self.n, self.world, self.acc64),
+                                        dtype=torch.uint8, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        if self.kernel_events is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        capi.launch_pair_forces_f32(src.data_ptr(), self.n, self.lo, self.n_tgt, self.eps2, stream, self._fpart.data_ptr(),
+                                    self._pair_ws.data_ptr(), self._pair_ws.numel(), acc64=self.acc64)
+        if self.kernel_events is not None:
+            e1.record()
+            self.kernel_events.append((e0, e1))
+        if dist.get_backend(self.group) == "nccl":
+            dist.reduce_scatter_tensor(self._facc, self._fpart, op=dist.ReduceOp.SUM, group=self.group)
+        else:  # gloo rehearsal on one GPU: the same sum through host memory
+            host = self._fpart.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            self._facc.copy_(host[self.lo:self.hi])
+        capi.launch_kick_drift_f32(src.data_ptr(), out.data_ptr(), self.n, self.lo, self.n_tgt, self.dt, stream,
+                                   self._facc.data_ptr(), parts=1, vel_ptr=self.vel.data_ptr(),
+                                   pos64_ptr=self.pos64.data_ptr() if self.pos64 is not None else 0,
+                                   vel64_ptr=self.vel64.data_ptr() if self.vel64 is not None else 0, acc64=self.acc64)
+        self._exchange(out)
 
     @property
     def positions(self):

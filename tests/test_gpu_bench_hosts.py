@@ -125,15 +125,17 @@ def _two_gpus(nb):
         pytest.skip("needs two GPUs: the cross-device halves of the exchanges (hipMemcpyPeerAsync, RCCL with 2 ranks)")
 
 
+@pytest.mark.parametrize("n", [32768, 262144])  # ordered pairs (K1) / the GPUs share the unordered pairs (K1s + reduce-scatter)
 @pytest.mark.parametrize("overlap", [False, True])
 @pytest.mark.parametrize("exchange", ["copy", "rccl"])
-def test_two_distinct_gpus_follow_nb_step(nb, oracle, exchange, overlap):
-    """Devices [0, 1]: peer copies over xGMI / a two-rank RCCL all-gather, plain and overlapped, against nb_step and
-    oracle rows from both shards.  NOT EXECUTED on the builder's one-GPU boxes."""
+def test_two_distinct_gpus_follow_nb_step(nb, oracle, exchange, overlap, n):
+    """Devices [0, 1]: peer copies over xGMI / a two-rank RCCL all-gather (and, at 262144 bodies, reduce-scatter of the
+    partial forces), plain and overlapped, against nb_step and oracle rows from both shards.  NOT EXECUTED on the builder's
+    one-GPU boxes."""
     _two_gpus(nb)
     from test_gpu_sharded_native import _oracle_one_step
     c, syn = nb.capi, nb.synthetic
-    n, dt = 32768, 1e-2
+    dt = 1e-2
     q, v, m = syn.bodies(n)
     with c.Context(n, c.NB_F32, 0, G=syn.G, eps=syn.EPS, dt=dt) as ctx:
         ctx.set_state(q, v, m)

@@ -17,7 +17,8 @@ pytestmark = pytest.mark.gpu
 N, STEPS = 16384, 4
 
 
-def _run(rank, world, port, path, acc64=False, backend="gloo", overlap=False, exchange="in_place"):
+def _run(rank, world, port, path, acc64=False, backend="gloo", overlap=False, exchange="in_place", N=N, STEPS=STEPS,
+         shared_pairs=None):
     sys.path.insert(0, ROOT)
     import nbody_amd  # noqa: F401
     from nbody_amd import synthetic
@@ -36,7 +37,9 @@ def _run(rank, world, port, path, acc64=False, backend="gloo", overlap=False, ex
         pos = np.concatenate([q.T, (synthetic.G * m)[:, None]], axis=1)
         vel = np.concatenate([v.T, np.zeros((hi - lo, 1))], axis=1)
     sysm = ShardedSystem(N, torch.from_numpy(pos), torch.from_numpy(vel), synthetic.EPS, 1e-2, dev, acc64=acc64,
-                         overlap=overlap, exchange=exchange)
+                         overlap=overlap, exchange=exchange, shared_pairs=shared_pairs)
+    if shared_pairs is not None:
+        assert sysm.shared_pairs == shared_pairs
     if backend == "nccl":
         assert sysm.exchange_mode == "in_place"
         before = sysm.positions.clone()
@@ -114,6 +117,40 @@ def test_ranks_on_one_gpu_match_single_acc64(nb, oracle, tmp_path, world):
     dv = np.abs(b["vel"][:, :3].T - v).max()
     assert dq < 2e-6 and dv < 2e-4, (dq, dv)
     assert np.abs(b["pos64"][:, :3].T - syn.bodies(N)[0]).max() > 1e-4  # they did move
+
+
+@pytest.mark.parametrize("world,acc64", [(2, False), (4, False), (4, True)])
+def test_ranks_sharing_the_unordered_pairs_match_single(nb, oracle, tmp_path, world, acc64):
+    """shared_pairs (the default from 262144 bodies on, whole 4096-body superblocks per shard): every rank runs K1s on its
+    share of the UNORDERED pairs, the partial forces on all N bodies are summed to their owners (reduce-scatter; through
+    host memory in this gloo rehearsal), the owner kicks and drifts.  Two steps of N = 2^18 against the one-rank run (K1s on
+    the whole system) and the first step's velocities against oracle rows of every shard."""
+    n, steps = 1 << 18, 2
+    one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
+    mp.spawn(_run, args=(1, 0, one, acc64, "gloo", False, "in_place", n, steps), nprocs=1, join=True)
+    mp.spawn(_run, args=(world, _free_port(), two, acc64, "gloo", False, "in_place", n, steps, True), nprocs=world, join=True)
+    a, b = np.load(one), np.load(two)
+    if acc64:
+        assert np.abs(a["pos64"] - b["pos64"])[:, :3].max() < 1e-9 and np.abs(a["vel"] - b["vel"]).max() < 1e-7
+    else:
+        assert np.abs(a["pos"] - b["pos"]).max() < 5e-7 and np.abs(a["vel"] - b["vel"]).max() < 1e-5
+    # one step from the initial state against the oracle, rows from every shard
+    three = str(tmp_path / "three.npz")
+    mp.spawn(_run, args=(world, _free_port(), three, acc64, "gloo", False, "in_place", n, 1, True), nprocs=world, join=True)
+    c = np.load(three)
+    syn = nb.synthetic
+    q, v, m = syn.bodies(n)
+    per = n // world
+    rows = np.concatenate([[r * per, r * per + per // 2 + 3, (r + 1) * per - 1] for r in range(world)])
+    gm = (syn.G * m).astype(np.float32).astype(np.float64) / syn.G
+    q32 = q.astype(np.float32).astype(np.float64)
+    dt = np.float64(np.float32(1e-2))
+    for i in rows:
+        ref, s = oracle.accel_rows(q32, gm, syn.G, syn.EPS, int(i), int(i) + 1, want_abs=True)
+        v0 = v[:, i] if acc64 else v[:, i].astype(np.float32).astype(np.float64)
+        a_gpu = (c["vel"][i, :3].astype(np.float64) - v0) / dt
+        slack = 0.0 if acc64 else 2.0 ** -23 * np.abs(c["vel"][i, :3]).max() / dt
+        assert np.abs(a_gpu - ref[:, 0]).max() <= (1e-6 if acc64 else 1e-5) * s[0] + slack, (i, a_gpu, ref[:, 0])
 
 
 def test_nccl_world1_in_place_all_gather(nb, tmp_path):

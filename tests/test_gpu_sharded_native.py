@@ -87,6 +87,47 @@ def test_ranks_sharing_one_gpu_follow_nb_step_and_the_oracle(nb, oracle, ranks, 
     assert np.abs(q3 - q).max() > 1e-6  # it moved
 
 
+@pytest.mark.parametrize("precision", ["NB_F32", "NB_F32_ACC64"])
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_ranks_share_the_unordered_pairs(nb, oracle, ranks, precision):
+    """From 262144 bodies on (whole 4096-body superblocks per shard, step not overlapped) the GPUs share the UNORDERED pairs
+    of the system: K1s per rank on the superblocks of its shard, the partial forces on all bodies reduce-scattered to the
+    shard owners (copy exchange here: peer copies + an ordered sum in the kick-drift kernel), then the all-gather.  One
+    step against oracle rows of every shard, three against nb_step (K1s on one GPU) and against the ordered-pair form."""
+    c, syn = nb.capi, nb.synthetic
+    prec = getattr(c, precision)
+    n, dt = 1 << 18, 1e-2
+    q, v, m = syn.bodies(n)
+    with c.Context(n, prec, 0, G=syn.G, eps=syn.EPS, dt=dt) as ctx:
+        ctx.set_state(q, v, m)
+        ctx.step(1, 3)
+        q_ref, v_ref = ctx.get_state()
+    with c.Sharded(n, [0] * ranks, prec, G=syn.G, eps=syn.EPS, dt=dt, exchange="copy") as sh:
+        assert sh.kernel_name() == f"nbody_force_sym_f32<{'true' if prec == c.NB_F32_ACC64 else 'false'}>"
+        info = sh.info()
+        assert (info["targets_per_lane"], info["wg_size"]) == (8, 512) and info["j_split"] == -(-256 // (64 // ranks))
+        sh.set_state(q, v, m)
+        sh.step(1)
+        q1, v1 = sh.get_state()
+        sh.step(2)
+        q3, v3 = sh.get_state()
+    with c.Sharded(n, [0] * ranks, prec, G=syn.G, eps=syn.EPS, dt=dt, exchange="copy", ordered_pairs=True) as sh:
+        assert sh.kernel_name().startswith("nbody_force_f32<")
+        sh.set_state(q, v, m)
+        sh.step(3)
+        q3o, v3o = sh.get_state()
+    per = n // ranks
+    rows = [(r * per + off, 4) for r in range(ranks) for off in (0, per // 2 + 3, per - 4)]
+    idx, qo, vo = _oracle_one_step(oracle, syn, q, v, m, dt, rows, f32_start=(precision == "NB_F32"))
+    tol_v, tol_q = (2e-6, 2e-7) if precision == "NB_F32" else (2e-6, 3e-8)
+    assert np.abs(v1[:, idx] - vo).max() < tol_v, np.abs(v1[:, idx] - vo).max()
+    assert np.abs(q1[:, idx] - qo).max() < tol_q, np.abs(q1[:, idx] - qo).max()
+    for qq, vv in ((q_ref, v_ref), (q3o, v3o)):
+        assert np.abs(q3 - qq).max() < (5e-7 if precision == "NB_F32" else 1e-7), np.abs(q3 - qq).max()
+        assert np.abs(v3 - vv).max() < 1e-5, np.abs(v3 - vv).max()
+    assert np.abs(q3 - q).max() > 1e-6
+
+
 @pytest.mark.parametrize("overlap", [False, True])
 def test_overlap_flag_changes_nothing_but_the_schedule(nb, overlap):
     """Two ranks on one GPU, whole step vs own-shard-first phases: the same sums cut at another place."""
