@@ -10,8 +10,8 @@ import json
 import os
 import sys
 
-KERNEL = "nbody_force_f32"
-REDUCER = "nbody_reduce_update_f32"  # counted in the step's traffic: kernel_ms spans force + reducer, so must the bytes
+KERNEL = "nbody_force_f32"            # K1 (every ordered pair); switched to K1s' names below when the trace holds them
+REDUCER = "nbody_reduce_update_f32"   # counted in the step's traffic: kernel_ms spans force + reducer, so must the bytes
 
 
 def rows(pattern):
@@ -21,7 +21,10 @@ def rows(pattern):
 
 
 def main():
+    global KERNEL, REDUCER
     out, tag = sys.argv[1], sys.argv[2]
+    if any("nbody_force_sym_f32" in r.get("Name", "") for r in rows(f"{out}/stats/**/*kernel_stats.csv")):
+        KERNEL, REDUCER = "nbody_force_sym_f32", "nbody_reduce_sym_f32"  # K1s: every unordered pair once
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lines = [f"# rocprofv3 summary `{tag}` (bench/profile.sh; raw CSVs under {out}, scratch)", ""]
     # 1. kernel stats
@@ -35,10 +38,10 @@ def main():
         lines.append(f"| `{name[:90]}` | {r.get('Calls')} | {float(r.get('TotalDurationNs', 0)) / 1e6:.3f} | {avg:.4f} | {r.get('Percentage')} |")
         if KERNEL in name and avg_ms is None:
             avg_ms = avg
-            kernel = name.replace("void nbk::", "").replace("(nbk::F32Args)", "")
+            kernel = name.replace("void nbk::", "").replace("(nbk::F32Args, nbk::F32SymShape)", "").replace("(nbk::F32Args)", "")
         if KERNEL in name:
             force_total += float(r.get("TotalDurationNs", 0))
-        if "nbody_reduce_update_f32" in name:
+        if REDUCER in name:
             reduce_total += float(r.get("TotalDurationNs", 0))
     # per-dispatch registers from the trace
     for r in rows(f"{out}/stats/**/*kernel_trace.csv"):
@@ -110,7 +113,7 @@ def main():
         # bench.py only quotes these numbers for the configuration they were measured on
         t[key] = {"hbm_bytes_per_step": traffic, "force_bytes": force_bytes, "reducer_bytes": reducer_bytes,
                   "fetch_kib_raw": f_kib, "write_kib": w_kib, "tag": tag,
-                  "kernel_avg_ms": avg_ms, "kernel": kernel, "j_split": int(os.environ.get("NB_TRAFFIC_JSPLIT", "8")),
+                  "kernel_avg_ms": avg_ms, "kernel": kernel, "j_split": int(os.environ.get("NB_TRAFFIC_JSPLIT", "1" if "sym" in KERNEL else "8")),
                   "reduce_share_of_span": reduce_total / (reduce_total + force_total) if force_total else None,
                   "valu_busy": valu_busy}
         json.dump(t, open(tpath, "w"), indent=1)

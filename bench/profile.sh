@@ -8,7 +8,7 @@
 set -o pipefail
 cd "$(dirname "$0")/.." || exit 1
 TAG=${1:-r01}; shift
-ARGS=${@:---steps 3 --warmup 1 --no-cpu-baseline --no-parity-spot --no-live-pmc}
+ARGS=${@:---steps 3 --warmup 1 --no-cpu-baseline --no-parity-spot --no-live-pmc --no-diagnostics}
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT

@@ -275,9 +275,9 @@ const char* nb_kernel_name_f32(const nb_launch_f32* a, int accel_only);
 int nb_plan_f32(const nb_launch_f32* a, int* targets_per_lane, int* j_split, int* wg_size);
 /* workspace size that allows source slicing for n_tgt targets: 18 records per target (2 + 16 slots) */
 int64_t nb_workspace_bytes_f32(int64_t n_tgt, int acc64);
-/* workspace size that lets a whole-system launch of n bodies use K1s (source_path 3): one float4 record per body and
- * superblock round plus one (two with acc64) per workgroup of a superblock — n/8192 + 8 records per body: 2.3 GB at
- * n = 2^20, 34 GB at 2^22; 0 = K1s does not apply to this n
+/* workspace size that lets a whole-system launch of n bodies use K1s (source_path 3): three floats per body and
+ * superblock round plus three (six with acc64) per workgroup of a superblock — 12 B x (n/8192 + 8) per body: 1.7 GB at
+ * n = 2^20, 26 GB at 2^22; 0 = K1s does not apply to this n
  * (fewer than 262144 bodies, or more than 40 GiB of slots) */
 int64_t nb_workspace_bytes_sym_f32(int64_t n, int acc64);
 

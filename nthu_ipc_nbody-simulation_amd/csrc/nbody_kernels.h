@@ -50,14 +50,14 @@ constexpr int MAX_JSPLIT = 1024;       // source slices per step (processed SLIC
 constexpr int SYM_P = 4, SYM_WGS = 512;            // packed target pairs per lane, threads per workgroup (8 waves)
 constexpr int SYM_SB = SYM_WGS * 2 * SYM_P;        // superblock: 4096 bodies, the targets one workgroup holds in registers
 constexpr long SYM_MIN_N = 262144;                 // below this the pair list is too short to fill the chip (64 superblocks)
-constexpr size_t SYM_MAX_WORKSPACE = (size_t)40 << 30;  // partial-sum slots grow with n^2/8192 * 16 B: 2.2 GB at 2^20, 34 GB at 2^22
+constexpr size_t SYM_MAX_WORKSPACE = (size_t)40 << 30;  // partial-sum slots grow with n^2/8192 * 12 B: 1.6 GB at 2^20, 26 GB at 2^22
 struct F32SymShape {  // who computes what in one launch
     int B;         // superblocks covering the system
     int b0, nb;    // I-superblocks this launch owns: [b0, b0 + nb)   (one GPU: 0, B)
     int chunks;    // workgroups per I-superblock: its 1 + rounds work units are split evenly over them
     int by_super;  // slot of a finished superblock pair: 0 = round - 1 (one GPU: B/2 slots), 1 = I-superblock - b0 (several
                    // GPUs share the pairs: nb slots)
-    long npad;     // B * SYM_SB: bodies per slot
+    long npad;     // B * SYM_SB: bodies per slot plane (a slot = three planes x, y, z of npad floats)
 };
 __host__ __device__ inline int sym_own_slots(const F32SymShape& s, bool acc64) { return s.chunks * (acc64 ? 2 : 1); }
 __host__ __device__ inline int sym_total_slots(const F32SymShape& s, bool acc64) {

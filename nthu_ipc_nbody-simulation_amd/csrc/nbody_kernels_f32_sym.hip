@@ -183,27 +183,31 @@ __global__ __launch_bounds__(WGS, 1) void nbody_force_sym_f32(F32Args a, F32SymS
             __syncthreads();  // phases must not overlap: the next one touches tiles other waves have just updated
         }
         const int slot = sym_own_slots(sh, ACC64) + (sh.by_super ? b - sh.b0 : u - 1);
-        float4* out = (float4*)a.partial + (long)slot * sh.npad + jbase;
+        float* out = (float*)a.partial + (long)slot * 3 * sh.npad + jbase;  // a slot = three planes x, y, z of npad floats
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             const int e = k * WGS + t;
-            out[e] = make_float4(lds[0][e], lds[1][e], lds[2][e], 0.f);
+            out[e] = lds[0][e]; out[sh.npad + e] = lds[1][e]; out[2 * sh.npad + e] = lds[2][e];
             lds[0][e] = lds[1][e] = lds[2][e] = 0.f;  // by the thread that wrote it out: clean for the next pair
         }
         __syncthreads();
     }
-    // own sums -> slot `chunk` (fp64 sums: two records, the value split into two floats)
-    float4* own = (float4*)a.partial + ibase;
+    // own sums -> slot `chunk` (fp64 sums: two slots, the value split into a float and the float of the remainder)
+    float* own = (float*)a.partial + ibase;
+    const long plane = sh.npad;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int p = r >> 1, h = r & 1;
         const long i = (long)r * WGS + t;
         if (ACC64) {
             const float hx = (float)dax[r], hy = (float)day[r], hz = (float)daz[r];
-            own[(long)(2 * chunk) * sh.npad + i] = make_float4(hx, hy, hz, (float)(dax[r] - (double)hx));
-            own[(long)(2 * chunk + 1) * sh.npad + i] = make_float4((float)(day[r] - (double)hy), (float)(daz[r] - (double)hz), 0.f, 0.f);
+            float* hi = own + (long)(2 * chunk) * 3 * plane + i;
+            float* lo = own + (long)(2 * chunk + 1) * 3 * plane + i;
+            hi[0] = hx; hi[plane] = hy; hi[2 * plane] = hz;
+            lo[0] = (float)(dax[r] - (double)hx); lo[plane] = (float)(day[r] - (double)hy); lo[2 * plane] = (float)(daz[r] - (double)hz);
         } else {
-            own[(long)chunk * sh.npad + i] = make_float4(sx[p][h], sy[p][h], sz[p][h], 0.f);
+            float* o = own + (long)chunk * 3 * plane + i;
+            o[0] = sx[p][h]; o[plane] = sy[p][h]; o[2 * plane] = sz[p][h];
         }
     }
 }
@@ -216,44 +220,32 @@ __global__ __launch_bounds__(WG) void nbody_reduce_sym_f32(F32Args a, F32SymShap
     const long i = (long)blockIdx.x * WG + threadIdx.x;
     if (i >= a.n_src) return;
     const int B = sh.B, J = (int)(i / SB);
-    const float4* ws = (const float4*)a.partial;
+    const float* ws = (const float*)a.partial + i;  // slot s, component c of this body: ws[(3 s + c) * npad]
+    const long plane = sh.npad;
     const int own = sym_own_slots(sh, ACC64);
     double dx = 0, dy = 0, dz = 0;                          // ACC64
     float rx = 0, ry = 0, rz = 0, kx = 0, ky = 0, kz = 0;   // F32: Kahan
-    auto add = [&](float x, float y, float z) {
+    auto add = [&](long slot) {
+        const float* p = ws + slot * 3 * plane;
+        const float x = p[0], y = p[plane], z = p[2 * plane];
         if (ACC64) { dx += (double)x; dy += (double)y; dz += (double)z; return; }
         float u, v;
         u = x - kx; v = rx + u; kx = (v - rx) - u; rx = v;
         u = y - ky; v = ry + u; ky = (v - ry) - u; ry = v;
         u = z - kz; v = rz + u; kz = (v - rz) - u; rz = v;
     };
-    if (J >= sh.b0 && J < sh.b0 + sh.nb) {
-        for (int c = 0; c < sh.chunks; ++c) {
-            if (ACC64) {
-                const float4 hi = ws[(long)(2 * c) * sh.npad + i], lo = ws[(long)(2 * c + 1) * sh.npad + i];
-                dx += (double)hi.x + (double)hi.w; dy += (double)hi.y + (double)lo.x; dz += (double)hi.z + (double)lo.y;
-            } else {
-                const float4 p = ws[(long)c * sh.npad + i];
-                add(p.x, p.y, p.z);
-            }
-        }
-    }
+    if (J >= sh.b0 && J < sh.b0 + sh.nb)
+        for (int c = 0; c < own; ++c) add(c);  // (fp64 sums: the float and the float of its remainder, one after the other)
     if (sh.by_super) {  // a slot per producing I-superblock of this launch
         for (int k = 0; k < sh.nb; ++k) {
             const int b = sh.b0 + k;
             const int r = ((J - b) % B + B) % B;
-            if (r >= 1 && r <= sym_rounds(B, b)) {
-                const float4 p = ws[(long)(own + k) * sh.npad + i];
-                add(p.x, p.y, p.z);
-            }
+            if (r >= 1 && r <= sym_rounds(B, b)) add(own + k);
         }
     } else {  // a slot per round: producer b = J - r
         for (int r = 1; r <= B / 2; ++r) {
             const int b = ((J - r) % B + B) % B;
-            if (b >= sh.b0 && b < sh.b0 + sh.nb && r <= sym_rounds(B, b)) {
-                const float4 p = ws[(long)(own + r - 1) * sh.npad + i];
-                add(p.x, p.y, p.z);
-            }
+            if (b >= sh.b0 && b < sh.b0 + sh.nb && r <= sym_rounds(B, b)) add(own + r - 1);
         }
     }
     if (MODE == 2) {
@@ -328,7 +320,7 @@ F32SymShape sym_shape(long n, int n_cus, int b0, int nb, int force_chunks) {
 }
 
 size_t sym_workspace_bytes(const F32SymShape& s, bool acc64) {
-    return (size_t)sym_total_slots(s, acc64) * (size_t)s.npad * sizeof(float4);
+    return (size_t)sym_total_slots(s, acc64) * (size_t)s.npad * 3 * sizeof(float);  // a slot = 3 planes of npad floats
 }
 
 int launch_f32_sym(const F32Args& a0, const F32SymShape& sh, bool acc64, int mode, hipStream_t stream) {
