@@ -109,6 +109,33 @@ __global__ __launch_bounds__(WGS, V == 2 ? 4 : 1) void sym_force(SymArgs a) {
         for (int s = 0; s < 64; ++s) {
             float4 m0 = n0, m1 = n1;
             if (V == 1) { m0 = jt[w][(lane - s - 2) & 63]; m1 = jt[w][64 + ((lane - s - 2) & 63)]; }  // for step s + 2
+            if (V == 5) {
+#pragma unroll
+                for (int p0 = 0; p0 < P; p0 += 2) {  // FOUR packed sets in flight: pairs p0, p0 + 1, straight and swapped
+                    v2f dx[4], dy[4], dz[4], r2[4], rinv[4], r3[4], si[4], sj[4];
+#define ST4(stmt) _Pragma("unroll") for (int g = 0; g < 4; ++g) { const int p = p0 + (g >> 1); const bool sw = g & 1; (void)p; (void)sw; stmt; }
+                    ST4(dx[g] = (sw ? swp(xj) : xj) - xi[p])
+                    ST4(dy[g] = (sw ? swp(yj) : yj) - yi[p])
+                    ST4(dz[g] = (sw ? swp(zj) : zj) - zi[p])
+                    ST4(r2[g] = pk_fma(dx[g], dx[g], eps2))
+                    ST4(r2[g] = pk_fma(dy[g], dy[g], r2[g]))
+                    ST4(r2[g] = pk_fma(dz[g], dz[g], r2[g]))
+                    ST4(rinv[g] = ((v2f){__builtin_amdgcn_rsqf(r2[g].x), __builtin_amdgcn_rsqf(r2[g].y)}))
+                    ST4(r3[g] = rinv[g] * rinv[g])
+                    ST4(r3[g] = r3[g] * rinv[g])
+                    ST4(si[g] = (sw ? swp(gj) : gj) * r3[g])
+                    if (SYM) { ST4(sj[g] = gi[p] * r3[g]) }
+                    ST4(ax[p] = pk_fma(dx[g], si[g], ax[p]))
+                    ST4(ay[p] = pk_fma(dy[g], si[g], ay[p]))
+                    ST4(az[p] = pk_fma(dz[g], si[g], az[p]))
+                    if (SYM) {
+                        ST4(ajx = sw ? pk_fma(-swp(dx[g]), swp(sj[g]), ajx) : pk_fma(-dx[g], sj[g], ajx))
+                        ST4(ajy = sw ? pk_fma(-swp(dy[g]), swp(sj[g]), ajy) : pk_fma(-dy[g], sj[g], ajy))
+                        ST4(ajz = sw ? pk_fma(-swp(dz[g]), swp(sj[g]), ajz) : pk_fma(-dz[g], sj[g], ajz))
+                    }
+#undef ST4
+                }
+            } else
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 // two packed sets advanced stage by stage so that no packed result feeds the very next VALU instruction:
@@ -174,10 +201,14 @@ __global__ __launch_bounds__(WGS, V == 2 ? 4 : 1) void sym_force(SymArgs a) {
             tile_pass(a.src[jb + lane], a.src[jb + 64 + lane], T{}, ajx, ajy, ajz);
             flush();
             const int e = tile * 128 + lane;
-            lds[0][e] += ajx.x; lds[0][e + 64] += ajx.y;
-            lds[1][e] += ajy.x; lds[1][e + 64] += ajy.y;
-            lds[2][e] += ajz.x; lds[2][e + 64] += ajz.y;
-            __syncthreads();
+            if (V == 6) {  // timing only: private accumulation, no barrier (WRONG results)
+                lds[0][t] += ajx.x + ajx.y + ajy.x + ajy.y + ajz.x + ajz.y;
+            } else {
+                lds[0][e] += ajx.x; lds[0][e + 64] += ajx.y;
+                lds[1][e] += ajy.x; lds[1][e + 64] += ajy.y;
+                lds[2][e] += ajz.x; lds[2][e + 64] += ajz.y;
+                __syncthreads();
+            }
         }
         float4* out = a.partial + (long)r * a.n + jbase;
 #pragma unroll
@@ -300,6 +331,8 @@ int main(int argc, char** argv) {
     else if (P == 4 && wgs == 512 && V == 1) run<4, 512, 1>(n, reps, C);
     else if (P == 4 && wgs == 512 && V == 2) run<4, 512, 2>(n, reps, C);
     else if (P == 4 && wgs == 512 && V == 3) run<4, 512, 3>(n, reps, C);
+    else if (P == 4 && wgs == 512 && V == 5) run<4, 512, 5>(n, reps, C);
+    else if (P == 4 && wgs == 512 && V == 6) run<4, 512, 6>(n, reps, C);
     else if (P == 4 && wgs == 512 && V == 4) run<4, 512, 4>(n, reps, C);
     else if (P == 4 && wgs == 256 && V == 0) run<4, 256, 0>(n, reps, C);
     else if (P == 2 && wgs == 512 && V == 0) run<2, 512, 0>(n, reps, C);
