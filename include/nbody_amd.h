@@ -278,7 +278,7 @@ int64_t nb_workspace_bytes_f32(int64_t n_tgt, int acc64);
 /* workspace size that lets a whole-system launch of n bodies use K1s (source_path 3): three floats per body and
  * superblock round plus three (six with acc64) per workgroup of a superblock — 12 B x (n/8192 + 8) per body: 1.7 GB at
  * n = 2^20, 26 GB at 2^22; 0 = K1s does not apply to this n
- * (fewer than 262144 bodies, or more than 40 GiB of slots) */
+ * (fewer than 262144 bodies, or more than 128 GiB of slots: 103 GB at n = 2^23 is the last that fits) */
 int64_t nb_workspace_bytes_sym_f32(int64_t n, int acc64);
 
 /* ---- K1s over several GPUs, for hosts that own the collectives themselves (one process per GPU: nbody_amd.distributed).

@@ -50,7 +50,8 @@ constexpr int MAX_JSPLIT = 1024;       // source slices per step (processed SLIC
 constexpr int SYM_P = 4, SYM_WGS = 512;            // packed target pairs per lane, threads per workgroup (8 waves)
 constexpr int SYM_SB = SYM_WGS * 2 * SYM_P;        // superblock: 4096 bodies, the targets one workgroup holds in registers
 constexpr long SYM_MIN_N = 262144;                 // below this the pair list is too short to fill the chip (64 superblocks)
-constexpr size_t SYM_MAX_WORKSPACE = (size_t)40 << 30;  // partial-sum slots grow with n^2/8192 * 12 B: 1.6 GB at 2^20, 26 GB at 2^22
+constexpr size_t SYM_MAX_WORKSPACE = (size_t)128 << 30;  // partial-sum slots grow with n^2/8192 * 12 B: 1.6 GB at 2^20, 26 GB at 2^22,
+                                                         // 103 GB at 2^23 (and per GPU at 2^24 over 8) — of 288 GB
 struct F32SymShape {  // who computes what in one launch
     int B;         // superblocks covering the system
     int b0, nb;    // I-superblocks this launch owns: [b0, b0 + nb)   (one GPU: 0, B)
