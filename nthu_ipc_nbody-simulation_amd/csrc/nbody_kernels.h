@@ -49,21 +49,28 @@ constexpr int MAX_JSPLIT = 1024;       // source slices per step (processed SLIC
 // ---- K1s (nbody_kernels_f32_sym.hip): every unordered pair once — Newton's third law
 constexpr int SYM_P = 4, SYM_WGS = 512;            // packed target pairs per lane, threads per workgroup (8 waves)
 constexpr int SYM_SB = SYM_WGS * 2 * SYM_P;        // superblock: 4096 bodies, the targets one workgroup holds in registers
-constexpr long SYM_MIN_N = 262144;                 // below this the pair list is too short to fill the chip (64 superblocks)
+#ifndef NB_SYM_MIN_N
+#define NB_SYM_MIN_N 131072
+#endif
+constexpr long SYM_MIN_N = NB_SYM_MIN_N;           // below this the pair list is too short to fill the chip (N = 65536: 16 superblocks of
+                                                   // 8.5 work units — 0.35 of peak against K1's 0.48; N = 131072: 0.73 against 0.58)
 constexpr size_t SYM_MAX_WORKSPACE = (size_t)128 << 30;  // partial-sum slots grow with n^2/8192 * 12 B: 1.6 GB at 2^20, 26 GB at 2^22,
                                                          // 103 GB at 2^23 (and per GPU at 2^24 over 8) — of 288 GB
 struct F32SymShape {  // who computes what in one launch
     int B;         // superblocks covering the system
     int b0, nb;    // I-superblocks this launch owns: [b0, b0 + nb)   (one GPU: 0, B)
-    int chunks;    // workgroups per I-superblock: its 1 + rounds work units are split evenly over them
+    int chunks;    // workgroups per I-superblock: the tile phases of its 1 + rounds work units are cut evenly among them
     int by_super;  // slot of a finished superblock pair: 0 = round - 1 (one GPU: B/2 slots), 1 = I-superblock - b0 (several
                    // GPUs share the pairs: nb slots)
     long npad;     // B * SYM_SB: bodies per slot plane (a slot = three planes x, y, z of npad floats)
 };
 __host__ __device__ inline int sym_own_slots(const F32SymShape& s, bool acc64) { return s.chunks * (acc64 ? 2 : 1); }
-__host__ __device__ inline int sym_total_slots(const F32SymShape& s, bool acc64) {
-    return sym_own_slots(s, acc64) + (s.by_super ? s.nb : s.B / 2);
+// slots: own sums per chunk | finished superblock pairs (by round, or by I-superblock) | per chunk the second part of the
+// round that straddles it and the chunk before (the work is cut at tile-phase granularity)
+__host__ __device__ inline int sym_tail_slot(const F32SymShape& s, bool acc64, int chunk) {
+    return sym_own_slots(s, acc64) + (s.by_super ? s.nb : s.B / 2) + chunk;
 }
+__host__ __device__ inline int sym_total_slots(const F32SymShape& s, bool acc64) { return sym_tail_slot(s, acc64, s.chunks); }
 F32SymShape sym_shape(long n, int n_cus, int b0 = 0, int nb = 0, int force_chunks = 0);
 size_t sym_workspace_bytes(const F32SymShape& s, bool acc64);
 // mode 0: force + kick-drift of the whole system; 1: accelerations out; 2: this launch's partial force out (a.acc:

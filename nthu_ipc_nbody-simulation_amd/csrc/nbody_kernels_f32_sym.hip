@@ -21,8 +21,9 @@
 //     accelerations by plain read-modify-write: the tiles of one phase are distinct, phases are separated by a barrier,
 //     so the order of the additions — and with it every bit of the result — is fixed (bitwise reproducible, like K1);
 //   * superblock pairs: I-superblock b takes J = b + r (mod B) for r = 1 .. (B-1)/2, plus r = B/2 for b < B/2 when B is
-//     even — every unordered pair of superblocks once — and its own diagonal block without the symmetric half.  These
-//     1 + rounds work units are split evenly over `chunks` workgroups.  The LDS image of a finished pair goes to a slot of
+//     even — every unordered pair of superblocks once — and its own diagonal block without the symmetric half.  The
+//     tile phases of these 1 + rounds work units are cut evenly among `chunks` workgroups (a round that straddles two of
+//     them leaves its second part in a tail slot).  The LDS image of a finished pair goes to a slot of
 //     a partial-sum workspace, the workgroup's own sums (two-level: 128 contributions in fp32 registers, then Kahan /
 //     fp64 running sums, as in K1) to another; nbody_reduce_sym_f32 adds the slots of a body in a fixed order and runs
 //     the fused kick-drift epilogue (samples/nbody.cc:76-88), or hands the per-GPU partial force to the host's
@@ -142,15 +143,26 @@ __global__ __launch_bounds__(WGS, 1) void nbody_force_sym_f32(F32Args a, F32SymS
     using Yes = std::true_type;
     using No = std::false_type;
 
-    // this workgroup's share of the I-superblock's work units: unit 0 = the diagonal block, unit r = round r
+    // this workgroup's share of the I-superblock's work: unit 0 = the diagonal block, unit r = round r, NT tile phases
+    // each; the phases of all units, in order, are cut into `chunks` equal ranges (the same cut points for every
+    // superblock: those with one round fewer simply end earlier).  A round that straddles two workgroups leaves two
+    // partial images: the first part in the round's regular slot, the second in the TAIL slot of the workgroup that
+    // starts with it — one tail slot per chunk suffices because, for a given chunk, it is the same round for every
+    // superblock, so the images land on different J-superblocks of that slot.
     const int units = 1 + sym_rounds(B, b);
-    const int u_lo = (int)((long)chunk * units / sh.chunks), u_hi = (int)((long)(chunk + 1) * units / sh.chunks);
+    const long Q = (long)NT * (1 + B / 2);  // phases of a superblock with the most rounds
+    const long q_lo = chunk * Q / sh.chunks;
+    const long q_end = (long)NT * units;
+    const long q_hi = (chunk + 1) * Q / sh.chunks < q_end ? (chunk + 1) * Q / sh.chunks : q_end;
     v2f ajx, ajy, ajz;
     bool lds_clean = false;
-    for (int u = u_lo; u < u_hi; ++u) {
+    for (long q = q_lo; q < q_hi;) {
+        const int u = (int)(q / NT), ph0 = (int)(q % NT);
+        const int ph1 = (q_hi - q) < (NT - ph0) ? ph0 + (int)(q_hi - q) : NT;
+        q += ph1 - ph0;
         if (u == 0) {  // the superblock against itself, without the symmetric half; the self pair adds exactly +0
-            float4 j0 = body(ibase + lane), j1 = body(ibase + 64 + lane);
-            for (int k = 0; k < NT; ++k) {
+            float4 j0 = body(ibase + (long)ph0 * 128 + lane), j1 = body(ibase + (long)ph0 * 128 + 64 + lane);
+            for (int k = ph0; k < ph1; ++k) {
                 const long nb_ = ibase + (long)((k + 1) & (NT - 1)) * 128;
                 const float4 n0 = body(nb_ + lane), n1 = body(nb_ + 64 + lane);  // next tile, in flight during this one
                 tile_pass(j0, j1, No{}, ajx, ajy, ajz);
@@ -167,9 +179,9 @@ __global__ __launch_bounds__(WGS, 1) void nbody_force_sym_f32(F32Args a, F32SymS
         }
         const int J = (b + u) % B;
         const long jbase = (long)J * SB;
-        const int tile0 = (w * P) & (NT - 1);
+        const int tile0 = (ph0 + w * P) & (NT - 1);
         float4 j0 = body(jbase + (long)tile0 * 128 + lane), j1 = body(jbase + (long)tile0 * 128 + 64 + lane);
-        for (int ph = 0; ph < NT; ++ph) {
+        for (int ph = ph0; ph < ph1; ++ph) {
             const int tile = (ph + w * P) & (NT - 1);
             const long nb_ = jbase + (long)((tile + 1) & (NT - 1)) * 128;
             const float4 n0 = body(nb_ + lane), n1 = body(nb_ + 64 + lane);  // next phase's tile, in flight during this one
@@ -182,7 +194,8 @@ __global__ __launch_bounds__(WGS, 1) void nbody_force_sym_f32(F32Args a, F32SymS
             j0 = n0; j1 = n1;
             __syncthreads();  // phases must not overlap: the next one touches tiles other waves have just updated
         }
-        const int slot = sym_own_slots(sh, ACC64) + (sh.by_super ? b - sh.b0 : u - 1);
+        const int slot = ph0 ? sym_tail_slot(sh, ACC64, chunk)
+                             : sym_own_slots(sh, ACC64) + (sh.by_super ? b - sh.b0 : u - 1);
         float* out = (float*)a.partial + (long)slot * 3 * sh.npad + jbase;  // a slot = three planes x, y, z of npad floats
 #pragma unroll
         for (int k = 0; k < R; ++k) {
@@ -248,6 +261,16 @@ __global__ __launch_bounds__(WG) void nbody_reduce_sym_f32(F32Args a, F32SymShap
             if (b >= sh.b0 && b < sh.b0 + sh.nb && r <= sym_rounds(B, b)) add(own + r - 1);
         }
     }
+    // second parts of the rounds that straddle two workgroups: chunk c starts inside round q_c / NT (the same for every
+    // superblock), whose producer for this body's superblock is J - that round
+    const long Q = (long)NT * (1 + B / 2);
+    for (int c = 1; c < sh.chunks; ++c) {
+        const long q = c * Q / sh.chunks;
+        const int r = (int)(q / NT);
+        if (q % NT == 0 || r == 0) continue;  // cut at a unit boundary, or inside the diagonal block (no image)
+        const int b = ((J - r) % B + B) % B;
+        if (b >= sh.b0 && b < sh.b0 + sh.nb && r <= sym_rounds(B, b)) add(sym_tail_slot(sh, ACC64, c));
+    }
     if (MODE == 2) {
         if (ACC64) ((double4*)a.acc)[i] = make_double4(dx, dy, dz, 0.0);
         else ((float4*)a.acc)[i] = make_float4(rx, ry, rz, 0.f);
@@ -310,9 +333,22 @@ F32SymShape sym_shape(long n, int n_cus, int b0, int nb, int force_chunks) {
     s.b0 = b0;
     s.nb = nb;
     s.by_super = nb < s.B;  // several launches (GPUs) share the pairs: nb <= B/2 slots instead of B/2
-    // one 512-thread workgroup fits a CU (152 VGPRs): give every CU at least one
-    int c = force_chunks > 0 ? force_chunks : (n_cus + nb - 1) / nb;
-    const int units_min = 1 + (s.B - 1) / 2;
+    // One 512-thread workgroup fits a CU, so workgroups run in rounds of n_cus and a partly filled last round is idle
+    // time: take the chunk count that minimises  ceil(nb * c / n_cus) / c  (time in units of one superblock's work), with
+    // 0.4 % per extra chunk for the reloaded targets and the shorter runs between slot writes (measured at N = 2^20:
+    // 1 / 2 / 4 / 8 chunks = 177.1 / 178.1 / 178.5 / 182.8 ms).  nb = 256: 1;  128: 2;  32 (an eighth of 2^20): 8;
+    // 48: 16 (768 workgroups = 3 full rounds; 6 would be 288 = one round and an eighth);  366: 2.
+    const int units_min = 1 + (s.B - 1) / 2;  // a chunk must hold at least one whole unit's worth of phases
+    int c = force_chunks;
+    if (c <= 0) {
+        double best = 1e30;
+        c = 1;
+        for (int k = 1; k <= 16 && k <= units_min; ++k) {
+            const long rounds = ((long)nb * k + n_cus - 1) / n_cus;
+            const double cost = (double)rounds / k * (1.0 + 0.004 * (k - 1));
+            if (cost < best - 1e-12) { best = cost; c = k; }
+        }
+    }
     if (c > units_min) c = units_min;
     if (c < 1) c = 1;
     s.chunks = c;

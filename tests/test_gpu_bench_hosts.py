@@ -55,7 +55,8 @@ def test_native_host_line_without_a_launcher(nb):
     # per-rank kernel time from HIP events on each rank's stream; the slowest rank prices the roofline
     assert len(r["kernel_ms_per_rank"]) == 2 and all(k > 0 for k in r["kernel_ms_per_rank"])
     assert r["roofline"]["kernel_ms"] == max(r["kernel_ms_per_rank"]) and 0 < r["roofline"]["frac"] < 1
-    assert r["roofline"]["kernel"].startswith("nbody_force_f32<")
+    # 131072 bodies in two shards of whole superblocks: the ranks share the unordered pairs (K1s + reduce-scatter of forces)
+    assert r["roofline"]["kernel"] == "nbody_force_sym_f32<false>" and r["pairs"].startswith("every unordered pair once")
     # the line carries its own proof: rows of BOTH shards against the oracle
     ps = r["parity_spot"]
     assert ps["ok"] and ps["ranks_covered"] == 2 and ps["rows"] == 64 and ps["max_err_over_sum_abs"] < ps["tol"] == 1e-5
@@ -63,6 +64,7 @@ def test_native_host_line_without_a_launcher(nb):
     # variants ran as children: the overlapped step (copy exchange on one GPU: rccl is skipped there)
     v = r["variants"]
     assert v["overlap_on"]["ms_per_step"] > 0 and "exchange_rccl" not in v and "exchange_copy" not in v
+    assert v["pairs_ordered"]["kernel"].startswith("nbody_force_f32<") and v["overlap_on"]["kernel"].startswith("nbody_force_f32<")
     # the reference's own multi-GPU mode (two device slots, both this GPU): golden outputs
     assert r["replicas"]["b200"]["byte_identical"] and r["replicas"]["b1024"]["byte_identical"]
 
@@ -102,7 +104,7 @@ def test_single_gpu_line_reports_the_lds_kernel_and_step_traffic(nb):
                         "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=_env(), cwd=ROOT)
     r = _line(p)
     assert r["n_gpus"] == 1 and r["host"] == "single" and r["parity_spot"]["ok"]
-    # a whole system of >= 262144 bodies on one GPU: K1s (every unordered pair once) is what is timed; the two kernels that
+    # a whole system of >= 131072 bodies on one GPU: K1s (every unordered pair once) is what is timed; the two kernels that
     # evaluate every ordered pair are measured beside it by the same run
     assert r["roofline"]["kernel"] == "nbody_force_sym_f32<false>" and r["roofline"]["pair_evaluation"].startswith("each unordered")
     assert r["roofline"]["kernel_ms_spans"] == ["nbody_force_sym_f32<false>", "nbody_reduce_sym_f32<false, 0>"]

@@ -288,25 +288,27 @@ def test_config4_rank_shape_acc64(nb, oracle):
 
 
 def test_bench_plan_step_against_oracle(nb, oracle):
-    """The exact kernel bench.py times — nbody_force_f32<4,false,false,true,true,512> (512-thread workgroups, R = 8,
-    source slices, step mode) + its reducer's kick-drift — stepped once against the oracle: ragged N = 131072 + 77
-    through nb_step's default plan, 40 rows of q,v vs  v + a_oracle*dt , q + v'*dt  (samples/nbody.cc:76-88)."""
+    """K1 in the shape bench.py timed until round 3 — nbody_force_f32<4,false,false,true,true,512> (512-thread workgroups,
+    R = 8, source slices, step mode) + its reducer's kick-drift — stepped once against the oracle on a ragged N = 131072 + 77
+    (a raw launch with K1's own workspace: a context of this size runs K1s since round 4, tests/test_gpu_f32_symmetric.py),
+    40 rows of q,v vs  v + a_oracle*dt , q + v'*dt  (samples/nbody.cc:76-88)."""
     syn = nb.synthetic
     n, dt = 131072 + 77, 1e-2
     ws = nb.capi.workspace_bytes_f32(n)
     assert nb.capi.kernel_name_f32(n, n, workspace_bytes=ws) == "nbody_force_f32<4, false, false, true, true, 512>"
     assert nb.capi.kernel_name_f32(1 << 20, 1 << 20, workspace_bytes=nb.capi.workspace_bytes_f32(1 << 20)) == \
         "nbody_force_f32<4, false, false, true, true, 512>"
-    q, v, m = syn.bodies(n)
+    import torch
     pos, vel = syn.body4_f32(n)
-    with nb.capi.Context(n, nb.capi.NB_F32, 0, G=syn.G, eps=syn.EPS, dt=dt) as ctx:
-        ctx.set_state(q, v, m)
-        ctx.step(1, 1)
-        qg, vg = ctx.get_state()
+    src, v_gpu = torch.from_numpy(pos).cuda(), torch.from_numpy(vel).cuda()
+    out_gpu = torch.zeros_like(src)
+    w = torch.empty(ws, dtype=torch.uint8, device="cuda")
+    nb.capi.launch_f32(src.data_ptr(), out_gpu.data_ptr(), n, 0, n, syn.EPS ** 2, dt, torch.cuda.current_stream().cuda_stream,
+                       vel_ptr=v_gpu.data_ptr(), workspace_ptr=w.data_ptr(), workspace_bytes=w.numel())
+    torch.cuda.synchronize()
     rows = np.concatenate([np.arange(36) * (n // 36) + 3, [n - 77, n - 76, n - 2, n - 1]])  # incl. the ragged tail block
     ref, s = _oracle_rows(oracle, syn, pos, rows)
-    out = np.concatenate([qg.T, pos[:, 3:4].astype(np.float64)], axis=1).astype(np.float32)
-    _check_step_rows(pos, vel, out, vg.T.astype(np.float32), rows, 0, ref, s, dt, TOL_F32)
+    _check_step_rows(pos, vel, out_gpu.cpu().numpy(), v_gpu.cpu().numpy(), rows, 0, ref, s, dt, TOL_F32)
 
 
 @pytest.mark.parametrize("acc64", [False, True])

@@ -74,7 +74,7 @@ def test_symmetric_accelerations_vs_oracle_and_k1(nb, oracle, n, chunks, acc64):
 
 
 def test_symmetric_is_bitwise_reproducible_and_is_what_a_context_runs(nb, oracle):
-    """No atomics anywhere: two launches give identical bits; nb_accel / nb_step of a context with >= 262144 bodies pick
+    """No atomics anywhere: two launches give identical bits; nb_accel / nb_step of a context with >= 131072 bodies pick
     K1s by themselves (the workspace is sized for it at nb_create) and give exactly the raw launch's numbers."""
     import torch
     c, syn = nb.capi, nb.synthetic
@@ -142,7 +142,7 @@ def test_symmetric_refusals_and_fallbacks(nb):
     stream = torch.cuda.current_stream().cuda_stream
     big = torch.empty(c.workspace_bytes_sym_f32(n), dtype=torch.uint8, device="cuda")
     small = torch.empty(c.workspace_bytes_f32(n), dtype=torch.uint8, device="cuda")
-    assert c.workspace_bytes_sym_f32(SB * 63) == 0 and c.workspace_bytes_sym_f32(1 << 24) == 0  # too small / > 128 GiB of slots (412 GB)
+    assert c.workspace_bytes_sym_f32(SB * 31) == 0 and c.workspace_bytes_sym_f32(1 << 24) == 0  # too small / > 128 GiB of slots (412 GB)
     for kw in (dict(workspace_ptr=small.data_ptr(), workspace_bytes=small.numel()),                      # workspace too small
                dict(workspace_ptr=big.data_ptr(), workspace_bytes=big.numel(), src_begin=0, src_end=n // 2),  # a source range
                dict(workspace_ptr=big.data_ptr(), workspace_bytes=big.numel(), tgt_ptr=src.data_ptr())):  # a target block
