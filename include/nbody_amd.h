@@ -299,11 +299,14 @@ int64_t nb_workspace_bytes_shared_pairs_f32(int64_t n_src, int ranks, int acc64)
 /* ---- index-sharded multi-GPU stepping: ONE process, P GPUs of a node, RCCL over xGMI (csrc/nbody_sharded.cpp) ----
  * The reference's only multi-GPU use is task parallelism (hw5.cu:564-567,587-588); this is the data-parallel scheme of
  * GPU r owns targets [r*n/P, (r+1)*n/P) (velocities, fp64 masters), every GPU holds all positions twice
- * (ping-pong float4[n] {x,y,z,G*m}); per step and GPU one force + fused kick-drift launch sequence on its own stream,
- * then ONE in-place ncclAllGather(sendbuff = recvbuff + r*4n/P, ncclFloat) per GPU.  RCCL is loaded (dlopen) by the
- * first nb_sharded_create.  The same scheme with one process per GPU: nbody_amd.distributed (torch.distributed).
- * n must be divisible by n_devices; precision NB_F32 or NB_F32_ACC64; with one device the trajectory equals nb_step's
- * bit for bit. */
+ * (ping-pong float4[n] {x,y,z,G*m}).  Per step and GPU, on its own stream:
+ *   default (whole 4096-body superblocks per shard, n >= 131072, no overlap): its share of the UNORDERED pairs of the system
+ *     (kernel K1s) -> a partial force on all n bodies -> ONE ncclReduceScatter (sum) to the shard owners -> kick-drift;
+ *   otherwise / NB_SHARDED_ORDERED_PAIRS: every ordered pair of its own targets with the kick-drift fused (kernel K1);
+ *   then ONE in-place ncclAllGather(sendbuff = recvbuff + r*4n/P, ncclFloat) of the positions.
+ * RCCL is loaded (dlopen) by the first nb_sharded_create.  The same scheme with one process per GPU: nbody_amd.distributed
+ * (torch.distributed).  n must be divisible by n_devices; precision NB_F32 or NB_F32_ACC64; with one device the trajectory
+ * equals nb_step's bit for bit. */
 typedef struct nb_sharded nb_sharded;
 #define NB_SHARDED_OVERLAP 1 /* two-phase step: own-shard sources while the all-gather of the other shards is in flight
                                 on a second stream, remote sources after it; n/P must be a multiple of 256 */

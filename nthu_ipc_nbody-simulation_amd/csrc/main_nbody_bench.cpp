@@ -1,7 +1,9 @@
 // main_nbody_bench.cpp — a compiled host of the C ABI for large N (no Python, no torch):
-//     bin/nbody_bench [N=1048576] [steps=10] [warmup=2] [precision: f32|f32acc64|f64] [gpus=0] [overlap=0] [exchange=rccl]
-// gpus >= 1 runs the index-sharded stepper (nb_sharded_*: this one process drives GPUs 0..gpus-1, one in-place RCCL
-// all-gather of positions per GPU per step; overlap=1 = two-phase step hiding the gather); gpus = 0 the plain context.
+//     bin/nbody_bench [N=1048576] [steps=10] [warmup=2] [precision: f32|f32acc64|f64] [gpus=0] [overlap=0] [exchange=rccl] [pairs=shared]
+// gpus >= 1 runs the index-sharded stepper (nb_sharded_*: this one process drives GPUs 0..gpus-1; per step the GPUs share
+// the unordered pairs of the system — K1s, one reduce-scatter of partial forces — and all-gather the positions in place;
+// pairs=ordered: every GPU evaluates every ordered pair of its own targets (K1), all-gather only; overlap=1 = two-phase
+// ordered-pair step hiding the gather); gpus = 0 the plain context.
 // exchange: rccl | copy (peer copies on the copy engines, NB_SHARDED_COPY_EXCHANGE) | copy-one-gpu (the same with all
 // `gpus` ranks on device 0 — every P > 1 line of the host runs on a one-GPU box; the ranks then share the chip).
 // Generates the synthetic bodies of SURVEY §8(d) (same splitmix64 stream as nbody_amd/synthetic.py), uploads them with
@@ -32,6 +34,7 @@ int main(int argc, char** argv) {
     const int gpus = argc > 5 ? atoi(argv[5]) : 0;
     const int overlap = argc > 6 ? atoi(argv[6]) : 0;
     const char* exchange = argc > 7 ? argv[7] : "rccl";
+    const bool ordered = argc > 8 && !strcmp(argv[8], "ordered");
     const bool one_gpu = !strcmp(exchange, "copy-one-gpu");
     const bool copy = one_gpu || !strcmp(exchange, "copy");
     if (!copy && strcmp(exchange, "rccl")) {
@@ -59,7 +62,8 @@ int main(int argc, char** argv) {
         for (int g = 0; g < gpus; ++g) devs[g] = one_gpu ? 0 : g;
         nb_sharded* sh = nullptr;
         int rc = nb_sharded_create(&sh, devs.data(), gpus, n, cfg.precision, cfg.G, cfg.eps, cfg.dt,
-                                   (overlap ? NB_SHARDED_OVERLAP : 0) | (copy ? NB_SHARDED_COPY_EXCHANGE : 0));
+                                   (overlap ? NB_SHARDED_OVERLAP : 0) | (copy ? NB_SHARDED_COPY_EXCHANGE : 0) |
+                                       (ordered ? NB_SHARDED_ORDERED_PAIRS : 0));
         if (!rc) rc = nb_sharded_set_state(sh, &q[0], &q[n], &q[2 * n], &v[0], &v[n], &v[2 * n], m.data());
         if (!rc && warmup > 0) rc = nb_sharded_step(sh, warmup);
         double ms = 0;
@@ -73,9 +77,9 @@ int main(int argc, char** argv) {
         int64_t per = 0;
         nb_sharded_info(sh, nullptr, &per, &tpl, &js, &wg);
         printf("{\"n\": %ld, \"precision\": \"%s\", \"gpus\": %d, \"exchange\": \"%s\", \"overlap\": %d, \"steps\": %d, \"ms_per_step\": %.4f, "
-               "\"pairs_per_s\": %.6e, \"tflops_20flop\": %.2f, \"targets_per_gpu\": %lld, \"plan\": [%d, %d, %d]}\n",
+               "\"pairs_per_s\": %.6e, \"tflops_20flop\": %.2f, \"targets_per_gpu\": %lld, \"plan\": [%d, %d, %d], \"kernel\": \"%s\"}\n",
                n, prec, gpus, exchange, overlap, steps, ms, pairs / (ms * 1e-3), pairs / (ms * 1e-3) * 20 / 1e12, (long long)per, tpl, js,
-               wg);
+               wg, nb_sharded_kernel_name(sh));
         nb_sharded_destroy(sh);
         return 0;
     }
