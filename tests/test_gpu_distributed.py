@@ -46,6 +46,14 @@ def _run(rank, world, port, path, acc64=False, backend="gloo", overlap=False, ex
         dist.all_gather_into_tensor(sysm.positions, sysm.positions[sysm.lo:sysm.hi])  # the aliased call by itself
         torch.cuda.synchronize()
         assert torch.equal(before, sysm.positions)
+        # the other collective of a step whose ranks share the unordered pairs: reduce_scatter_tensor of float4[N] partial
+        # forces (double4 with fp64 accumulation) — with one rank the sum is the input itself
+        for fdt in (torch.float32, torch.float64):
+            f = torch.arange(N * 4, dtype=fdt, device=dev).reshape(N, 4)
+            o = torch.empty_like(f)
+            dist.reduce_scatter_tensor(o, f, op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize()
+            assert torch.equal(o, f)
     for _ in range(STEPS):
         sysm.step()
     torch.cuda.synchronize()
