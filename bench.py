@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 FLOP_PER_PAIR = 20            # GPU Gems 3 ch.31 convention
 PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz
 ISSUE_CEILING_FRAC = 0.62     # K1 (every ordered pair): what the pair loop's instruction mix can issue
-ISSUE_CEILING_FRAC_SYM = 0.957  # K1s (every unordered pair once): 16 packed VALU + 2 v_rsq_f32 per 4 interactions + 14 moves / 32
+ISSUE_CEILING_FRAC_SYM = 0.92   # K1s (every unordered pair once): 16 packed VALU + 2 v_rsq_f32 per 4 interactions + 14 DPP moves / 32
 
 
 def cpu_model():
@@ -360,9 +360,9 @@ def roofline_block(achieved, kname, k_ms, tpl, jsp, wgs, acc64, traffic=None, tr
     ceiling = ISSUE_CEILING_FRAC_SYM if sym else ISSUE_CEILING_FRAC
     detail = ("every UNORDERED pair once (Newton's third law; `value` counts the N(N-1) ordered interactions the reference "
               "evaluates, nbody.cc:57-60): per 4 interactions x 64 lanes a SIMD issues 16 packed fp32 VALU ops (4 cycles each) "
-              "+ 2 v_rsq_f32 (8 cycles each) = 80 cycles, plus 14 v_mov_b32_dpp (2 cycles) per 32 such sets that rotate the "
-              "travelling sources -> 20.9 cycles per 64 interactions = 0.957 of peak at 20 flop/pair "
-              "(nbody_kernels_f32_sym.hip, profiles/r01_ubench_valu_rate.txt)") if sym else (
+              "+ 2 v_rsq_f32 (8 cycles each) = 80 cycles, plus 14 v_mov_b32_dpp (4 cycles each, measured) per 8 such sets that "
+              "rotate the travelling sources -> 696 cycles per 2048 interactions = 21.75 per 64 = 0.92 of peak at 20 flop/pair "
+              "(nbody_kernels_f32_sym.hip, profiles/r01_ubench_valu_rate.txt, r04_ubench_dpp_rate.txt)") if sym else (
               "per 64 pairs a SIMD issues 12 fp32 VALU ops (2 cycles each, packed: 6 x 4) "
               "+ 1 v_rsq_f32 (8 cycles, does not overlap VALU) = 32 cycles -> 1024 SIMDs "
               "x 2.4 GHz x 64/32 = 4.9e12 pairs/s = 0.62 of peak at 20 flop/pair "

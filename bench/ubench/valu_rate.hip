@@ -7,6 +7,7 @@
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -o valu_rate valu_rate.hip
 #include <hip/hip_runtime.h>
+#include <cstring>
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -20,11 +21,12 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 enum Op { FMA32, PKFMA32, MUL32, PKMUL32, ADD32, PKADD32, RSQ32, RCP32, SQRT32,
           MIX_PAIR_PK, MIX_PAIR_SC, FMA64, MUL64, ADD64, RSQ64, RCP64, SQRT64, DIVSCALE64, DIVFMAS64,
-          DIVFIXUP64, LDS128_FMA, NOPS };
+          DIVFIXUP64, LDS128_FMA, DPP_WAVE_ROR, DPP_ROW_ROR, DPP_BETWEEN_PK, NOPS };
 static const char* op_name[] = { "v_fma_f32", "v_pk_fma_f32", "v_mul_f32", "v_pk_mul_f32", "v_add_f32",
   "v_pk_add_f32", "v_rsq_f32", "v_rcp_f32", "v_sqrt_f32", "mix:12pk+2rsq(2 pairs)", "mix:12sc+1rsq(1 pair)",
   "v_fma_f64", "v_mul_f64", "v_add_f64", "v_rsq_f64", "v_rcp_f64", "v_sqrt_f64", "v_div_scale_f64",
-  "v_div_fmas_f64", "v_div_fixup_f64", "ds_read_b128+12pk+2rsq", "" };
+  "v_div_fmas_f64", "v_div_fixup_f64", "ds_read_b128+12pk+2rsq", "v_mov_b32_dpp wave_ror:1", "v_mov_b32_dpp row_ror:1",
+  "8 v_pk_fma + 1 dpp wave_ror", "" };
 
 constexpr int U = 16;      // independent chains per lane
 constexpr int ITERS = 32768;
@@ -97,6 +99,12 @@ __global__ __launch_bounds__(256) void k(float* out, WaveRec* rec, float seed) {
         if constexpr (OP == PKMUL32) asm volatile("v_pk_mul_f32 %0, %1, %0" : "+v"(p[u]) : "v"(pb));
         if constexpr (OP == ADD32) asm volatile("v_add_f32 %0, %1, %0" : "+v"(a[u]) : "v"(b));
         if constexpr (OP == PKADD32) asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(p[u]) : "v"(pb));
+        if constexpr (OP == DPP_WAVE_ROR) asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %0 wave_ror:1 row_mask:0xf bank_mask:0xf" : "+v"(a[u]));
+        if constexpr (OP == DPP_ROW_ROR) asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf" : "+v"(a[u]));
+        if constexpr (OP == DPP_BETWEEN_PK) {  // the product's ratio: 8 packed ops per DPP move, different registers
+          asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p[u]) : "v"(pb), "v"(pc));
+          if ((u & 7) == 7) asm volatile("v_mov_b32_dpp %0, %0 wave_ror:1 row_mask:0xf bank_mask:0xf" : "+v"(a[u]));
+        }
         if constexpr (OP == RSQ32) asm volatile("v_rsq_f32 %0, %0" : "+v"(a[u]));
         if constexpr (OP == RCP32) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[u]));
         if constexpr (OP == SQRT32) asm volatile("v_sqrt_f32 %0, %0" : "+v"(a[u]));
@@ -164,12 +172,20 @@ static void run(int ncu, int instr_per_iter_per_lane_chain, float* d_out, WaveRe
   }
 }
 
-int main() {
+int main(int argc, char** argv) {
+  const bool only_dpp = argc > 1 && !strcmp(argv[1], "dpp");
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
   int ncu = prop.multiProcessorCount;
   printf("device %s  CUs=%d  clockRate=%d kHz  arch=%s\n", prop.name, ncu, prop.clockRate, prop.gcnArchName);
   float* d_out; WaveRec* d_cyc;
   CK(hipMalloc(&d_out, (size_t)ncu * 8 * 256 * 4)); CK(hipMalloc(&d_cyc, (size_t)ncu * 8 * 4 * sizeof(WaveRec)));
+  if (only_dpp) {  // what a cross-lane move costs (K1s rotates its travelling sources with 14 of them per step)
+    run<PKFMA32>(ncu, U, d_out, d_cyc);
+    run<DPP_WAVE_ROR>(ncu, U, d_out, d_cyc);
+    run<DPP_ROW_ROR>(ncu, U, d_out, d_cyc);
+    run<DPP_BETWEEN_PK>(ncu, U + U / 8, d_out, d_cyc);
+    return 0;
+  }
   run<FMA32>(ncu, U, d_out, d_cyc);
   run<PKFMA32>(ncu, U, d_out, d_cyc);
   run<MUL32>(ncu, U, d_out, d_cyc);

@@ -6,7 +6,8 @@
 // ceiling of 62 % of the fp32 peak in the 20-flop convention, of which K1 reaches 96 %.  The distance, the rsqrt and the
 // inverse cube of a pair are the same for both bodies: evaluating the pair once costs
 //     3 sub, 3 fma (r2), v_rsq_f32, 2 mul (rinv^3), 2 mul (x G*m_j, x G*m_i), 3 fma (a_i), 3 fma (a_j)
-//   = 16 packed VALU + 2 v_rsq_f32 per two packed pairs = FOUR interactions  ->  20 SIMD cycles per 64 interactions.
+//   = 16 packed VALU + 2 v_rsq_f32 per two packed pairs = FOUR interactions  ->  20 SIMD cycles per 64 interactions
+//   (21.75 with the 14 DPP moves per 8 such sets that rotate the sources: a ceiling of 0.92 of peak).
 // The obstacle on a GPU is a_j: the partial sum of a source is spread over the lanes that hold its partners (the reference
 // throws atomics at it, hw5.cu:211-213).  Here it is solved systolically inside a wave, with no atomics anywhere:
 //   * a lane owns P = 4 packed pairs of TARGETS in registers (as in K1) and one packed pair of SOURCES that travels:
