@@ -18,7 +18,7 @@ HDR  := $(SRC)/nbody_kernels.h $(SRC)/nbody_f32_common.h include/nbody_amd.h inc
 all: lib hw5 nbody_bench nbconv stamps
 
 lib: $(LIB)
-HOSTSRC := $(SRC)/nbody_capi.cpp $(SRC)/nbody_scenario.cpp $(SRC)/nbody_solve.cpp $(SRC)/nbody_statefile.cpp $(SRC)/nbody_sharded.cpp
+HOSTSRC := $(SRC)/nbody_capi.cpp $(SRC)/nbody_launch.cpp $(SRC)/nbody_scenario.cpp $(SRC)/nbody_solve.cpp $(SRC)/nbody_statefile.cpp $(SRC)/nbody_sharded.cpp
 $(LIB): $(KSRC) $(HOSTSRC) $(HDR) $(SRC)/nbody_internal.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(KSRC) -x hip $(HOSTSRC) -lpthread -ldl
 

@@ -1,6 +1,7 @@
 // nbody_internal.h — what the translation units behind the C ABI share (not installed; the public surface is
 // include/nbody_amd.h, the kernel interface nbody_kernels.h):
-//   nbody_capi.cpp       contexts, state, nb_step / nb_accel, raw launches            run_step call sites, nbody.cc:116,129
+//   nbody_capi.cpp       contexts, state, nb_step / nb_accel                          run_step call sites, nbody.cc:116,129
+//   nbody_launch.cpp     raw launches on caller-owned HBM (nb_launch_*_f32, shared-pairs pair)
 //   nbody_scenario.cpp   scenario drivers: persistent engine, per-step engine, graph replay, the Problem-3 follower queue
 //                                                                                     nbody.cc:114-138 ; hw5.cu:366-404,489-508
 //   nbody_solve.cpp      nb_solve: the whole program                                  nbody.cc:91-146 ; hw5.cu:532-606

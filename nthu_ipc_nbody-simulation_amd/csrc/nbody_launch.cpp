@@ -1,0 +1,178 @@
+// nbody_launch.cpp — the raw launches of the C ABI on caller-owned HBM (device pointers + a hipStream_t): nb_launch_*_f32,
+// their plan / kernel-name / workspace queries, and the two-call form of the step in which several GPUs share the unordered
+// pairs of one system (nb_launch_pair_forces_f32 -> the host's reduce-scatter -> nb_launch_kick_drift_f32).  For hosts that
+// own device memory and the collectives themselves: bench.py, nbody_amd.distributed (one process per GPU, torch + RCCL).
+// The call site these replace is run_step at samples/nbody.cc:116,129 — one launch sequence per step and rank.
+#include <algorithm>
+
+#include "nbody_internal.h"
+
+using namespace nbk;
+using namespace nbi;
+
+extern "C" {
+
+// ---------------------------------------------------------------- raw launches on caller-owned HBM
+static int check_launch(const nb_launch_f32* a, bool accel_only) {
+    if (!a || !a->src || a->n_src <= 0 || a->n_tgt <= 0 || a->tgt_off < 0) return NB_ERR_INVALID;
+    if (!a->tgt && a->tgt_off + a->n_tgt > a->n_src) return NB_ERR_INVALID;  // targets are a window of the sources
+    if (!(a->eps2 > 0.f)) return NB_ERR_INVALID;
+    if (accel_only ? !a->acc : (!a->out || (a->acc64 ? (!a->pos64 || !a->vel64) : !a->vel))) return NB_ERR_INVALID;
+    const int r = a->targets_per_lane;
+    if (r != 0 && r != 2 && r != 4 && r != 8) return NB_ERR_INVALID;
+    if (a->j_split < 0 || a->j_split > MAX_JSPLIT) return NB_ERR_INVALID;
+    if (a->j_split > 1 && !a->workspace) return NB_ERR_INVALID;
+    if (a->source_path < 0 || a->source_path > 3) return NB_ERR_INVALID;
+    if (a->wg_size != 0 && a->wg_size != 256 && a->wg_size != 512 && a->wg_size != 1024) return NB_ERR_INVALID;
+    if (a->phase < NB_PHASE_WHOLE || a->phase > NB_PHASE_MIDDLE) return NB_ERR_INVALID;
+    if (a->src_begin || a->src_end) {  // a sub-range of the sources: whole 256-body tiles, except at the very end
+        if (a->src_begin < 0 || a->src_begin > a->src_end || a->src_end > a->n_src) return NB_ERR_INVALID;
+        if (a->src_begin % TILE || (a->src_end % TILE && a->src_end != a->n_src)) return NB_ERR_INVALID;
+    }
+    if (a->phase != NB_PHASE_WHOLE && (!a->workspace || a->workspace_bytes < nb_workspace_bytes_f32(a->n_tgt, a->acc64)))
+        return set_error(NB_ERR_INVALID, "a step cut into phases keeps its running sums in the workspace");
+    return NB_OK;
+}
+
+// partial-sum slots the caller's workspace holds behind the running sum and its compensation (records 0 and 1; 18 records
+// per target is the documented minimum; a larger workspace, up to 66 records, lets up to 64 slices go out in one launch)
+static int workspace_slots(const nb_launch_f32* a) {
+    if (!a->workspace || a->n_tgt <= 0) return 0;
+    const size_t rec = a->acc64 ? sizeof(double4) : sizeof(float4);
+    const long records = (long)((size_t)a->workspace_bytes / ((size_t)a->n_tgt * rec));
+    return (int)std::min<long>(std::max<long>(records - 2, 0), MAX_SLICES_PER_LAUNCH);
+}
+
+static F32Plan resolve_plan(const nb_launch_f32* a) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    // slices are planned for the sources this launch covers (a phase of a step covers a sub-range)
+    const long n_cover = (a->src_begin || a->src_end) ? std::max<long>(1, a->src_end - a->src_begin) : a->n_src;
+    F32Plan p = plan_f32(a->n_tgt, n_cover, cus, a->targets_per_lane, a->j_split, a->workspace != nullptr,
+                         a->source_path, a->wg_size);
+    // the caller's workspace must hold SLICES_PER_LAUNCH partial records + running sum + compensation per target
+    if (workspace_slots(a) < SLICES_PER_LAUNCH) p.j_split = 1;
+    // K1s (every unordered pair once): the whole system in one launch and a workspace of nb_workspace_bytes_sym_f32
+    const bool whole = a->phase == NB_PHASE_WHOLE && !a->src_begin && !a->src_end && !a->tgt && a->tgt_off == 0;
+    // (a forced register blocking, workgroup size or slice count asks for K1; with source_path 3 j_split = chunks)
+    if (a->targets_per_lane == 0 && a->wg_size == 0 && (a->j_split == 0 || a->source_path == 3))
+        (void)plan_symmetric(p, a->n_tgt, a->n_src, whole, a->workspace ? (size_t)a->workspace_bytes : 0, a->acc64 != 0, cus,
+                             a->source_path, a->j_split);
+    return p;
+}
+
+static int refuse_unmet_symmetric(const nb_launch_f32* a, const F32Plan& p) {
+    if (a->source_path == 3 && !p.symmetric)
+        return set_error(NB_ERR_INVALID, "source_path 3 (every unordered pair once) needs the whole system in one launch "
+                         "(n_tgt == n_src, tgt_off 0, no phases), n_src >= 131072 and a workspace of nb_workspace_bytes_sym_f32");
+    return NB_OK;
+}
+
+static F32Args to_args(const nb_launch_f32* a) {
+    F32Args k{};
+    k.src = (const float4*)a->src;
+    k.tgt = (const float4*)a->tgt;  // null -> src + tgt_off
+    k.out = (float4*)a->out;
+    k.vel = (float4*)a->vel;
+    k.pos64 = (double4*)a->pos64;
+    k.vel64 = (double4*)a->vel64;
+    k.acc = a->acc;
+    k.partial = a->workspace;
+    k.slots = workspace_slots(a);
+    k.n_src = a->n_src;
+    k.tgt_off = a->tgt_off;
+    k.n_tgt = a->n_tgt;
+    k.src_begin = a->src_begin;
+    k.src_end = a->src_end;
+    k.phase = a->phase;
+    k.eps2 = a->eps2;
+    k.dt = a->dt;
+    return k;
+}
+
+int nb_launch_step_f32(const nb_launch_f32* a, void* hip_stream) {
+    if (int rc = check_launch(a, false)) return rc;
+    const F32Plan plan = resolve_plan(a);
+    if (int rc = refuse_unmet_symmetric(a, plan)) return rc;
+    hipError_t e = (hipError_t)launch_f32(to_args(a), plan, a->acc64 != 0, false, (hipStream_t)hip_stream);
+    return e == hipSuccess ? NB_OK : fail_hip(nullptr, e, "nb_launch_step_f32");
+}
+
+int nb_launch_accel_f32(const nb_launch_f32* a, void* hip_stream) {
+    if (int rc = check_launch(a, true)) return rc;
+    const F32Plan plan = resolve_plan(a);
+    if (int rc = refuse_unmet_symmetric(a, plan)) return rc;
+    hipError_t e = (hipError_t)launch_f32(to_args(a), plan, a->acc64 != 0, true, (hipStream_t)hip_stream);
+    return e == hipSuccess ? NB_OK : fail_hip(nullptr, e, "nb_launch_accel_f32");
+}
+
+const char* nb_kernel_name_f32(const nb_launch_f32* a, int accel_only) {
+    if (!a) return "";
+    return kernel_name_f32(resolve_plan(a), a->acc64 != 0, accel_only != 0);
+}
+
+int nb_plan_f32(const nb_launch_f32* a, int* targets_per_lane, int* j_split, int* wg_size) {
+    if (!a || a->n_src <= 0 || a->n_tgt <= 0) return NB_ERR_INVALID;
+    F32Plan p = resolve_plan(a);
+    if (targets_per_lane) *targets_per_lane = p.targets_per_lane;
+    if (j_split) *j_split = p.j_split;
+    if (wg_size) *wg_size = p.wg_size;
+    return NB_OK;
+}
+
+// ---- several GPUs sharing the unordered pairs of one system (hosts that own the collectives: nbody_amd.distributed)
+static bool shared_pairs_shape(const nb_launch_f32* a, F32SymShape* sh) {
+    if (!a || a->n_tgt <= 0 || a->n_src <= 0 || a->n_src % a->n_tgt || a->tgt_off % a->n_tgt) return false;
+    const int P = (int)(a->n_src / a->n_tgt), rank = (int)(a->tgt_off / a->n_tgt);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (rank >= P || !sym_sharded_ok(a->n_src, P, cus, a->acc64 != 0, sh)) return false;
+    sh->b0 = rank * sh->nb;
+    return true;
+}
+
+int nb_launch_pair_forces_f32(const nb_launch_f32* a, void* hip_stream) {
+    F32SymShape sh{};
+    if (!a || !a->src || !a->acc || !a->workspace || !(a->eps2 > 0.f) || a->tgt || a->phase != NB_PHASE_WHOLE || a->src_begin ||
+        a->src_end || !shared_pairs_shape(a, &sh))
+        return set_error(NB_ERR_INVALID, "nb_launch_pair_forces_f32: the shard must be whole 4096-body superblocks of a system of "
+                         ">= 131072 bodies (n_src = ranks * n_tgt, tgt_off = rank * n_tgt), with acc and a workspace");
+    if ((size_t)a->workspace_bytes < sym_workspace_bytes(sh, a->acc64 != 0))
+        return set_error(NB_ERR_INVALID, "nb_launch_pair_forces_f32: workspace smaller than nb_workspace_bytes_shared_pairs_f32");
+    hipError_t e = (hipError_t)launch_f32_sym(to_args(a), sh, a->acc64 != 0, 2, (hipStream_t)hip_stream);
+    return e == hipSuccess ? NB_OK : fail_hip(nullptr, e, "nb_launch_pair_forces_f32");
+}
+
+int nb_launch_kick_drift_f32(const nb_launch_f32* a, int parts, void* hip_stream) {
+    if (!a || !a->src || !a->out || !a->acc || a->n_tgt <= 0 || a->tgt_off < 0 || a->tgt_off + a->n_tgt > a->n_src || parts < 1 ||
+        (a->acc64 ? (!a->pos64 || !a->vel64) : !a->vel))
+        return NB_ERR_INVALID;
+    hipError_t e = (hipError_t)launch_kick_drift_f32(to_args(a), a->acc64 != 0, parts, (hipStream_t)hip_stream);
+    return e == hipSuccess ? NB_OK : fail_hip(nullptr, e, "nb_launch_kick_drift_f32");
+}
+
+int64_t nb_workspace_bytes_shared_pairs_f32(int64_t n_src, int ranks, int acc64) {
+    if (ranks < 2 || n_src <= 0 || n_src % ranks) return 0;
+    nb_launch_f32 a{};
+    a.n_src = n_src;
+    a.n_tgt = n_src / ranks;
+    a.acc64 = acc64;
+    F32SymShape sh{};
+    return shared_pairs_shape(&a, &sh) ? (int64_t)sym_workspace_bytes(sh, acc64 != 0) : 0;
+}
+
+int64_t nb_workspace_bytes_sym_f32(int64_t n, int acc64) {
+    if (n < SYM_MIN_N) return 0;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    F32SymShape sh = sym_shape(n, cus);
+    sh.chunks = std::max(sh.chunks, 8);  // room for up to 8 workgroups per superblock (j_split with source_path 3)
+    const size_t b = sym_workspace_bytes(sh, acc64 != 0);
+    return b <= SYM_MAX_WORKSPACE ? (int64_t)b : 0;
+}
+
+int64_t nb_workspace_bytes_f32(int64_t n_tgt, int acc64) {
+    return (int64_t)(SLICES_PER_LAUNCH + 2) * n_tgt * (int64_t)(acc64 ? sizeof(double4) : sizeof(float4));
+}
+
+}  // extern "C"
