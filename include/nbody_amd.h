@@ -295,6 +295,12 @@ int64_t nb_workspace_bytes_sym_f32(int64_t n, int acc64);
 int nb_launch_pair_forces_f32(const nb_launch_f32* a, void* hip_stream);
 int nb_launch_kick_drift_f32(const nb_launch_f32* a, int parts, void* hip_stream);
 int64_t nb_workspace_bytes_shared_pairs_f32(int64_t n_src, int ranks, int acc64);
+/* host-only replay of K1s' pair schedule for n bodies on `ranks` GPUs of n_cus compute units (ranks 1 = the one-GPU launch),
+ * with the index arithmetic the kernels share: every unordered pair of 4096-body superblocks met exactly once in every tile
+ * phase over all ranks and workgroups, no slot region written twice, the reducer's slot list equal to what was written.
+ * Needs no GPU — it is how the 8-GPU shapes are checked on machines that have one or none.  NB_OK, or NB_ERR_STATE with the
+ * first inconsistency in msg */
+int nb_selftest_pair_schedule(int64_t n, int n_cus, int ranks, int acc64, char* msg, int msg_len);
 
 /* ---- index-sharded multi-GPU stepping: ONE process, P GPUs of a node, RCCL over xGMI (csrc/nbody_sharded.cpp) ----
  * The reference's only multi-GPU use is task parallelism (hw5.cu:564-567,587-588); this is the data-parallel scheme of

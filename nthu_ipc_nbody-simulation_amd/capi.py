@@ -102,6 +102,7 @@ SYMBOLS = {
     "nb_launch_pair_forces_f32": (C.c_int, [C.POINTER(NbLaunchF32), C.c_void_p]),
     "nb_launch_kick_drift_f32": (C.c_int, [C.POINTER(NbLaunchF32), C.c_int, C.c_void_p]),
     "nb_workspace_bytes_shared_pairs_f32": (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
+    "nb_selftest_pair_schedule": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]),
     "nb_sharded_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int64, C.c_int, C.c_double,
                                    C.c_double, C.c_double, C.c_int]),
     "nb_sharded_destroy": (C.c_int, [C.c_void_p]),
@@ -569,6 +570,14 @@ def launch_kick_drift_f32(src_ptr, out_ptr, n_src, tgt_off, n_tgt, dt, stream, a
 def workspace_bytes_shared_pairs_f32(n_src, ranks, acc64=False):
     """Workspace of nb_launch_pair_forces_f32; 0 = the ranks cannot share the unordered pairs of this system."""
     return lib().nb_workspace_bytes_shared_pairs_f32(n_src, ranks, int(acc64))
+
+
+def selftest_pair_schedule(n, n_cus=256, ranks=1, acc64=False):
+    """Host-only replay of K1s' pair schedule (no GPU needed); raises NBodyError with the first inconsistency."""
+    buf = C.create_string_buffer(256)
+    rc = lib().nb_selftest_pair_schedule(n, n_cus, ranks, int(acc64), buf, len(buf))
+    if rc != NB_OK:
+        raise NBodyError(rc, "nb_selftest_pair_schedule", buf.value.decode())
 
 
 def plan_f32(n_src, n_tgt, acc64=False, targets_per_lane=0, j_split=0, workspace_bytes=0, source_path=0, wg_size=0):

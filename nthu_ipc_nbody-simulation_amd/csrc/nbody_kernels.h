@@ -71,6 +71,59 @@ __host__ __device__ inline int sym_tail_slot(const F32SymShape& s, bool acc64, i
     return sym_own_slots(s, acc64) + (s.by_super ? s.nb : s.B / 2) + chunk;
 }
 __host__ __device__ inline int sym_total_slots(const F32SymShape& s, bool acc64) { return sym_tail_slot(s, acc64, s.chunks); }
+
+// ---- the pair schedule, shared by the force kernel, the reducer and the host-side self-test (nb_selftest_pair_schedule)
+constexpr int SYM_NT = SYM_SB / 128;  // tile phases of one work unit (a wave meets one 128-source tile per phase)
+// rounds of I-superblock b: J = b + r (mod B), r = 1 .. (B-1)/2, plus r = B/2 for the lower half when B is even
+__host__ __device__ inline int sym_rounds(int B, int b) { return (B - 1) / 2 + ((B % 2 == 0 && b < B / 2) ? 1 : 0); }
+// the phases [q_lo, q_hi) of superblock b's work (unit u = q / SYM_NT: 0 = the diagonal block, r = round r) that
+// workgroup `chunk` executes.  The cut points are those of a superblock with the most rounds, the same for every b.
+__host__ __device__ inline void sym_chunk_range(const F32SymShape& s, int b, int chunk, long* q_lo, long* q_hi) {
+    const long Q = (long)SYM_NT * (1 + s.B / 2), q_end = (long)SYM_NT * (1 + sym_rounds(s.B, b));
+    const long lo = chunk * Q / s.chunks, hi = (chunk + 1) * Q / s.chunks;
+    *q_lo = lo < q_end ? lo : q_end;
+    *q_hi = hi < q_end ? hi : q_end;
+}
+// the piece that starts at phase q: unit u, phases [ph0, ph1) of it; returns the phase the next piece starts at
+__host__ __device__ inline long sym_piece(long q, long q_hi, int* u, int* ph0, int* ph1) {
+    *u = (int)(q / SYM_NT);
+    *ph0 = (int)(q % SYM_NT);
+    *ph1 = (q_hi - q) < (SYM_NT - *ph0) ? *ph0 + (int)(q_hi - q) : SYM_NT;
+    return q + (*ph1 - *ph0);
+}
+// slot of the image a piece of round u (u >= 1) leaves: the second part of a round that straddles two workgroups goes to
+// the tail slot of the workgroup that starts with it
+__host__ __device__ inline int sym_piece_slot(const F32SymShape& s, bool acc64, int b, int chunk, int u, int ph0) {
+    return ph0 ? sym_tail_slot(s, acc64, chunk) : sym_own_slots(s, acc64) + (s.by_super ? b - s.b0 : u - 1);
+}
+// every slot of this launch that holds a contribution for the bodies of superblock J, in the order the reducer adds them
+template <class F>
+__host__ __device__ inline void sym_for_each_slot_of(const F32SymShape& s, bool acc64, int J, F&& f) {
+    const int B = s.B, own = sym_own_slots(s, acc64);
+    if (J >= s.b0 && J < s.b0 + s.nb)
+        for (int c = 0; c < own; ++c) f(c);  // own sums (fp64 sums: the float and the float of its remainder)
+    if (s.by_super) {  // a slot per producing I-superblock of this launch
+        for (int k = 0; k < s.nb; ++k) {
+            const int b = s.b0 + k, r = ((J - b) % B + B) % B;
+            if (r >= 1 && r <= sym_rounds(B, b)) f(own + k);
+        }
+    } else {  // a slot per round: producer b = J - r
+        for (int r = 1; r <= B / 2; ++r) {
+            const int b = ((J - r) % B + B) % B;
+            if (b >= s.b0 && b < s.b0 + s.nb && r <= sym_rounds(B, b)) f(own + r - 1);
+        }
+    }
+    // second parts of the rounds that straddle two workgroups: chunk c starts inside round q_c / SYM_NT (the same for every
+    // superblock), whose producer for superblock J is J - that round
+    const long Q = (long)SYM_NT * (1 + B / 2);
+    for (int c = 1; c < s.chunks; ++c) {
+        const long q = c * Q / s.chunks;
+        const int r = (int)(q / SYM_NT);
+        if (q % SYM_NT == 0 || r == 0) continue;  // cut at a unit boundary, or inside the diagonal block (no image)
+        const int b = ((J - r) % B + B) % B;
+        if (b >= s.b0 && b < s.b0 + s.nb && r <= sym_rounds(B, b)) f(sym_tail_slot(s, acc64, c));
+    }
+}
 F32SymShape sym_shape(long n, int n_cus, int b0 = 0, int nb = 0, int force_chunks = 0);
 size_t sym_workspace_bytes(const F32SymShape& s, bool acc64);
 // mode 0: force + kick-drift of the whole system; 1: accelerations out; 2: this launch's partial force out (a.acc:

@@ -50,11 +50,9 @@ __device__ __forceinline__ float rot1(float x) {  // lane l <- lane l-1, wave-wi
 }
 __device__ __forceinline__ v2f rot(v2f v) { return (v2f){rot1(v.x), rot1(v.y)}; }
 
-__host__ __device__ inline int sym_rounds(int B, int b) { return (B - 1) / 2 + ((B % 2 == 0 && b < B / 2) ? 1 : 0); }
-
 }  // namespace
 
-constexpr int P = SYM_P, WGS = SYM_WGS, NW = WGS / 64, R = 2 * P, SB = SYM_SB, NT = SB / 128;
+constexpr int P = SYM_P, WGS = SYM_WGS, NW = WGS / 64, R = 2 * P, SB = SYM_SB, NT = SYM_NT;
 static_assert(NT == NW * P && (NT & (NT - 1)) == 0, "tiles per superblock");
 
 template <bool ACC64>
@@ -150,17 +148,13 @@ __global__ __launch_bounds__(WGS, 1) void nbody_force_sym_f32(F32Args a, F32SymS
     // partial images: the first part in the round's regular slot, the second in the TAIL slot of the workgroup that
     // starts with it — one tail slot per chunk suffices because, for a given chunk, it is the same round for every
     // superblock, so the images land on different J-superblocks of that slot.
-    const int units = 1 + sym_rounds(B, b);
-    const long Q = (long)NT * (1 + B / 2);  // phases of a superblock with the most rounds
-    const long q_lo = chunk * Q / sh.chunks;
-    const long q_end = (long)NT * units;
-    const long q_hi = (chunk + 1) * Q / sh.chunks < q_end ? (chunk + 1) * Q / sh.chunks : q_end;
+    long q, q_hi;
+    sym_chunk_range(sh, b, chunk, &q, &q_hi);
     v2f ajx, ajy, ajz;
     bool lds_clean = false;
-    for (long q = q_lo; q < q_hi;) {
-        const int u = (int)(q / NT), ph0 = (int)(q % NT);
-        const int ph1 = (q_hi - q) < (NT - ph0) ? ph0 + (int)(q_hi - q) : NT;
-        q += ph1 - ph0;
+    while (q < q_hi) {
+        int u, ph0, ph1;
+        q = sym_piece(q, q_hi, &u, &ph0, &ph1);
         if (u == 0) {  // the superblock against itself, without the symmetric half; the self pair adds exactly +0
             float4 j0 = body(ibase + (long)ph0 * 128 + lane), j1 = body(ibase + (long)ph0 * 128 + 64 + lane);
             for (int k = ph0; k < ph1; ++k) {
@@ -195,8 +189,7 @@ __global__ __launch_bounds__(WGS, 1) void nbody_force_sym_f32(F32Args a, F32SymS
             j0 = n0; j1 = n1;
             __syncthreads();  // phases must not overlap: the next one touches tiles other waves have just updated
         }
-        const int slot = ph0 ? sym_tail_slot(sh, ACC64, chunk)
-                             : sym_own_slots(sh, ACC64) + (sh.by_super ? b - sh.b0 : u - 1);
+        const int slot = sym_piece_slot(sh, ACC64, b, chunk, u, ph0);
         float* out = (float*)a.partial + (long)slot * 3 * sh.npad + jbase;  // a slot = three planes x, y, z of npad floats
 #pragma unroll
         for (int k = 0; k < R; ++k) {
@@ -233,10 +226,9 @@ template <bool ACC64, int MODE>
 __global__ __launch_bounds__(WG) void nbody_reduce_sym_f32(F32Args a, F32SymShape sh) {
     const long i = (long)blockIdx.x * WG + threadIdx.x;
     if (i >= a.n_src) return;
-    const int B = sh.B, J = (int)(i / SB);
+    const int J = (int)(i / SB);
     const float* ws = (const float*)a.partial + i;  // slot s, component c of this body: ws[(3 s + c) * npad]
     const long plane = sh.npad;
-    const int own = sym_own_slots(sh, ACC64);
     double dx = 0, dy = 0, dz = 0;                          // ACC64
     float rx = 0, ry = 0, rz = 0, kx = 0, ky = 0, kz = 0;   // F32: Kahan
     auto add = [&](long slot) {
@@ -248,30 +240,7 @@ __global__ __launch_bounds__(WG) void nbody_reduce_sym_f32(F32Args a, F32SymShap
         u = y - ky; v = ry + u; ky = (v - ry) - u; ry = v;
         u = z - kz; v = rz + u; kz = (v - rz) - u; rz = v;
     };
-    if (J >= sh.b0 && J < sh.b0 + sh.nb)
-        for (int c = 0; c < own; ++c) add(c);  // (fp64 sums: the float and the float of its remainder, one after the other)
-    if (sh.by_super) {  // a slot per producing I-superblock of this launch
-        for (int k = 0; k < sh.nb; ++k) {
-            const int b = sh.b0 + k;
-            const int r = ((J - b) % B + B) % B;
-            if (r >= 1 && r <= sym_rounds(B, b)) add(own + k);
-        }
-    } else {  // a slot per round: producer b = J - r
-        for (int r = 1; r <= B / 2; ++r) {
-            const int b = ((J - r) % B + B) % B;
-            if (b >= sh.b0 && b < sh.b0 + sh.nb && r <= sym_rounds(B, b)) add(own + r - 1);
-        }
-    }
-    // second parts of the rounds that straddle two workgroups: chunk c starts inside round q_c / NT (the same for every
-    // superblock), whose producer for this body's superblock is J - that round
-    const long Q = (long)NT * (1 + B / 2);
-    for (int c = 1; c < sh.chunks; ++c) {
-        const long q = c * Q / sh.chunks;
-        const int r = (int)(q / NT);
-        if (q % NT == 0 || r == 0) continue;  // cut at a unit boundary, or inside the diagonal block (no image)
-        const int b = ((J - r) % B + B) % B;
-        if (b >= sh.b0 && b < sh.b0 + sh.nb && r <= sym_rounds(B, b)) add(sym_tail_slot(sh, ACC64, c));
-    }
+    sym_for_each_slot_of(sh, ACC64, J, add);
     if (MODE == 2) {
         if (ACC64) ((double4*)a.acc)[i] = make_double4(dx, dy, dz, 0.0);
         else ((float4*)a.acc)[i] = make_float4(rx, ry, rz, 0.f);

@@ -4,6 +4,8 @@
 // own device memory and the collectives themselves: bench.py, nbody_amd.distributed (one process per GPU, torch + RCCL).
 // The call site these replace is run_step at samples/nbody.cc:116,129 — one launch sequence per step and rank.
 #include <algorithm>
+#include <cstdint>
+#include <vector>
 
 #include "nbody_internal.h"
 
@@ -159,6 +161,81 @@ int64_t nb_workspace_bytes_shared_pairs_f32(int64_t n_src, int ranks, int acc64)
     a.acc64 = acc64;
     F32SymShape sh{};
     return shared_pairs_shape(&a, &sh) ? (int64_t)sym_workspace_bytes(sh, acc64 != 0) : 0;
+}
+
+// Host-only replay of K1s' pair schedule for `n` bodies on `ranks` GPUs of `n_cus` compute units each (ranks = 1: the
+// one-GPU launch) with the very index arithmetic the kernels use (sym_chunk_range / sym_piece / sym_piece_slot /
+// sym_for_each_slot_of, nbody_kernels.h).  Checks, for shapes no box here can run (8 GPUs): every unordered pair of
+// superblocks is met in all its tile phases exactly once over all ranks and workgroups, and every diagonal block once; no
+// two workgroups of a launch write the same (slot, J-superblock) region; the slots the reducer adds for a superblock are
+// exactly the ones that were written for it; the workspace is large enough.  0 = consistent; else NB_ERR_STATE with the first
+// inconsistency in msg.
+int nb_selftest_pair_schedule(int64_t n, int n_cus, int ranks, int acc64, char* msg, int msg_len) {
+    auto say = [&](const char* fmt, long a = 0, long b = 0, long c = 0, long d = 0) {
+        if (msg && msg_len > 0) snprintf(msg, (size_t)msg_len, fmt, a, b, c, d);
+        return NB_ERR_STATE;
+    };
+    if (msg && msg_len > 0) msg[0] = 0;
+    if (n <= 0 || n_cus <= 0 || ranks < 1) return NB_ERR_INVALID;
+    F32SymShape base{};
+    if (ranks == 1) base = sym_shape(n, n_cus);
+    else if (!sym_sharded_ok(n, ranks, n_cus, acc64 != 0, &base)) return say("the %ld ranks cannot share the pairs of %ld bodies", ranks, n);
+    const int B = base.B;
+    const bool a64 = acc64 != 0;
+    try {
+        // phases[b * B + J]: bit mask of the tile phases in which I-superblock b has met superblock J (J == b: diagonal)
+        std::vector<uint32_t> phases((size_t)B * B, 0u);
+        for (int rank = 0; rank < ranks; ++rank) {
+            F32SymShape sh = base;
+            sh.b0 = rank * sh.nb;
+            const int slots = sym_total_slots(sh, a64);
+            if ((size_t)slots * (size_t)sh.npad * 3 * sizeof(float) != sym_workspace_bytes(sh, a64)) return say("workspace size formula");
+            std::vector<uint8_t> written((size_t)slots * B, 0);  // (slot, J-superblock) regions written by this launch
+            for (int b = sh.b0; b < sh.b0 + sh.nb; ++b)
+                for (int chunk = 0; chunk < sh.chunks; ++chunk) {
+                    if (written[(size_t)(chunk * (a64 ? 2 : 1)) * B + b]++) return say("own slot of chunk %ld written twice for superblock %ld", chunk, b);
+                    if (a64) written[(size_t)(2 * chunk + 1) * B + b]++;
+                    long q, q_hi;
+                    sym_chunk_range(sh, b, chunk, &q, &q_hi);
+                    while (q < q_hi) {
+                        int u, ph0, ph1;
+                        q = sym_piece(q, q_hi, &u, &ph0, &ph1);
+                        if (ph1 <= ph0 || ph1 > SYM_NT || u > sym_rounds(B, b)) return say("bad piece: unit %ld phases %ld..%ld of superblock %ld", u, ph0, ph1, b);
+                        const int J = (b + u) % B;
+                        for (int ph = ph0; ph < ph1; ++ph) {
+                            uint32_t& m = phases[(size_t)b * B + J];
+                            if (m & (1u << ph)) return say("superblock %ld meets %ld twice in phase %ld", b, J, ph);
+                            m |= 1u << ph;
+                        }
+                        if (u == 0) continue;
+                        const int slot = sym_piece_slot(sh, a64, b, chunk, u, ph0);
+                        if (slot < sym_own_slots(sh, a64) || slot >= slots) return say("slot %ld out of range (superblock %ld, round %ld)", slot, b, u);
+                        if (written[(size_t)slot * B + J]++) return say("slot %ld written twice for superblock %ld (by %ld, round %ld)", slot, J, b, u);
+                    }
+                }
+            for (int J = 0; J < B; ++J) {  // the reducer's view of this launch
+                std::vector<uint8_t> added((size_t)slots, 0);
+                int bad = -1;
+                sym_for_each_slot_of(sh, a64, J, [&](long slot) {
+                    if (slot < 0 || slot >= slots || added[(size_t)slot]++) bad = (int)slot;
+                });
+                if (bad >= 0) return say("reducer adds slot %ld twice or out of range for superblock %ld (rank %ld)", bad, J, rank);
+                for (int sl = 0; sl < slots; ++sl)
+                    if ((added[(size_t)sl] != 0) != (written[(size_t)sl * B + J] != 0))
+                        return say("slot %ld of superblock %ld (rank %ld): written %ld but the reducer disagrees", sl, J, rank, written[(size_t)sl * B + J]);
+            }
+        }
+        const uint32_t all = SYM_NT >= 32 ? 0xffffffffu : ((1u << SYM_NT) - 1);
+        for (int b = 0; b < B; ++b)
+            for (int J = b; J < B; ++J) {
+                const uint32_t f = phases[(size_t)b * B + J], r = phases[(size_t)J * B + b];
+                if (J == b ? f != all : !((f == all && r == 0) || (f == 0 && r == all)))
+                    return say("superblocks %ld and %ld: phase masks %ld / %ld (each unordered pair once, all phases)", b, J, (long)f, (long)r);
+            }
+    } catch (...) {
+        return NB_ERR_NOMEM;
+    }
+    return NB_OK;
 }
 
 int64_t nb_workspace_bytes_sym_f32(int64_t n, int acc64) {

@@ -280,3 +280,40 @@ def test_bench_multi_gpu_command_needs_no_launcher():
                        env=env, timeout=300)
     assert p.returncode != 0 and "nb_sharded_create" in p.stderr and "no usable HIP device" in p.stderr
     assert "torch.distributed.run" not in p.stderr and not p.stdout.strip()
+
+
+def test_pair_schedule_of_the_symmetric_kernel_on_shapes_no_box_here_can_run(nb):
+    """K1s evaluates every unordered pair of bodies once: every unordered pair of 4096-body superblocks must be met exactly
+    once, in all 32 tile phases, over all GPUs, superblocks and workgroups; no slot region may be written twice; the reducer
+    must add exactly the slots that were written.  nb_selftest_pair_schedule replays the schedule on the host with the index
+    functions the kernels themselves call (csrc/nbody_kernels.h: sym_chunk_range / sym_piece / sym_piece_slot /
+    sym_for_each_slot_of) — needs no GPU, so the 8-GPU shapes of BASELINE configs[2]-[4] are checked here."""
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+    c = nb.capi
+    SB = 4096
+    for n, cus, ranks, acc64 in [(1 << 20, 256, 1, False), (1 << 20, 256, 2, False), (1 << 20, 256, 4, True),
+                                 (1 << 20, 256, 8, False),           # configs[2] at 1, 2, 4, 8 GPUs
+                                 (1 << 22, 256, 8, False),           # configs[3]
+                                 (1 << 24, 256, 8, True),            # configs[4]
+                                 (131072 + 5, 256, 1, True), (196608, 256, 1, False), (1500000, 256, 1, False),
+                                 (67 * SB, 256, 1, False), (1 << 18, 304, 1, False), (15 * SB * 8, 256, 3, False)]:
+        c.selftest_pair_schedule(n, cus, ranks, acc64)
+    with pytest.raises(c.NBodyError, match="cannot share"):
+        c.selftest_pair_schedule((1 << 20) + SB, 256, 8)  # shards are not whole superblocks
+    with pytest.raises(c.NBodyError, match="cannot share"):
+        c.selftest_pair_schedule(1 << 16, 256, 2)         # too few bodies
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.integers(32, 700), st.integers(0, SB - 1), st.sampled_from([64, 104, 228, 256, 304]), st.booleans())
+    def one_gpu(blocks, ragged, cus, acc64):
+        c.selftest_pair_schedule(blocks * SB - ragged, cus, 1, acc64)
+
+    @settings(max_examples=40, deadline=None)
+    @given(st.integers(2, 8), st.integers(4, 96), st.sampled_from([64, 256, 304]), st.booleans())
+    def several_gpus(ranks, per_rank, cus, acc64):
+        if ranks * per_rank * SB >= 131072:
+            c.selftest_pair_schedule(ranks * per_rank * SB, cus, ranks, acc64)
+
+    one_gpu()
+    several_gpus()
