@@ -290,9 +290,9 @@ int nbi::create_context(nb_context** out, const nb_config* cfg, hipStream_t borr
             c->partial_slots = (int)std::max<long>(SLICES_PER_LAUNCH, std::min<long>(std::min<long>(js, MAX_SLICES_PER_LAUNCH), cap));
             c->partial_bytes = (size_t)(c->partial_slots + 2) * n * rec;
         }
-        if (c->n >= SYM_MIN_N) {  // K1s: a slot per superblock round, B/2 + 1 records per body (2.2 GB at 2^20)
-            const size_t sym = sym_workspace_bytes(sym_shape(c->n, c->n_cus), cfg->precision == NB_F32_ACC64);
-            if (sym <= SYM_MAX_WORKSPACE) c->partial_bytes = std::max(c->partial_bytes, sym);
+        if (c->n >= SYM_MIN_N) {  // K1s: a slot per superblock round (1.6 GB at 2^20), in batches beyond 32 GiB of them
+            const F32SymBatches kb = sym_batches(c->n, c->n_cus, cfg->precision == NB_F32_ACC64);
+            if (kb.count >= 1 && kb.bytes <= SYM_MAX_WORKSPACE) c->partial_bytes = std::max(c->partial_bytes, kb.bytes);
         }
         if (c->partial_bytes) NB_HIP(c, hipMalloc(&c->partial, c->partial_bytes));
         if (cfg->precision == NB_F32_ACC64) {

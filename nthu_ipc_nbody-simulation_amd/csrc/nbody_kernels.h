@@ -126,9 +126,23 @@ __host__ __device__ inline void sym_for_each_slot_of(const F32SymShape& s, bool 
 }
 F32SymShape sym_shape(long n, int n_cus, int b0 = 0, int nb = 0, int force_chunks = 0);
 size_t sym_workspace_bytes(const F32SymShape& s, bool acc64);
+// One GPU: up to SYM_WHOLE_WORKSPACE of slots the whole system is ONE launch (a slot per round, B/2 of them).  Larger systems
+// go in batches of `nb` I-superblocks — each a launch like one rank of a multi-GPU step, a slot per I-superblock of the batch —
+// whose reducers add up a running force kept behind the slots; the last one runs the epilogue.  bytes = workspace needed.
+constexpr size_t SYM_WHOLE_WORKSPACE = (size_t)32 << 30;  // 26 GB at n = 2^22 is the last system taken in one launch
+constexpr size_t SYM_BATCH_WORKSPACE = (size_t)64 << 30;  // budget of a batched step: n = 2^23 -> 4 x 512 superblocks, 52 GB (103 GB
+                                                          // in one launch), 2^24 -> 16 x 256
+struct F32SymBatches {
+    int nb = 0;       // I-superblocks per batch (= B when count == 1)
+    int count = 0;    // 0: K1s does not apply (too small, or no batch fits SYM_MAX_WORKSPACE)
+    size_t bytes = 0;
+};
+F32SymBatches sym_batches(long n, int n_cus, bool acc64);
 // mode 0: force + kick-drift of the whole system; 1: accelerations out; 2: this launch's partial force out (a.acc:
 // float4[n] / double4[n]) for the reduce-scatter of a multi-GPU step.  a.partial = the slot workspace.
 int launch_f32_sym(const F32Args& a, const F32SymShape& s, bool acc64, int mode, hipStream_t stream);  // hipError_t
+// the whole system on one GPU, in kb.count launches (mode 0 or 1)
+int launch_f32_sym_batched(const F32Args& a, const F32SymBatches& kb, int n_cus, bool acc64, int mode, hipStream_t stream);
 // kick-drift of targets [tgt_off, tgt_off + n_tgt) from accelerations arriving as a.acc[parts][n_tgt], added in order
 int launch_kick_drift_f32(const F32Args& a, bool acc64, int parts, hipStream_t stream);
 // several GPUs sharing the pairs of one system: every GPU owns whole superblocks (n % (P * SYM_SB) == 0), n >= SYM_MIN_N,
@@ -141,7 +155,9 @@ struct F32Plan {
     bool sgpr_sources = true;  // sources via scalar loads into SGPRs (default) instead of the LDS tile
     int wg_size = 256;         // threads per workgroup: 256, 512 (R = 8) or 1024 (R = 4); LDS path: 256
     bool symmetric = false;    // K1s instead of K1 (whole-system launches with a slot workspace; plan_symmetric)
-    F32SymShape sym{};
+    F32SymShape sym{};         // shape of the (first) launch
+    F32SymBatches sym_batches{};
+    int sym_cus = 256;
 };
 // K1s for this launch?  Needs the whole system as targets AND sources in one launch (n_tgt == n_src, no phases, no
 // travelling target block), SYM_MIN_N bodies or more and a workspace of sym_workspace_bytes.  source_path: 0 = auto (yes

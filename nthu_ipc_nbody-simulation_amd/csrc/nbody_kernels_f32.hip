@@ -325,8 +325,14 @@ static int launch_p(const F32Args& a, int js, bool acc64, bool accel_only, hipSt
 }
 
 // valid (source path, workgroup size, targets per lane) combinations; anything else is refused
+static int launch_f32_sym_batched_or_whole(const F32Args& a, const F32Plan& plan, bool acc64, bool accel_only, hipStream_t stream) {
+    if (plan.sym_batches.count > 1) return launch_f32_sym_batched(a, plan.sym_batches, plan.sym_cus, acc64, accel_only ? 1 : 0, stream);
+    return launch_f32_sym(a, plan.sym, acc64, accel_only ? 1 : 0, stream);
+}
+
 int launch_f32(const F32Args& a, const F32Plan& plan, bool acc64, bool accel_only, hipStream_t stream) {
-    if (plan.symmetric) return launch_f32_sym(a, plan.sym, acc64, accel_only ? 1 : 0, stream);  // K1s: every unordered pair once
+    if (plan.symmetric)  // K1s: every unordered pair once (in several launches when the system is too large for a slot per round)
+        return launch_f32_sym_batched_or_whole(a, plan, acc64, accel_only, stream);
     const int R = plan.targets_per_lane, js = plan.j_split, wg = plan.wg_size;
     if (!plan.sgpr_sources) {
         if (wg != 256) return (int)hipErrorInvalidValue;

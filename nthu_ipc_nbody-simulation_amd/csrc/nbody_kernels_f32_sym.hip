@@ -222,8 +222,9 @@ __global__ __launch_bounds__(WGS, 1) void nbody_force_sym_f32(F32Args a, F32SymS
 // add the slots that hold a contribution of THIS launch for body i, in a fixed order, then the epilogue.
 // MODE 0: kick-drift; 1: accelerations out; 2: the launch's partial force out (float4 / double4 [n], for a reduce-scatter
 // over the GPUs that share the pairs)
+// `carry` (float4[n], double4 with ACC64; may alias the MODE 2 output): sums of earlier batches of the same step to start from
 template <bool ACC64, int MODE>
-__global__ __launch_bounds__(WG) void nbody_reduce_sym_f32(F32Args a, F32SymShape sh) {
+__global__ __launch_bounds__(WG) void nbody_reduce_sym_f32(F32Args a, F32SymShape sh, const void* carry) {
     const long i = (long)blockIdx.x * WG + threadIdx.x;
     if (i >= a.n_src) return;
     const int J = (int)(i / SB);
@@ -231,6 +232,10 @@ __global__ __launch_bounds__(WG) void nbody_reduce_sym_f32(F32Args a, F32SymShap
     const long plane = sh.npad;
     double dx = 0, dy = 0, dz = 0;                          // ACC64
     float rx = 0, ry = 0, rz = 0, kx = 0, ky = 0, kz = 0;   // F32: Kahan
+    if (carry) {
+        if (ACC64) { const double4 c = ((const double4*)carry)[i]; dx = c.x; dy = c.y; dz = c.z; }
+        else { const float4 c = ((const float4*)carry)[i]; rx = c.x; ry = c.y; rz = c.z; }
+    }
     auto add = [&](long slot) {
         const float* p = ws + slot * 3 * plane;
         const float x = p[0], y = p[plane], z = p[2 * plane];
@@ -283,11 +288,14 @@ bool plan_symmetric(F32Plan& p, long n_tgt, long n_src, bool whole, size_t works
                     int source_path, int force_chunks) {
     if (source_path != 0 && source_path != 3) return false;
     if (!whole || n_tgt != n_src || n_src < SYM_MIN_N) return false;
-    const F32SymShape s = sym_shape(n_src, n_cus, 0, 0, force_chunks);
-    const size_t need = sym_workspace_bytes(s, acc64);
-    if (need > SYM_MAX_WORKSPACE || workspace_bytes < need) return false;
+    F32SymBatches kb = sym_batches(n_src, n_cus, acc64);
+    F32SymShape s = sym_shape(n_src, n_cus, 0, kb.count > 1 ? kb.nb : 0, kb.count > 1 ? 0 : force_chunks);
+    if (kb.count == 1) kb.bytes = sym_workspace_bytes(s, acc64);  // (a forced chunk count changes the own and tail slots)
+    if (kb.count < 1 || kb.bytes > SYM_MAX_WORKSPACE || workspace_bytes < kb.bytes) return false;
     p.symmetric = true;
     p.sym = s;
+    p.sym_batches = kb;
+    p.sym_cus = n_cus;
     p.targets_per_lane = 2 * SYM_P;
     p.wg_size = SYM_WGS;
     p.j_split = s.chunks;
@@ -329,6 +337,19 @@ size_t sym_workspace_bytes(const F32SymShape& s, bool acc64) {
     return (size_t)sym_total_slots(s, acc64) * (size_t)s.npad * 3 * sizeof(float);  // a slot = 3 planes of npad floats
 }
 
+static int launch_sym_pass(const F32Args& a, const F32SymShape& sh, bool acc64, int mode, const void* carry, hipStream_t stream) {
+    const unsigned G = (unsigned)sh.nb * (unsigned)sh.chunks;
+    const unsigned rb = (unsigned)((a.n_src + WG - 1) / WG);
+    if (acc64) hipLaunchKernelGGL(nbody_force_sym_f32<true>, dim3(G), dim3(WGS), 0, stream, a, sh);
+    else hipLaunchKernelGGL(nbody_force_sym_f32<false>, dim3(G), dim3(WGS), 0, stream, a, sh);
+    if (hipError_t e = hipGetLastError()) return (int)e;
+#define NB_RED(A, M) hipLaunchKernelGGL((nbody_reduce_sym_f32<A, M>), dim3(rb), dim3(WG), 0, stream, a, sh, carry)
+    if (acc64) { if (mode == 0) NB_RED(true, 0); else if (mode == 1) NB_RED(true, 1); else NB_RED(true, 2); }
+    else { if (mode == 0) NB_RED(false, 0); else if (mode == 1) NB_RED(false, 1); else NB_RED(false, 2); }
+#undef NB_RED
+    return (int)hipGetLastError();
+}
+
 int launch_f32_sym(const F32Args& a0, const F32SymShape& sh, bool acc64, int mode, hipStream_t stream) {
     if (!a0.src || !a0.partial || a0.n_src <= 0 || sh.B <= 0 || sh.nb <= 0 || sh.chunks <= 0 || mode < 0 || mode > 2)
         return (int)hipErrorInvalidValue;
@@ -336,16 +357,65 @@ int launch_f32_sym(const F32Args& a0, const F32SymShape& sh, bool acc64, int mod
     if (mode != 2 && (sh.nb != sh.B || a0.tgt_off != 0 || a0.n_tgt != a0.n_src)) return (int)hipErrorInvalidValue;
     F32Args a = a0;
     a.tgt = a.src;
-    const unsigned G = (unsigned)sh.nb * (unsigned)sh.chunks;
-    const unsigned rb = (unsigned)((a.n_src + WG - 1) / WG);
-    if (acc64) hipLaunchKernelGGL(nbody_force_sym_f32<true>, dim3(G), dim3(WGS), 0, stream, a, sh);
-    else hipLaunchKernelGGL(nbody_force_sym_f32<false>, dim3(G), dim3(WGS), 0, stream, a, sh);
-    if (hipError_t e = hipGetLastError()) return (int)e;
-#define NB_RED(A, M) hipLaunchKernelGGL((nbody_reduce_sym_f32<A, M>), dim3(rb), dim3(WG), 0, stream, a, sh)
-    if (acc64) { if (mode == 0) NB_RED(true, 0); else if (mode == 1) NB_RED(true, 1); else NB_RED(true, 2); }
-    else { if (mode == 0) NB_RED(false, 0); else if (mode == 1) NB_RED(false, 1); else NB_RED(false, 2); }
-#undef NB_RED
-    return (int)hipGetLastError();
+    return launch_sym_pass(a, sh, acc64, mode, nullptr, stream);
+}
+
+// ---- one GPU, system too large for a slot per round (B/2 slots of n bodies): the I-superblocks go in BATCHES of `nb`, each a
+// launch like one rank of a multi-GPU step (a slot per I-superblock of the batch) whose reducer adds the batch's slots to a
+// running force F[n] kept behind the slots in the workspace; the last batch's reducer runs the epilogue from the total.
+F32SymBatches sym_batches(long n, int n_cus, bool acc64) {
+    F32SymBatches k{};
+    if (n < SYM_MIN_N) return k;
+    const F32SymShape whole = sym_shape(n, n_cus);
+    if (sym_workspace_bytes(whole, acc64) <= SYM_WHOLE_WORKSPACE) {
+        k.nb = whole.B;
+        k.count = 1;
+        k.bytes = sym_workspace_bytes(whole, acc64);
+        return k;
+    }
+    // the largest batch of whole rounds of workgroups (a multiple of the CU count; failing that a half, a quarter ... of it)
+    // whose slots — of the first and of the smaller last batch, which may be cut into more chunks — fit the budget
+    const size_t frec = acc64 ? sizeof(double4) : sizeof(float4);
+    auto bytes_of = [&](int nb) {
+        const int last = whole.B % nb ? whole.B % nb : nb;
+        const size_t a = sym_workspace_bytes(sym_shape(n, n_cus, 0, nb, 0), acc64);
+        const size_t b = sym_workspace_bytes(sym_shape(n, n_cus, 0, last, 0), acc64);
+        return (a > b ? a : b) + (size_t)whole.npad * frec;
+    };
+    auto take = [&](int nb, size_t budget) {
+        if (nb < 1 || nb >= whole.B || bytes_of(nb) > budget) return false;
+        k.nb = nb;
+        k.count = (whole.B + nb - 1) / nb;
+        k.bytes = bytes_of(nb);
+        return true;
+    };
+    for (int nb = (whole.B / n_cus) * n_cus; nb >= n_cus; nb -= n_cus)
+        if (take(nb, SYM_BATCH_WORKSPACE)) return k;
+    for (int nb = n_cus / 2; nb >= 16; nb /= 2)
+        if (take(nb, SYM_MAX_WORKSPACE)) return k;
+    return k;  // count == 0: not even 16 superblocks per batch fit
+}
+
+int launch_f32_sym_batched(const F32Args& a0, const F32SymBatches& kb, int n_cus, bool acc64, int mode, hipStream_t stream) {
+    if (!a0.src || !a0.partial || a0.n_src <= 0 || kb.count < 1 || kb.nb < 1 || mode < 0 || mode > 1) return (int)hipErrorInvalidValue;
+    if (a0.tgt_off != 0 || a0.n_tgt != a0.n_src) return (int)hipErrorInvalidValue;
+    if (kb.count == 1) return launch_f32_sym(a0, sym_shape(a0.n_src, n_cus), acc64, mode, stream);
+    const int B = (int)((a0.n_src + SB - 1) / SB);
+    F32Args a = a0;
+    a.tgt = a.src;
+    const size_t frec = acc64 ? sizeof(double4) : sizeof(float4);
+    const long npad = (long)B * SB;
+    void* F = (char*)a.partial + (kb.bytes - (size_t)npad * frec);  // the running force, behind the slots of the largest batch
+    void* user_acc = a.acc;
+    for (int k = 0; k < kb.count; ++k) {
+        const int b0 = k * kb.nb, nb = b0 + kb.nb <= B ? kb.nb : B - b0;
+        F32SymShape sh = sym_shape(a.n_src, n_cus, b0, nb, 0);
+        sh.by_super = 1;  // (a last batch of all B superblocks cannot happen: count > 1)
+        const bool last = k == kb.count - 1;
+        a.acc = last ? user_acc : F;
+        if (int e = launch_sym_pass(a, sh, acc64, last ? mode : 2, k ? F : nullptr, stream)) return e;
+    }
+    return (int)hipSuccess;
 }
 
 int launch_kick_drift_f32(const F32Args& a, bool acc64, int parts, hipStream_t stream) {

@@ -177,17 +177,39 @@ int nb_selftest_pair_schedule(int64_t n, int n_cus, int ranks, int acc64, char* 
     };
     if (msg && msg_len > 0) msg[0] = 0;
     if (n <= 0 || n_cus <= 0 || ranks < 1) return NB_ERR_INVALID;
-    F32SymShape base{};
-    if (ranks == 1) base = sym_shape(n, n_cus);
-    else if (!sym_sharded_ok(n, ranks, n_cus, acc64 != 0, &base)) return say("the %ld ranks cannot share the pairs of %ld bodies", ranks, n);
-    const int B = base.B;
     const bool a64 = acc64 != 0;
+    // the launches that together cover the system: one per rank; on one GPU one, or one per batch of I-superblocks
+    std::vector<F32SymShape> launches;
+    try {
+        if (ranks == 1) {
+            const F32SymBatches kb = sym_batches(n, n_cus, a64);
+            if (kb.count < 1) return say("K1s does not apply to %ld bodies", n);
+            const int B = (int)((n + SYM_SB - 1) / SYM_SB);
+            if (kb.count == 1) launches.push_back(sym_shape(n, n_cus));
+            else
+                for (int k = 0; k < kb.count; ++k) {
+                    const int b0 = k * kb.nb, nb = b0 + kb.nb <= B ? kb.nb : B - b0;
+                    launches.push_back(sym_shape(n, n_cus, b0, nb, 0));
+                    if (sym_workspace_bytes(launches.back(), a64) + (size_t)launches.back().npad * (a64 ? 32 : 16) > kb.bytes)
+                        return say("batch %ld needs more workspace than sym_batches reports", k);
+                }
+        } else {
+            F32SymShape base{};
+            if (!sym_sharded_ok(n, ranks, n_cus, a64, &base)) return say("the %ld ranks cannot share the pairs of %ld bodies", ranks, n);
+            for (int r = 0; r < ranks; ++r) {
+                launches.push_back(base);
+                launches.back().b0 = r * base.nb;
+            }
+        }
+    } catch (...) {
+        return NB_ERR_NOMEM;
+    }
+    const int B = launches[0].B;
     try {
         // phases[b * B + J]: bit mask of the tile phases in which I-superblock b has met superblock J (J == b: diagonal)
         std::vector<uint32_t> phases((size_t)B * B, 0u);
-        for (int rank = 0; rank < ranks; ++rank) {
-            F32SymShape sh = base;
-            sh.b0 = rank * sh.nb;
+        for (size_t rank = 0; rank < launches.size(); ++rank) {
+            const F32SymShape sh = launches[rank];
             const int slots = sym_total_slots(sh, a64);
             if ((size_t)slots * (size_t)sh.npad * 3 * sizeof(float) != sym_workspace_bytes(sh, a64)) return say("workspace size formula");
             std::vector<uint8_t> written((size_t)slots * B, 0);  // (slot, J-superblock) regions written by this launch
@@ -219,10 +241,10 @@ int nb_selftest_pair_schedule(int64_t n, int n_cus, int ranks, int acc64, char* 
                 sym_for_each_slot_of(sh, a64, J, [&](long slot) {
                     if (slot < 0 || slot >= slots || added[(size_t)slot]++) bad = (int)slot;
                 });
-                if (bad >= 0) return say("reducer adds slot %ld twice or out of range for superblock %ld (rank %ld)", bad, J, rank);
+                if (bad >= 0) return say("reducer adds slot %ld twice or out of range for superblock %ld (launch %ld)", bad, J, (long)rank);
                 for (int sl = 0; sl < slots; ++sl)
                     if ((added[(size_t)sl] != 0) != (written[(size_t)sl * B + J] != 0))
-                        return say("slot %ld of superblock %ld (rank %ld): written %ld but the reducer disagrees", sl, J, rank, written[(size_t)sl * B + J]);
+                        return say("slot %ld of superblock %ld (launch %ld): written %ld but the reducer disagrees", sl, J, (long)rank, written[(size_t)sl * B + J]);
             }
         }
         const uint32_t all = SYM_NT >= 32 ? 0xffffffffu : ((1u << SYM_NT) - 1);
@@ -242,9 +264,14 @@ int64_t nb_workspace_bytes_sym_f32(int64_t n, int acc64) {
     if (n < SYM_MIN_N) return 0;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    F32SymShape sh = sym_shape(n, cus);
-    sh.chunks = std::max(sh.chunks, 8);  // room for up to 8 workgroups per superblock (j_split with source_path 3)
-    const size_t b = sym_workspace_bytes(sh, acc64 != 0);
+    const F32SymBatches kb = sym_batches(n, cus, acc64 != 0);
+    if (kb.count < 1) return 0;
+    size_t b = kb.bytes;
+    if (kb.count == 1) {  // one launch: room for up to 8 workgroups per superblock (j_split with source_path 3)
+        F32SymShape sh = sym_shape(n, cus);
+        sh.chunks = std::max(sh.chunks, 8);
+        b = sym_workspace_bytes(sh, acc64 != 0);
+    }
     return b <= SYM_MAX_WORKSPACE ? (int64_t)b : 0;
 }
 

@@ -456,8 +456,8 @@ int create_impl(nb_sharded** out, const int* devices, int n_devices, int64_t n, 
             k.ws_bytes = (size_t)workspace_bytes(s, k.ws_slots);
         }
         if (n_devices == 1 && n >= SYM_MIN_N && !(flags & NB_SHARDED_ORDERED_PAIRS)) {  // room for K1s' pair slots (as nb_create)
-            const size_t sym = sym_workspace_bytes(sym_shape(n, k.n_cus), acc64(s));
-            if (sym <= SYM_MAX_WORKSPACE) k.ws_bytes = std::max(k.ws_bytes, sym);
+            const F32SymBatches kb = sym_batches(n, k.n_cus, acc64(s));
+            if (kb.count >= 1 && kb.bytes <= SYM_MAX_WORKSPACE) k.ws_bytes = std::max(k.ws_bytes, kb.bytes);
         }
         if (s->sym) {
             k.ws_bytes = std::max(k.ws_bytes, sym_workspace_bytes(s->shape, acc64(s)));

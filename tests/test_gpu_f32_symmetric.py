@@ -159,3 +159,28 @@ def test_symmetric_refusals_and_fallbacks(nb):
     assert c.kernel_name_f32(n, n, targets_per_lane=8, workspace_bytes=big.numel()).startswith("nbody_force_f32<")
     assert c.kernel_name_f32(n, n, j_split=8, workspace_bytes=big.numel()).startswith("nbody_force_f32<")
     assert c.kernel_name_f32(n, n, workspace_bytes=big.numel(), source_path=2).startswith("nbody_force_f32<")
+
+
+def test_batched_launches_of_a_system_too_large_for_a_slot_per_round(nb, oracle):
+    """N = 2^23 on one GPU: a slot per round would be 103 GB, so the I-superblocks go in 4 batches of 512 — each a launch like
+    one rank of a multi-GPU step, whose reducer adds the batch's slots to a running force behind them — and the last batch's
+    reducer runs the epilogue (52 GB of workspace).  nb_accel of a context against 8 oracle rows from the first, a middle
+    and the last batch, and against the momentum identity."""
+    c, syn = nb.capi, nb.synthetic
+    n = 1 << 23
+    assert 50e9 < c.workspace_bytes_sym_f32(n) < 60e9
+    c.selftest_pair_schedule(n, 256, 1)
+    q, v, m = syn.bodies(n)
+    with c.Context(n, c.NB_F32, 0, G=syn.G, eps=syn.EPS, dt=syn.DT) as ctx:
+        ctx.set_state(q, v, m)
+        a = ctx.accel(1)
+    assert np.isfinite(a).all()
+    q32 = np.ascontiguousarray(q.astype(np.float32).astype(np.float64))
+    gm = (syn.G * m).astype(np.float32).astype(np.float64) / syn.G
+    worst = 0.0
+    for i in (0, 4095, 512 * SB - 1, 512 * SB, n // 2 + 77, 3 * 512 * SB + 5, n - SB, n - 1):
+        ref, s = oracle.accel_rows(q32, gm, syn.G, syn.EPS, i, i + 1, want_abs=True, omp=True)
+        worst = max(worst, float(np.abs(a[:, i] - ref[:, 0]).max() / s[0]))
+    assert worst < 2e-7, worst  # (tolerance 1e-5; K1s delivers 3e-8)
+    p = (a * gm).sum(axis=1)
+    assert np.all(np.abs(p) < 1e-5 * (np.abs(a) * gm).sum(axis=1)), p
