@@ -277,8 +277,8 @@ int nb_plan_f32(const nb_launch_f32* a, int* targets_per_lane, int* j_split, int
 int64_t nb_workspace_bytes_f32(int64_t n_tgt, int acc64);
 /* workspace size that lets a whole-system launch of n bodies use K1s (source_path 3): three floats per body and
  * superblock round plus three (six with acc64) per workgroup of a superblock — 12 B x (n/8192 + 8) per body: 1.7 GB at
- * n = 2^20, 26 GB at 2^22; 0 = K1s does not apply to this n
- * (fewer than 131072 bodies, or more than 128 GiB of slots: 103 GB at n = 2^23 is the last that fits) */
+ * n = 2^20, 26 GB at 2^22; larger systems are stepped in batches of superblocks with a running force behind the slots: 52 GB
+ * at 2^23 and 2^24, 107 GB at 2^26; 0 = K1s does not apply to this n (fewer than 131072 bodies, or no batch fits 128 GiB) */
 int64_t nb_workspace_bytes_sym_f32(int64_t n, int acc64);
 
 /* ---- K1s over several GPUs, for hosts that own the collectives themselves (one process per GPU: nbody_amd.distributed).
