@@ -63,6 +63,7 @@ struct F32SymShape {  // who computes what in one launch
     int by_super;  // slot of a finished superblock pair: 0 = round - 1 (one GPU: B/2 slots), 1 = I-superblock - b0 (several
                    // GPUs share the pairs: nb slots)
     long npad;     // B * SYM_SB: bodies per slot plane (a slot = three planes x, y, z of npad floats)
+    int cus;       // compute units the chunk count was chosen for
 };
 __host__ __device__ inline int sym_own_slots(const F32SymShape& s, bool acc64) { return s.chunks * (acc64 ? 2 : 1); }
 // slots: own sums per chunk | finished superblock pairs (by round, or by I-superblock) | per chunk the second part of the
@@ -138,6 +139,12 @@ struct F32SymBatches {
     size_t bytes = 0;
 };
 F32SymBatches sym_batches(long n, int n_cus, bool acc64);
+// a launch that leaves a partial force (mode 2: one rank of a multi-GPU step): its I-superblocks go in sub-launches of
+// sym_sub_batch(s) superblocks when a slot for each of them would not fit SYM_BATCH_WORKSPACE (configs[4] over 8 GPUs: 512
+// superblocks per rank = 103 GB -> 2 x 256 = 52 GB); sym_partial_workspace_bytes = the workspace such a launch needs
+int sym_sub_batch(const F32SymShape& s, bool acc64);
+F32SymShape sym_sub_shape(const F32SymShape& s, int b0, int nb);  // superblocks [b0, b0 + nb) of launch s as a launch of their own
+size_t sym_partial_workspace_bytes(const F32SymShape& s, bool acc64);
 // mode 0: force + kick-drift of the whole system; 1: accelerations out; 2: this launch's partial force out (a.acc:
 // float4[n] / double4[n]) for the reduce-scatter of a multi-GPU step.  a.partial = the slot workspace.
 int launch_f32_sym(const F32Args& a, const F32SymShape& s, bool acc64, int mode, hipStream_t stream);  // hipError_t

@@ -303,20 +303,13 @@ bool plan_symmetric(F32Plan& p, long n_tgt, long n_src, bool whole, size_t works
     return true;
 }
 
-F32SymShape sym_shape(long n, int n_cus, int b0, int nb, int force_chunks) {
-    F32SymShape s{};
-    s.B = (int)((n + SB - 1) / SB);
-    s.npad = (long)s.B * SB;
-    if (nb <= 0) { b0 = 0; nb = s.B; }
-    s.b0 = b0;
-    s.nb = nb;
-    s.by_super = nb < s.B;  // several launches (GPUs) share the pairs: nb <= B/2 slots instead of B/2
-    // One 512-thread workgroup fits a CU, so workgroups run in rounds of n_cus and a partly filled last round is idle
-    // time: take the chunk count that minimises  ceil(nb * c / n_cus) / c  (time in units of one superblock's work), with
-    // 0.4 % per extra chunk for the reloaded targets and the shorter runs between slot writes (measured at N = 2^20:
-    // 1 / 2 / 4 / 8 chunks = 177.1 / 178.1 / 178.5 / 182.8 ms).  nb = 256: 1;  128: 2;  32 (an eighth of 2^20): 8;
-    // 48: 16 (768 workgroups = 3 full rounds; 6 would be 288 = one round and an eighth);  366: 2.
-    const int units_min = 1 + (s.B - 1) / 2;  // a chunk must hold at least one whole unit's worth of phases
+// One 512-thread workgroup fits a CU, so workgroups run in rounds of n_cus and a partly filled last round is idle time:
+// take the chunk count that minimises  ceil(nb * c / n_cus) / c  (time in units of one superblock's work), with 0.4 % per
+// extra chunk for the reloaded targets and the shorter runs between slot writes (measured at N = 2^20: 1 / 2 / 4 / 8 chunks =
+// 177.1 / 178.1 / 178.5 / 182.8 ms).  nb = 256: 1;  128: 2;  32 (an eighth of 2^20): 8;  48: 16 (768 workgroups = 3 full
+// rounds; 6 would be 288 = one round and an eighth);  366: 2.
+static int sym_choose_chunks(int nb, int B, int n_cus, int force_chunks) {
+    const int units_min = 1 + (B - 1) / 2;  // a chunk must hold at least one whole unit's worth of phases
     int c = force_chunks;
     if (c <= 0) {
         double best = 1e30;
@@ -328,9 +321,44 @@ F32SymShape sym_shape(long n, int n_cus, int b0, int nb, int force_chunks) {
         }
     }
     if (c > units_min) c = units_min;
-    if (c < 1) c = 1;
-    s.chunks = c;
+    return c < 1 ? 1 : c;
+}
+
+F32SymShape sym_shape(long n, int n_cus, int b0, int nb, int force_chunks) {
+    F32SymShape s{};
+    s.B = (int)((n + SB - 1) / SB);
+    s.npad = (long)s.B * SB;
+    if (nb <= 0) { b0 = 0; nb = s.B; }
+    s.b0 = b0;
+    s.nb = nb;
+    s.by_super = nb < s.B;  // several launches (GPUs, batches) share the pairs: nb slots instead of B/2
+    s.cus = n_cus > 0 ? n_cus : 256;
+    s.chunks = sym_choose_chunks(nb, s.B, s.cus, force_chunks);
     return s;
+}
+
+F32SymShape sym_sub_shape(const F32SymShape& s, int b0, int nb) {
+    F32SymShape t = s;
+    t.b0 = b0;
+    t.nb = nb;
+    t.by_super = 1;
+    t.chunks = sym_choose_chunks(nb, s.B, s.cus, 0);
+    return t;
+}
+
+int sym_sub_batch(const F32SymShape& s, bool acc64) {
+    if (sym_workspace_bytes(s, acc64) <= SYM_BATCH_WORKSPACE) return s.nb;
+    int nb = s.nb;
+    while (nb > 16 && sym_workspace_bytes(sym_sub_shape(s, s.b0, nb), acc64) > SYM_BATCH_WORKSPACE) nb = (nb + 1) / 2;
+    return nb;
+}
+
+size_t sym_partial_workspace_bytes(const F32SymShape& s, bool acc64) {
+    const int nb = sym_sub_batch(s, acc64);
+    if (nb >= s.nb) return sym_workspace_bytes(s, acc64);
+    const int last = s.nb % nb ? s.nb % nb : nb;
+    const size_t a = sym_workspace_bytes(sym_sub_shape(s, s.b0, nb), acc64), b = sym_workspace_bytes(sym_sub_shape(s, s.b0, last), acc64);
+    return a > b ? a : b;
 }
 
 size_t sym_workspace_bytes(const F32SymShape& s, bool acc64) {
@@ -357,7 +385,14 @@ int launch_f32_sym(const F32Args& a0, const F32SymShape& sh, bool acc64, int mod
     if (mode != 2 && (sh.nb != sh.B || a0.tgt_off != 0 || a0.n_tgt != a0.n_src)) return (int)hipErrorInvalidValue;
     F32Args a = a0;
     a.tgt = a.src;
-    return launch_sym_pass(a, sh, acc64, mode, nullptr, stream);
+    const int sub = mode == 2 ? sym_sub_batch(sh, acc64) : sh.nb;
+    if (sub >= sh.nb) return launch_sym_pass(a, sh, acc64, mode, nullptr, stream);
+    // a partial-force launch whose slots would not fit the budget: sub-launches, each adding to the partial force
+    for (int b0 = sh.b0; b0 < sh.b0 + sh.nb; b0 += sub) {
+        const int nb = b0 + sub <= sh.b0 + sh.nb ? sub : sh.b0 + sh.nb - b0;
+        if (int e = launch_sym_pass(a, sym_sub_shape(sh, b0, nb), acc64, 2, b0 > sh.b0 ? a.acc : nullptr, stream)) return e;
+    }
+    return (int)hipSuccess;
 }
 
 // ---- one GPU, system too large for a slot per round (B/2 slots of n bodies): the I-superblocks go in BATCHES of `nb`, each a
@@ -431,7 +466,7 @@ bool sym_sharded_ok(long n, int P, int n_cus, bool acc64, F32SymShape* shape_of_
     if (P < 2 || n < SYM_MIN_N || n % ((long)P * SYM_SB)) return false;
     const int B = (int)(n / SYM_SB);
     const F32SymShape s = sym_shape(n, n_cus, 0, B / P, 0);
-    if (sym_workspace_bytes(s, acc64) > SYM_MAX_WORKSPACE) return false;
+    if (sym_partial_workspace_bytes(s, acc64) > SYM_MAX_WORKSPACE) return false;
     if (shape_of_rank0) *shape_of_rank0 = s;
     return true;
 }

@@ -139,7 +139,7 @@ int nb_launch_pair_forces_f32(const nb_launch_f32* a, void* hip_stream) {
         a->src_end || !shared_pairs_shape(a, &sh))
         return set_error(NB_ERR_INVALID, "nb_launch_pair_forces_f32: the shard must be whole 4096-body superblocks of a system of "
                          ">= 131072 bodies (n_src = ranks * n_tgt, tgt_off = rank * n_tgt), with acc and a workspace");
-    if ((size_t)a->workspace_bytes < sym_workspace_bytes(sh, a->acc64 != 0))
+    if ((size_t)a->workspace_bytes < sym_partial_workspace_bytes(sh, a->acc64 != 0))
         return set_error(NB_ERR_INVALID, "nb_launch_pair_forces_f32: workspace smaller than nb_workspace_bytes_shared_pairs_f32");
     hipError_t e = (hipError_t)launch_f32_sym(to_args(a), sh, a->acc64 != 0, 2, (hipStream_t)hip_stream);
     return e == hipSuccess ? NB_OK : fail_hip(nullptr, e, "nb_launch_pair_forces_f32");
@@ -160,7 +160,7 @@ int64_t nb_workspace_bytes_shared_pairs_f32(int64_t n_src, int ranks, int acc64)
     a.n_tgt = n_src / ranks;
     a.acc64 = acc64;
     F32SymShape sh{};
-    return shared_pairs_shape(&a, &sh) ? (int64_t)sym_workspace_bytes(sh, acc64 != 0) : 0;
+    return shared_pairs_shape(&a, &sh) ? (int64_t)sym_partial_workspace_bytes(sh, acc64 != 0) : 0;
 }
 
 // Host-only replay of K1s' pair schedule for `n` bodies on `ranks` GPUs of `n_cus` compute units each (ranks = 1: the
@@ -196,9 +196,17 @@ int nb_selftest_pair_schedule(int64_t n, int n_cus, int ranks, int acc64, char* 
         } else {
             F32SymShape base{};
             if (!sym_sharded_ok(n, ranks, n_cus, a64, &base)) return say("the %ld ranks cannot share the pairs of %ld bodies", ranks, n);
-            for (int r = 0; r < ranks; ++r) {
-                launches.push_back(base);
-                launches.back().b0 = r * base.nb;
+            for (int r = 0; r < ranks; ++r) {  // a rank's launch, in sub-launches when its slots would not fit the budget
+                F32SymShape mine = base;
+                mine.b0 = r * base.nb;
+                const int sub = sym_sub_batch(mine, a64);
+                if (sub >= mine.nb) launches.push_back(mine);
+                else
+                    for (int b0 = mine.b0; b0 < mine.b0 + mine.nb; b0 += sub) {
+                        launches.push_back(sym_sub_shape(mine, b0, b0 + sub <= mine.b0 + mine.nb ? sub : mine.b0 + mine.nb - b0));
+                        if (sym_workspace_bytes(launches.back(), a64) > sym_partial_workspace_bytes(mine, a64))
+                            return say("a sub-launch of rank %ld needs more workspace than sym_partial_workspace_bytes reports", r);
+                    }
             }
         }
     } catch (...) {

@@ -460,7 +460,7 @@ int create_impl(nb_sharded** out, const int* devices, int n_devices, int64_t n, 
             if (kb.count >= 1 && kb.bytes <= SYM_MAX_WORKSPACE) k.ws_bytes = std::max(k.ws_bytes, kb.bytes);
         }
         if (s->sym) {
-            k.ws_bytes = std::max(k.ws_bytes, sym_workspace_bytes(s->shape, acc64(s)));
+            k.ws_bytes = std::max(k.ws_bytes, sym_partial_workspace_bytes(s->shape, acc64(s)));
             SH_HIP(s, hipMalloc(&k.fpart, N * force_rec(s)));
             SH_HIP(s, hipMalloc(&k.facc, (copy_exchange(s) ? (size_t)n_devices : 1) * per * force_rec(s)));
             if (copy_exchange(s)) SH_HIP(s, hipEventCreateWithFlags(&k.forced, hipEventDisableTiming));

@@ -297,17 +297,21 @@ def test_pair_schedule_of_the_symmetric_kernel_on_shapes_no_box_here_can_run(nb)
                                  (1 << 22, 256, 8, False),           # configs[3]
                                  (1 << 24, 256, 8, True),            # configs[4]
                                  (131072 + 5, 256, 1, True), (196608, 256, 1, False), (1500000, 256, 1, False),
+                                 (1 << 23, 256, 1, False), (1 << 24, 256, 1, True),   # one GPU, in batches of superblocks
                                  (67 * SB, 256, 1, False), (1 << 18, 304, 1, False), (15 * SB * 8, 256, 3, False)]:
         c.selftest_pair_schedule(n, cus, ranks, acc64)
     with pytest.raises(c.NBodyError, match="cannot share"):
         c.selftest_pair_schedule((1 << 20) + SB, 256, 8)  # shards are not whole superblocks
     with pytest.raises(c.NBodyError, match="cannot share"):
         c.selftest_pair_schedule(1 << 16, 256, 2)         # too few bodies
+    with pytest.raises(c.NBodyError, match="does not apply"):
+        c.selftest_pair_schedule(131071, 256, 1)
 
     @settings(max_examples=60, deadline=None)
     @given(st.integers(32, 700), st.integers(0, SB - 1), st.sampled_from([64, 104, 228, 256, 304]), st.booleans())
     def one_gpu(blocks, ragged, cus, acc64):
-        c.selftest_pair_schedule(blocks * SB - ragged, cus, 1, acc64)
+        if blocks * SB - ragged >= 131072:  # (below that K1s does not apply and the self-test says so)
+            c.selftest_pair_schedule(blocks * SB - ragged, cus, 1, acc64)
 
     @settings(max_examples=40, deadline=None)
     @given(st.integers(2, 8), st.integers(4, 96), st.sampled_from([64, 256, 304]), st.booleans())
