@@ -184,3 +184,34 @@ def test_batched_launches_of_a_system_too_large_for_a_slot_per_round(nb, oracle)
     assert worst < 2e-7, worst  # (tolerance 1e-5; K1s delivers 3e-8)
     p = (a * gm).sum(axis=1)
     assert np.all(np.abs(p) < 1e-5 * (np.abs(a) * gm).sum(axis=1)), p
+
+
+def test_config4_rank_shares_add_up_to_the_oracle_force(nb, oracle):
+    """BASELINE configs[4] at full size, every rank's launch on one GPU: N = 2^24, 8 ranks, fp32 pair math / fp64 sums.  A
+    rank's 512 superblocks would need 103 GB of slots, so nb_launch_pair_forces_f32 runs them as two sub-launches of 256 (52 GB),
+    the second adding to the first's partial force.  The eight partial forces added up (what the reduce-scatter does) against
+    8 oracle rows from different shards."""
+    import torch
+    c, syn = nb.capi, nb.synthetic
+    n, ranks = 1 << 24, 8
+    per = n // ranks
+    ws_bytes = c.workspace_bytes_shared_pairs_f32(n, ranks, True)
+    assert 50e9 < ws_bytes < 60e9
+    pos, _ = syn.body4_f32(n)
+    src = torch.from_numpy(pos).cuda()
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+    part = torch.empty((n, 4), dtype=torch.float64, device="cuda")
+    total = torch.zeros((n, 4), dtype=torch.float64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    for r in range(ranks):
+        part.fill_(float("nan"))  # every body must be written by every rank's launch
+        c.launch_pair_forces_f32(src.data_ptr(), n, r * per, per, syn.EPS ** 2, stream, part.data_ptr(), ws.data_ptr(),
+                                 ws.numel(), acc64=True)
+        total += part
+    torch.cuda.synchronize()
+    rows = np.array([0, per - 1, per, 3 * per + 4097, 5 * per + 256 * SB, 6 * per - 1, 7 * per + 11, n - 1])
+    a = total[torch.from_numpy(rows).cuda(), :3].cpu().numpy().T
+    assert np.isfinite(a).all()
+    ref, s = _oracle_rows(oracle, syn, pos, rows)
+    err = (np.abs(a - ref).max(axis=0) / s).max()
+    assert err < TOL_ACC64 and err < 2e-7, err
