@@ -173,6 +173,8 @@ class ShardedSystem:
         self.pos[0][self.lo:self.hi] = pos_shard.to(device=device, dtype=torch.float32)
         self._exchange(self.pos[0])
         self.pos[1].copy_(self.pos[0])  # G*m column of the other buffer for slots this rank never writes
+        if self.shared_pairs:
+            self._alloc_shared_pairs(self.pos[0].device)  # not inside somebody's timed first step
 
     @property
     def exchange_mode(self):
@@ -282,15 +284,20 @@ class ShardedSystem:
             torch.cuda.nvtx.range_pop()
         self.cur ^= 1
 
-    def _step_shared_pairs(self, src, out):
-        """K1s on this rank's share of the unordered pairs -> partial force on all N bodies -> reduce-scatter -> kick-drift
-        of the own shard -> all-gather of the positions."""
-        dev, fdt = src.device, (torch.float64 if self.acc64 else torch.float32)
+    def _alloc_shared_pairs(self, dev):
+        """Partial force on all N bodies, the summed force on the own shard, the pair-slot workspace (once)."""
         if self._fpart is None:
+            fdt = torch.float64 if self.acc64 else torch.float32
             self._fpart = torch.empty((self.n, 4), dtype=fdt, device=dev)
             self._facc = torch.empty((self.n_tgt, 4), dtype=fdt, device=dev)
             self._pair_ws = torch.empty(capi.workspace_bytes_shared_pairs_f32(self.n, self.world, self.acc64),
                                         dtype=torch.uint8, device=dev)
+
+    def _step_shared_pairs(self, src, out):
+        """K1s on this rank's share of the unordered pairs -> partial force on all N bodies -> reduce-scatter -> kick-drift
+        of the own shard -> all-gather of the positions."""
+        dev = src.device
+        self._alloc_shared_pairs(dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
         if self.kernel_events is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
