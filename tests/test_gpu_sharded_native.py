@@ -202,7 +202,9 @@ def test_compiled_host_runs_the_sharded_path(nb):
 
 
 @pytest.mark.parametrize("args", [["16384", "3", "1", "f32", "4", "1", "copy-one-gpu"], ["16384", "2", "1", "f32acc64", "2", "0", "copy-one-gpu"],
-                                  ["16384", "2", "0", "f32", "1", "0", "rccl"]])
+                                  ["16384", "2", "0", "f32", "1", "0", "rccl"],
+                                  ["131072", "2", "1", "f32acc64", "4", "0", "copy-one-gpu"],   # the ranks share the unordered pairs
+                                  ["131072", "2", "0", "f32", "1", "0", "rccl"]])              # K1s on one GPU through RCCL's rank-1 path
 def test_sharded_host_under_host_asan(nb, args):
     """bin/asan/nbody_bench (`make asan`): the multi-GPU host — per-rank streams and events, phased launches, the copy
     exchange, the RCCL path with one rank — compiled with AddressSanitizer + UBSan (device code: the plain gfx950 build), on the GPU."""
@@ -214,3 +216,4 @@ def test_sharded_host_under_host_asan(nb, args):
     assert p.returncode == 0 and "AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr, p.stderr[-2000:]
     r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert r["gpus"] == int(args[4]) and r["pairs_per_s"] > 1e9
+    assert r["kernel"].startswith("nbody_force_sym_f32" if args[0] == "131072" else "nbody_force_f32<")
