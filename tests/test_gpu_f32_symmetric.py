@@ -187,17 +187,19 @@ def test_batched_launches_of_a_system_too_large_for_a_slot_per_round(nb, oracle)
     assert np.all(np.abs(p) < 1e-5 * (np.abs(a) * gm).sum(axis=1)), p
 
 
-def test_config4_rank_shares_add_up_to_the_oracle_force(nb, oracle):
-    """BASELINE configs[4] at full size, every rank's launch on one GPU: N = 2^24, 8 ranks, fp32 pair math / fp64 sums.  A
-    rank's 512 superblocks would need 103 GB of slots, so nb_launch_pair_forces_f32 runs them as two sub-launches of 256 (52 GB),
-    the second adding to the first's partial force.  The eight partial forces added up (what the reduce-scatter does) against
-    8 oracle rows from different shards."""
+def test_sub_launched_rank_shares_add_up_to_the_oracle_force(nb, oracle):
+    """A rank whose superblocks would need more than 64 GiB of slots runs them as sub-launches, each adding to the partial force
+    of the one before: BASELINE configs[4] (N = 2^24 over 8 ranks: 512 superblocks per rank = 103 GB -> 2 x 256 in 52 GB) and,
+    executed here because it costs a quarter of the pairs, N = 2^23 over 2 ranks (1024 superblocks per rank -> 2 x 512), fp32
+    pair math / fp64 sums.  The ranks' partial forces added up (what the reduce-scatter does) against 8 oracle rows."""
     import torch
     c, syn = nb.capi, nb.synthetic
-    n, ranks = 1 << 24, 8
+    assert 50e9 < c.workspace_bytes_shared_pairs_f32(1 << 24, 8, True) < 60e9
+    c.selftest_pair_schedule(1 << 24, 256, 8, True)
+    n, ranks = 1 << 23, 2
     per = n // ranks
     ws_bytes = c.workspace_bytes_shared_pairs_f32(n, ranks, True)
-    assert 50e9 < ws_bytes < 60e9
+    assert 50e9 < ws_bytes < 60e9  # (a slot per superblock of the rank would be 103 GB)
     pos, _ = syn.body4_f32(n)
     src = torch.from_numpy(pos).cuda()
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
@@ -210,7 +212,7 @@ def test_config4_rank_shares_add_up_to_the_oracle_force(nb, oracle):
                                  ws.numel(), acc64=True)
         total += part
     torch.cuda.synchronize()
-    rows = np.array([0, per - 1, per, 3 * per + 4097, 5 * per + 256 * SB, 6 * per - 1, 7 * per + 11, n - 1])
+    rows = np.array([0, 512 * SB - 1, 512 * SB, per - 1, per, per + 512 * SB + 4097, n - SB - 1, n - 1])
     a = total[torch.from_numpy(rows).cuda(), :3].cpu().numpy().T
     assert np.isfinite(a).all()
     ref, s = _oracle_rows(oracle, syn, pos, rows)
