@@ -206,15 +206,15 @@ def test_ring_pass_on_one_gpu_matches_single(nb, tmp_path, world, acc64):
     assert np.abs(b["pos"][:, :3] - p0[:, :3]).max() > 1e-6 and np.array_equal(b["pos"][:, 3], p0[:, 3])
 
 
+@pytest.mark.parametrize("n", [8192 + 256, 131072 + 256])  # K1 (every ordered pair) / K1s (every unordered pair once)
 @pytest.mark.parametrize("acc64", [False, True])
-def test_sharded_checkpoint_resume_is_bitwise_on_gpu(nb, tmp_path, acc64):
+def test_sharded_checkpoint_resume_is_bitwise_on_gpu(nb, tmp_path, acc64, n):
     """ShardedSystem.save_checkpoint / load_checkpoint_shard with the real kernels (one rank; the two-rank form runs on CPU
     in tests/test_distributed_gloo.py): 2 steps + checkpoint + a NEW system from the file + 2 steps = 4 uninterrupted steps,
     bit for bit, in NB_F32 and with fp64 masters."""
     from nbody_amd.distributed import ShardedSystem
     syn, c = nb.synthetic, nb.capi
     dev = torch.device("cuda", 0)
-    n = 8192 + 256
 
     def fresh():
         if acc64:
