@@ -248,7 +248,7 @@ typedef struct nb_launch_f32 {
     int32_t source_path;      /* 0 = auto; 1 = sources through the LDS tile; 2 = sources through scalar loads/SGPRs (both: every
                                  ORDERED pair, kernel K1); 3 = every UNORDERED pair once, Newton's third law (kernel K1s: the
                                  sources travel through the wave by DPP rotation) — needs the whole system in this one launch
-                                 (n_tgt == n_src, tgt_off 0, phase WHOLE), n_src >= 131072 and a workspace of
+                                 (n_tgt == n_src, tgt_off 0, phase WHOLE), n_src >= 49152 and a workspace of
                                  nb_workspace_bytes_sym_f32(); auto picks it whenever that holds and nothing else is forced;
                                  j_split then = workgroups per 4096-body superblock (0 = auto) */
     int32_t wg_size;          /* 0 = auto; 256, 512 (targets_per_lane 8) or 1024 (targets_per_lane 4) */
@@ -278,13 +278,13 @@ int64_t nb_workspace_bytes_f32(int64_t n_tgt, int acc64);
 /* workspace size that lets a whole-system launch of n bodies use K1s (source_path 3): three floats per body and
  * superblock round plus three (six with acc64) per workgroup of a superblock — 12 B x (n/8192 + 8) per body: 1.7 GB at
  * n = 2^20, 26 GB at 2^22; larger systems are stepped in batches of superblocks with a running force behind the slots: 52 GB
- * at 2^23 and 2^24, 107 GB at 2^26; 0 = K1s does not apply to this n (fewer than 131072 bodies, or no batch fits 128 GiB) */
+ * at 2^23 and 2^24, 107 GB at 2^26; 0 = K1s does not apply to this n (fewer than 49152 bodies, or no batch fits 128 GiB) */
 int64_t nb_workspace_bytes_sym_f32(int64_t n, int acc64);
 
 /* ---- K1s over several GPUs, for hosts that own the collectives themselves (one process per GPU: nbody_amd.distributed).
  * The GPUs share the UNORDERED pairs of the system: rank r = tgt_off / n_tgt of P = n_src / n_tgt takes the 4096-body
  * superblocks of its shard against the half of the system behind each.  Needs whole superblocks per shard
- * (n_src % (P * 4096) == 0) and n_src >= 131072: nb_workspace_bytes_shared_pairs_f32 answers 0 otherwise (use the ordered
+ * (n_src % (P * 4096) == 0) and n_src >= 49152: nb_workspace_bytes_shared_pairs_f32 answers 0 otherwise (use the ordered
  * launches above).  Per step and rank:
  *   nb_launch_pair_forces_f32   a->acc = float4[n_src] (double4 with acc64): this rank's partial force on ALL bodies
  *   reduce-scatter (sum) of a->acc over the ranks -> the force on the rank's own shard
@@ -322,7 +322,7 @@ typedef struct nb_sharded nb_sharded;
                                 sharing a GPU, each with its own streams and arrays — which is how a one-GPU box executes the
                                 P > 1 host logic (tests/test_gpu_sharded_native.py) */
 #define NB_SHARDED_ORDERED_PAIRS 4 /* every GPU evaluates every ordered pair of its targets (kernel K1) even where the default
-                                applies: when every shard is a whole number of 4096-body superblocks, n >= 131072 and the step is
+                                applies: when every shard is a whole number of 4096-body superblocks, n >= 49152 and the step is
                                 not overlapped, the GPUs share the UNORDERED pairs of the system instead (kernel K1s: GPU r takes
                                 the superblocks of its shard against the half of the system behind each), which leaves every GPU
                                 with a partial force on all n bodies — one reduce-scatter per step (ncclReduceScatter, or peer

@@ -50,10 +50,10 @@ constexpr int MAX_JSPLIT = 1024;       // source slices per step (processed SLIC
 constexpr int SYM_P = 4, SYM_WGS = 512;            // packed target pairs per lane, threads per workgroup (8 waves)
 constexpr int SYM_SB = SYM_WGS * 2 * SYM_P;        // superblock: 4096 bodies, the targets one workgroup holds in registers
 #ifndef NB_SYM_MIN_N
-#define NB_SYM_MIN_N 131072
+#define NB_SYM_MIN_N 49152
 #endif
-constexpr long SYM_MIN_N = NB_SYM_MIN_N;           // below this the pair list is too short to fill the chip (N = 65536: 16 superblocks of
-                                                   // 8.5 work units — 0.35 of peak against K1's 0.48; N = 131072: 0.73 against 0.58)
+constexpr long SYM_MIN_N = NB_SYM_MIN_N;           // 12 superblocks; below, the pair list is too short to fill the chip even cut into
+                                                   // sub-unit chunks (N = 32768: 0.36 of peak against K1's 0.42; 49152: 0.57 against 0.46)
 constexpr size_t SYM_MAX_WORKSPACE = (size_t)128 << 30;  // partial-sum slots grow with n^2/8192 * 12 B: 1.6 GB at 2^20, 26 GB at 2^22,
                                                          // 103 GB at 2^23 (and per GPU at 2^24 over 8) — of 288 GB
 struct F32SymShape {  // who computes what in one launch

@@ -309,18 +309,20 @@ bool plan_symmetric(F32Plan& p, long n_tgt, long n_src, bool whole, size_t works
 // 177.1 / 178.1 / 178.5 / 182.8 ms).  nb = 256: 1;  128: 2;  32 (an eighth of 2^20): 8;  48: 16 (768 workgroups = 3 full
 // rounds; 6 would be 288 = one round and an eighth);  366: 2.
 static int sym_choose_chunks(int nb, int B, int n_cus, int force_chunks) {
-    const int units_min = 1 + (B - 1) / 2;  // a chunk must hold at least one whole unit's worth of phases
+    // a chunk holds at least 8 tile phases (a quarter of a work unit): every chunk then has at most one piece that does not
+    // start its round — the one its tail slot is for
+    const int c_max = (int)((long)SYM_NT * (1 + B / 2) / 8);
     int c = force_chunks;
     if (c <= 0) {
         double best = 1e30;
         c = 1;
-        for (int k = 1; k <= 16 && k <= units_min; ++k) {
+        for (int k = 1; k <= 64 && k <= c_max; ++k) {
             const long rounds = ((long)nb * k + n_cus - 1) / n_cus;
             const double cost = (double)rounds / k * (1.0 + 0.004 * (k - 1));
             if (cost < best - 1e-12) { best = cost; c = k; }
         }
     }
-    if (c > units_min) c = units_min;
+    if (c > c_max) c = c_max;
     return c < 1 ? 1 : c;
 }
 

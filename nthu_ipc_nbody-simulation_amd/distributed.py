@@ -27,7 +27,7 @@ whose positions do not fit twice on one device, parity-tested against the all-ga
 evaluated once, by the rank that owns the earlier of its two 4096-body superblocks (cyclically), with the symmetric kernel
 K1s (capi.launch_pair_forces_f32).  A rank then holds a partial force on ALL N bodies: per step ONE reduce-scatter (sum) of
 float4[N] hands every shard owner its total, the owner kicks and drifts (capi.launch_kick_drift_f32), and the all-gather of
-positions follows as before.  Needs whole superblocks per shard (N % (4096 P) == 0) and N >= 131072; K1s reaches ~0.79 of
+positions follows as before.  Needs whole superblocks per shard (N % (4096 P) == 0) and N >= 49152; K1s reaches ~0.79 of
 the fp32 peak per GPU where the ordered-pair kernel K1 reaches ~0.59.
 
 torch is used for device memory, the stream and the collective only; the arithmetic is the HIP kernel behind
@@ -143,7 +143,7 @@ class ShardedSystem:
                and capi.workspace_bytes_shared_pairs_f32(n, self.world, acc64) > 0)
         if shared_pairs and not can:
             raise ValueError("shared_pairs needs >= 2 ranks, HIP tensors, the all-gather exchange without overlap, "
-                             "n % (4096 * world) == 0 and n >= 131072")
+                             "n % (4096 * world) == 0 and n >= 49152")
         self.shared_pairs = can if shared_pairs is None else bool(shared_pairs)
         self._fpart = self._facc = self._pair_ws = None
         if self.ring:

@@ -303,20 +303,20 @@ def test_pair_schedule_of_the_symmetric_kernel_on_shapes_no_box_here_can_run(nb)
     with pytest.raises(c.NBodyError, match="cannot share"):
         c.selftest_pair_schedule((1 << 20) + SB, 256, 8)  # shards are not whole superblocks
     with pytest.raises(c.NBodyError, match="cannot share"):
-        c.selftest_pair_schedule(1 << 16, 256, 2)         # too few bodies
+        c.selftest_pair_schedule(1 << 15, 256, 2)         # too few bodies
     with pytest.raises(c.NBodyError, match="does not apply"):
-        c.selftest_pair_schedule(131071, 256, 1)
+        c.selftest_pair_schedule(49151, 256, 1)
 
     @settings(max_examples=60, deadline=None)
-    @given(st.integers(32, 700), st.integers(0, SB - 1), st.sampled_from([64, 104, 228, 256, 304]), st.booleans())
+    @given(st.integers(12, 700), st.integers(0, SB - 1), st.sampled_from([64, 104, 228, 256, 304]), st.booleans())
     def one_gpu(blocks, ragged, cus, acc64):
-        if blocks * SB - ragged >= 131072:  # (below that K1s does not apply and the self-test says so)
+        if blocks * SB - ragged >= 49152:  # (below that K1s does not apply and the self-test says so)
             c.selftest_pair_schedule(blocks * SB - ragged, cus, 1, acc64)
 
     @settings(max_examples=40, deadline=None)
     @given(st.integers(2, 8), st.integers(4, 96), st.sampled_from([64, 256, 304]), st.booleans())
     def several_gpus(ranks, per_rank, cus, acc64):
-        if ranks * per_rank * SB >= 131072:
+        if ranks * per_rank * SB >= 49152:
             c.selftest_pair_schedule(ranks * per_rank * SB, cus, ranks, acc64)
 
     one_gpu()

@@ -31,7 +31,10 @@ def _launch(nb, torch, src, n, acc64, source_path, accel=None, j_split=0, out=No
     return ws
 
 
-@pytest.mark.parametrize("n,chunks", [(64 * SB, 0),          # B = 64: even, the half round B/2 for b < 32
+@pytest.mark.parametrize("n,chunks", [(12 * SB, 0),          # the smallest system K1s takes: 7 work units per superblock cut into
+                                                             # sub-unit chunks (>= 8 of a unit's 32 tile phases each)
+                                      (16 * SB + 3, 0),      # B = 17, odd, ragged
+                                      (64 * SB, 0),          # B = 64: even, the half round B/2 for b < 32
                                       (65 * SB + 77, 0),     # B = 66 with a ragged last superblock (4019 bodies missing)
                                       (67 * SB, 3),          # B = 67: odd, no half round; three workgroups per superblock
                                       (64 * SB + 1, 1)])     # B = 65: one body in the last superblock; one workgroup each
@@ -74,7 +77,7 @@ def test_symmetric_accelerations_vs_oracle_and_k1(nb, oracle, n, chunks, acc64):
 
 
 def test_symmetric_is_bitwise_reproducible_and_is_what_a_context_runs(nb, oracle):
-    """No atomics anywhere: two launches give identical bits; nb_accel / nb_step of a context with >= 131072 bodies pick
+    """No atomics anywhere: two launches give identical bits; nb_accel / nb_step of a context with >= 49152 bodies pick
     K1s by themselves (the workspace is sized for it at nb_create) and give exactly the raw launch's numbers."""
     import torch
     c, syn = nb.capi, nb.synthetic
@@ -143,7 +146,7 @@ def test_symmetric_refusals_and_fallbacks(nb):
     big = torch.empty(c.workspace_bytes_sym_f32(n), dtype=torch.uint8, device="cuda")
     small = torch.empty(c.workspace_bytes_f32(n), dtype=torch.uint8, device="cuda")
     assert 50e9 < c.workspace_bytes_sym_f32(1 << 24) < 60e9  # 412 GB of slots in one launch: 16 batches of 256 superblocks
-    assert c.workspace_bytes_sym_f32(SB * 31) == 0 and c.workspace_bytes_sym_f32(1 << 28) == 0  # too small / no batch of superblocks fits 128 GiB
+    assert c.workspace_bytes_sym_f32(SB * 11) == 0 and c.workspace_bytes_sym_f32(1 << 28) == 0  # too small / no batch of superblocks fits 128 GiB
     for kw in (dict(workspace_ptr=small.data_ptr(), workspace_bytes=small.numel()),                      # workspace too small
                dict(workspace_ptr=big.data_ptr(), workspace_bytes=big.numel(), src_begin=0, src_end=n // 2),  # a source range
                dict(workspace_ptr=big.data_ptr(), workspace_bytes=big.numel(), tgt_ptr=src.data_ptr())):  # a target block
