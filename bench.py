@@ -935,6 +935,8 @@ def main():
         }
         if out["roofline"]["traffic_detail"]:
             out["roofline"]["traffic_detail"]["algorithmic"] = 56 * n  # 16N + 12N read, 12N + 16N written
+        if getattr(sysm, "shared_pairs_note", None):
+            out["shared_pairs_note"] = sysm.shared_pairs_note
         if world > 1:
             out["host_detail"] = ("nbody_amd.distributed: one process per GPU, torch.distributed (backend "
                                   f"{args.backend}) for the collective only; kernels through the C ABI (nb_launch_step_f32)")

@@ -145,6 +145,21 @@ class ShardedSystem:
             raise ValueError("shared_pairs needs >= 2 ranks, HIP tensors, the all-gather exchange without overlap, "
                              "n % (4096 * world) == 0 and n >= 49152")
         self.shared_pairs = can if shared_pairs is None else bool(shared_pairs)
+        self.shared_pairs_note = None
+        if self.shared_pairs and shared_pairs is None and dist.get_backend(group) == "nccl":
+            # the step will need a second collective, reduce_scatter_tensor: try it once on four numbers per rank, so that a
+            # communicator that cannot do it (an argument error raised before anything is enqueued) costs this run the
+            # shared pairs — said in `shared_pairs_note`, which bench.py prints — and not the whole measurement.  Asked for
+            # explicitly (shared_pairs=True) nothing is tried and nothing is caught.
+            try:
+                probe = torch.ones((self.world, 4), dtype=torch.float64 if acc64 else torch.float32, device=device)
+                got = torch.empty((1, 4), dtype=probe.dtype, device=device)
+                dist.reduce_scatter_tensor(got, probe, op=dist.ReduceOp.SUM, group=group)
+                if float(got.sum().item()) != 4.0 * self.world:
+                    raise RuntimeError(f"reduce_scatter_tensor of ones gave {got.tolist()}")
+            except Exception as e:  # noqa: BLE001
+                self.shared_pairs = False
+                self.shared_pairs_note = f"shared pairs off, every rank runs K1 on its own targets: {type(e).__name__}: {e}"
         self._fpart = self._facc = self._pair_ws = None
         if self.ring:
             if overlap:
