@@ -54,7 +54,7 @@ namespace {
 void release(nb_context* c) {
     free_dev(c->arena);  // q, v, m, coef, acc, mon, done_dev, ctl
     free_dev(c->snap_q); free_dev(c->snap_v); free_dev(c->fst_dev); free_dev(c->fst_chunk); free_dev(c->stamps);
-    free_dev(c->gm_large); free_dev(c->partial_large);
+    free_dev(c->gm_large); free_dev(c->partial_large); free_dev(c->sym64_slots);
     if (c->host_arena) (void)hipHostFree(c->host_arena);  // mon_host, done_host
     free_dev(c->pos[0]); free_dev(c->pos[1]); free_dev(c->vel); free_dev(c->pos64); free_dev(c->vel64);
     free_dev(c->acc32);
@@ -102,6 +102,7 @@ F64LargeArgs large_args(nb_context* c, int step) {
     a.partial = c->partial_large;
     a.n = c->n;
     a.j_split = c->slices_large;
+    a.sym_slots = c->sym64_slots;
     a.fst = fst_of(step, c->cfg.dt);
     a.G = c->cfg.G;
     a.eps2 = c->cfg.eps * c->cfg.eps;
@@ -113,7 +114,7 @@ int step_f64(nb_context* c, int first_step, int count) {
     if (c->gm_large) {  // n >= F64_LARGE_MIN (or the config's override)
         for (int s = 0; s < count; ++s) {
             F64LargeArgs a = large_args(c, first_step + s);
-            NB_HIP(c, (hipError_t)launch_f64_large(a, c->stream));
+            NB_HIP(c, (hipError_t)(a.sym_slots ? launch_f64_large_sym(a, c->n_cus, c->stream) : launch_f64_large(a, c->stream)));
             c->cur ^= 1;
         }
         return NB_OK;
@@ -276,6 +277,9 @@ int nbi::create_context(nb_context** out, const nb_config* cfg, hipStream_t borr
             NB_HIP(c, hipMalloc(&c->gm_large, n * sizeof(double)));
             if (c->slices_large > 1)
                 NB_HIP(c, hipMalloc(&c->partial_large, (size_t)c->slices_large * 3 * n * sizeof(double)));
+            // every unordered pair once (K1s-f64) where its slots are affordable and eps > 0 (the self pair then adds +0)
+            if (cfg->eps > 0 && sym64_workspace_bytes(c->n, c->n_cus) > 0)
+                NB_HIP(c, hipMalloc(&c->sym64_slots, sym64_workspace_bytes(c->n, c->n_cus)));
         }
     } else {
         NB_HIP(c, hipMalloc(&c->pos[0], n * sizeof(float4)));
@@ -472,7 +476,7 @@ static int nb_accel_impl(nb_context* c, int step, double* ax, double* ay, double
         if (c->gm_large) {
             F64LargeArgs a = large_args(c, step);
             a.acc_out = c->acc;
-            NB_HIP(c, (hipError_t)launch_f64_large(a, c->stream));
+            NB_HIP(c, (hipError_t)(a.sym_slots ? launch_f64_large_sym(a, c->n_cus, c->stream) : launch_f64_large(a, c->stream)));
         } else {
             F64Args a = base_args(c, step);
             a.acc_out = c->acc;

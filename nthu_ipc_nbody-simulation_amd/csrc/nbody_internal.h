@@ -50,6 +50,7 @@ struct nb_context {
     double* gm_large = nullptr;       // K1-f64 (n > F64_LARGE_MIN): G*m_eff scratch [n]
     double* partial_large = nullptr;  // ... and partial sums [slices][3][n]
     int slices_large = 1;
+    double* sym64_slots = nullptr;    // K1s-f64: pair slots (eps > 0 and sym64_workspace_bytes(n) > 0), else K1-f64 runs
     double* fst_dev = nullptr;  // |sin(step*dt/6000)| table, steps 0 .. fst_len-1, host-computed (glibc)
     int fst_len = 0;
     double* fst_chunk = nullptr;  // graph-driven stepping: |sin| of steps base .. base + chunk + 1, refilled per replay

@@ -125,7 +125,7 @@ __host__ __device__ inline void sym_for_each_slot_of(const F32SymShape& s, bool 
         if (b >= s.b0 && b < s.b0 + s.nb && r <= sym_rounds(B, b)) f(sym_tail_slot(s, acc64, c));
     }
 }
-F32SymShape sym_shape(long n, int n_cus, int b0 = 0, int nb = 0, int force_chunks = 0);
+F32SymShape sym_shape(long n, int n_cus, int b0 = 0, int nb = 0, int force_chunks = 0, int sb = SYM_SB);
 size_t sym_workspace_bytes(const F32SymShape& s, bool acc64);
 // One GPU: up to SYM_WHOLE_WORKSPACE of slots the whole system is ONE launch (a slot per round, B/2 of them).  Larger systems
 // go in batches of `nb` I-superblocks — each a launch like one rank of a multi-GPU step, a slot per I-superblock of the batch —
@@ -267,9 +267,18 @@ struct F64LargeArgs {
     int n;
     int j_split;
     double fst, G, eps2, dt;
+    double* sym_slots;  // K1s-f64: pair-slot workspace of sym64_workspace_bytes, or nullptr (K1-f64)
 };
 int launch_f64_large(const F64LargeArgs& a, hipStream_t stream);
 int plan_f64_large_slices(int n, int n_cus);
+// K1s-f64 (nbody_kernels_f64_sym.hip): the fp64 member with every unordered pair evaluated once — the scheme of K1s with one
+// travelling source per lane (a wave meets 64-source tiles), R = 4 targets per lane, superblocks of 2048 bodies, everything
+// (register sums, LDS image, slots) in fp64.  Taken for eps > 0 when a.sym_slots (the slot workspace, sym64_workspace_bytes)
+// is given.
+constexpr int SYM64_SB = 2048;
+constexpr size_t SYM64_MAX_WORKSPACE = (size_t)8 << 30;  // 0.4 GB at n = 2^18, 6.5 GB at 2^20
+size_t sym64_workspace_bytes(int n, int n_cus);  // 0: not applicable (fewer than 16 superblocks, or beyond the cap)
+int launch_f64_large_sym(const F64LargeArgs& a, int n_cus, hipStream_t stream);
 
 // K3: whole scenario of a small system (n <= SMALL_N_MAX) in ONE persistent single-workgroup launch
 constexpr int SMALL_N_MAX = 128;

@@ -326,10 +326,10 @@ static int sym_choose_chunks(int nb, int B, int n_cus, int force_chunks) {
     return c < 1 ? 1 : c;
 }
 
-F32SymShape sym_shape(long n, int n_cus, int b0, int nb, int force_chunks) {
+F32SymShape sym_shape(long n, int n_cus, int b0, int nb, int force_chunks, int sb) {
     F32SymShape s{};
-    s.B = (int)((n + SB - 1) / SB);
-    s.npad = (long)s.B * SB;
+    s.B = (int)((n + sb - 1) / sb);
+    s.npad = (long)s.B * sb;
     if (nb <= 0) { b0 = 0; nb = s.B; }
     s.b0 = b0;
     s.nb = nb;

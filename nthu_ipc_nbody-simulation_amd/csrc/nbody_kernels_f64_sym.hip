@@ -1,0 +1,190 @@
+// nbody_kernels_f64_sym.hip — K1s-f64: the fp64 all-pairs force of large systems (NB_F64, n >= 32768) with every UNORDERED
+// pair evaluated once — Newton's third law — hand-written for gfx950.  The fp64 sibling of K1s (nbody_kernels_f32_sym.hip);
+// replaces, for eps > 0, K1-f64 (nbody_kernels_f64.hip: every ordered pair, 17 fp64 VALU + v_rsq_f64 per pair = 84 SIMD cycles
+// per 64 pairs) in run_step's accel phase (samples/nbody.cc:56-74; hw5.cu:159-215 with its three fp64 atomics per pair).
+//
+// One pair evaluation serves both bodies: 3 add, 3 fma, v_rsq_f64 + 5 (Halley), 2 mul (y^3), 2 mul (x G*m_j, x G*m_i),
+// 3 fma (a_i), 3 fma (a_j) = 21 fp64 VALU (4 cycles) + 16 = 100 cycles per 64 pair evaluations = 50 per 64 interactions.
+// The scheme is K1s': a lane owns R = 4 targets in registers and ONE source that travels — {x, y, z, G*m} and its three
+// accumulators, 7 doubles = 14 v_mov_b32_dpp wave_ror:1 per step, so 57 cycles per 64 interactions with the moves — a
+// workgroup (8 waves) owns a superblock of 2048 bodies and meets another in 32 phases of 64-source tiles, adding its
+// travelling sums into an fp64 LDS image (48 KB) by plain read-modify-write (distinct tiles per phase, a barrier between
+// phases: bitwise reproducible); the pair schedule, the cut into chunks and the slots are K1s' own (sym_chunk_range,
+// sym_piece, sym_piece_slot, sym_for_each_slot_of in nbody_kernels.h — the host self-test covers them), with slots of three
+// fp64 planes.  G*m_eff of the step comes from nbody_gm_f64 (the device-mass law, nbody.cc:14-16), the reducer sums a body's
+// slots and does the non-contracted kick-drift (nbody.cc:76-88) like K1-f64's.
+#include <type_traits>
+
+#include "nbody_kernels.h"
+
+namespace nbk {
+
+namespace {
+
+constexpr int R = 4, WGS = 512, NW = WGS / 64, SB = SYM64_SB, NT = SYM_NT;
+static_assert(SB == WGS * R && SB / 64 == NT && NT == NW * R, "superblock = 32 tiles of 64 sources, 4 per wave and phase");
+
+__device__ __forceinline__ double rsqrt_fast64(double x) {  // as nbody_kernels_f64.hip: v_rsq_f64 + one Halley step
+    double y = __builtin_amdgcn_rsq(x);
+    double e = __builtin_fma(-x * y, y, 1.0);
+    double t = __builtin_fma(0.375, e, 0.5);
+    return __builtin_fma(y * e, t, y);
+}
+__device__ __forceinline__ double rot(double v) {  // lane l <- lane l-1, wave-wide: two v_mov_b32_dpp wave_ror:1
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, 0x13C, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, 0x13C, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(WGS, 1) void nbody_force_sym_f64(F64LargeArgs a, F32SymShape sh) {
+    __shared__ double lds[3][SB];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int B = sh.B, n = a.n;
+    const int G = (int)gridDim.x;
+    const int g = (G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    const int chunk = g / sh.nb, b = sh.b0 + g % sh.nb;
+    const long ibase = (long)b * SB;
+    const double* __restrict__ qx = a.q;
+    const double* __restrict__ qy = a.q + n;
+    const double* __restrict__ qz = a.q + 2 * (size_t)n;
+    const double* __restrict__ gm = a.gm;
+    // past the end: a massless body at the origin — adds exactly +0 (eps2 > 0)
+    auto X = [&](long i) { return i < n ? qx[i] : 0.0; };
+    auto Y = [&](long i) { return i < n ? qy[i] : 0.0; };
+    auto Z = [&](long i) { return i < n ? qz[i] : 0.0; };
+    auto M = [&](long i) { return i < n ? gm[i] : 0.0; };
+
+    double xi[R], yi[R], zi[R], gi[R], ax[R], ay[R], az[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const long i = ibase + (long)r * WGS + t;
+        xi[r] = X(i); yi[r] = Y(i); zi[r] = Z(i); gi[r] = M(i);
+        ax[r] = ay[r] = az[r] = 0.0;
+    }
+    const double eps2 = a.eps2;
+
+    // one tile of 64 sources (this lane's: xj..gj) against the lane's 4 targets: 64 rotation steps
+    auto tile_pass = [&](double xj, double yj, double zj, double gj, auto sym, double& ajx, double& ajy, double& ajz) {
+        constexpr bool SYM = decltype(sym)::value;
+        ajx = ajy = ajz = 0.0;
+#pragma unroll 1
+        for (int s = 0; s < 64; ++s) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const double dx = xj - xi[r], dy = yj - yi[r], dz = zj - zi[r];
+                const double r2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, __builtin_fma(dx, dx, eps2)));
+                const double y = rsqrt_fast64(r2);
+                const double y3 = y * y * y;
+                const double si = gj * y3;
+                ax[r] = __builtin_fma(dx, si, ax[r]); ay[r] = __builtin_fma(dy, si, ay[r]); az[r] = __builtin_fma(dz, si, az[r]);
+                if (SYM) {
+                    const double sj = gi[r] * y3;
+                    ajx = __builtin_fma(-dx, sj, ajx); ajy = __builtin_fma(-dy, sj, ajy); ajz = __builtin_fma(-dz, sj, ajz);
+                }
+            }
+            xj = rot(xj); yj = rot(yj); zj = rot(zj); gj = rot(gj);
+            if (SYM) { ajx = rot(ajx); ajy = rot(ajy); ajz = rot(ajz); }
+        }
+    };
+    using Yes = std::true_type;
+    using No = std::false_type;
+
+    long q, q_hi;
+    sym_chunk_range(sh, b, chunk, &q, &q_hi);
+    double ajx, ajy, ajz;
+    bool lds_clean = false;
+    while (q < q_hi) {
+        int u, ph0, ph1;
+        q = sym_piece(q, q_hi, &u, &ph0, &ph1);
+        if (u == 0) {  // the superblock against itself, without the symmetric half; the self pair adds exactly +0
+            for (int k = ph0; k < ph1; ++k) {
+                const long j = ibase + (long)k * 64 + lane;
+                tile_pass(X(j), Y(j), Z(j), M(j), No{}, ajx, ajy, ajz);
+            }
+            continue;
+        }
+        if (!lds_clean) {
+#pragma unroll
+            for (int k = 0; k < R; ++k) lds[0][k * WGS + t] = lds[1][k * WGS + t] = lds[2][k * WGS + t] = 0.0;
+            __syncthreads();
+            lds_clean = true;
+        }
+        const int J = (b + u) % B;
+        const long jbase = (long)J * SB;
+        for (int ph = ph0; ph < ph1; ++ph) {
+            const int tile = (ph + w * R) & (NT - 1);
+            const long j = jbase + (long)tile * 64 + lane;
+            tile_pass(X(j), Y(j), Z(j), M(j), Yes{}, ajx, ajy, ajz);
+            const int e = tile * 64 + lane;  // distinct tiles per wave within a phase: plain read-modify-write
+            lds[0][e] += ajx; lds[1][e] += ajy; lds[2][e] += ajz;
+            __syncthreads();
+        }
+        const int slot = sym_piece_slot(sh, false, b, chunk, u, ph0);
+        double* out = a.sym_slots + (long)slot * 3 * sh.npad + jbase;  // a slot = three fp64 planes of npad bodies
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int e = k * WGS + t;
+            out[e] = lds[0][e]; out[sh.npad + e] = lds[1][e]; out[2 * sh.npad + e] = lds[2][e];
+            lds[0][e] = lds[1][e] = lds[2][e] = 0.0;
+        }
+        __syncthreads();
+    }
+    double* own = a.sym_slots + (long)chunk * 3 * sh.npad + ibase;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const long i = (long)r * WGS + t;
+        own[i] = ax[r]; own[sh.npad + i] = ay[r]; own[2 * sh.npad + i] = az[r];
+    }
+}
+
+template <bool ACCEL_ONLY>
+__global__ __launch_bounds__(WG) void nbody_reduce_sym_f64(F64LargeArgs a, F32SymShape sh) {
+    const int i = blockIdx.x * WG + threadIdx.x, n = a.n;
+    if (i >= n) return;
+    const double* ws = a.sym_slots + i;
+    const long plane = sh.npad;
+    double ax = 0, ay = 0, az = 0;
+    sym_for_each_slot_of(sh, false, i / SB, [&](long slot) {
+        const double* p = ws + slot * 3 * plane;
+        ax += p[0]; ay += p[plane]; az += p[2 * plane];
+    });
+    if (ACCEL_ONLY) {
+        a.acc_out[i] = ax; a.acc_out[n + i] = ay; a.acc_out[2 * (size_t)n + i] = az;
+    } else {  // kick, drift (nbody.cc:76-88), non-contracted like K2 and K1-f64
+        const double vx = __dadd_rn(a.v[i], __dmul_rn(ax, a.dt));
+        const double vy = __dadd_rn(a.v[n + i], __dmul_rn(ay, a.dt));
+        const double vz = __dadd_rn(a.v[2 * (size_t)n + i], __dmul_rn(az, a.dt));
+        a.v[i] = vx; a.v[n + i] = vy; a.v[2 * (size_t)n + i] = vz;
+        a.qout[i] = __dadd_rn(a.q[i], __dmul_rn(vx, a.dt));
+        a.qout[n + i] = __dadd_rn(a.q[n + i], __dmul_rn(vy, a.dt));
+        a.qout[2 * (size_t)n + i] = __dadd_rn(a.q[2 * (size_t)n + i], __dmul_rn(vz, a.dt));
+    }
+}
+
+// (defined in nbody_kernels_f64.hip)
+__global__ void nbody_gm_f64(const double* __restrict__ m, const double* __restrict__ coef, double* __restrict__ gm, int n,
+                             double fst, double G);
+
+size_t sym64_workspace_bytes(int n, int n_cus) {
+    if (n < 16 * SB) return 0;
+    const F32SymShape s = sym_shape(n, n_cus, 0, 0, 0, SB);
+    const size_t bytes = (size_t)sym_total_slots(s, false) * (size_t)s.npad * 3 * sizeof(double);
+    return bytes <= SYM64_MAX_WORKSPACE ? bytes : 0;
+}
+
+int launch_f64_large_sym(const F64LargeArgs& a, int n_cus, hipStream_t stream) {
+    if (!a.sym_slots || !a.gm || !(a.eps2 > 0.0) || a.n < 16 * SB) return (int)hipErrorInvalidValue;
+    const F32SymShape sh = sym_shape(a.n, n_cus, 0, 0, 0, SB);
+    const unsigned b1 = (unsigned)((a.n + WG - 1) / WG);
+    hipLaunchKernelGGL(nbody_gm_f64, dim3(b1), dim3(WG), 0, stream, a.m, a.coef, a.gm, a.n, a.fst, a.G);
+    hipLaunchKernelGGL(nbody_force_sym_f64, dim3((unsigned)(sh.nb * sh.chunks)), dim3(WGS), 0, stream, a, sh);
+    if (hipError_t e = hipGetLastError()) return (int)e;
+    if (a.acc_out) hipLaunchKernelGGL(nbody_reduce_sym_f64<true>, dim3(b1), dim3(WG), 0, stream, a, sh);
+    else hipLaunchKernelGGL(nbody_reduce_sym_f64<false>, dim3(b1), dim3(WG), 0, stream, a, sh);
+    return (int)hipGetLastError();
+}
+
+}  // namespace nbk
