@@ -220,7 +220,8 @@ int nb_create_cu_masked(nb_context** out, const nb_config* cfg, int cu_mask) {
 int nbi::create_context(nb_context** out, const nb_config* cfg, hipStream_t borrowed, int cu_mask) {
     if (!out || !cfg || cfg->n <= 0) return NB_ERR_INVALID;
     if (cfg->precision < NB_F64 || cfg->precision > NB_F32_ACC64) return NB_ERR_INVALID;
-    if (cfg->precision != NB_F64 && !(cfg->eps > 0)) return NB_ERR_INVALID;  // fp32 kernels evaluate the self pair
+    // fp32 kernels evaluate the self pair: eps^2 must survive the rounding to fp32 (1e-23 squared would not)
+    if (cfg->precision != NB_F64 && !((float)(cfg->eps * cfg->eps) > 0.f)) return NB_ERR_INVALID;
     if (cfg->reserved != 0) return NB_ERR_INVALID;
     if (cfg->f64_split < 0 || cfg->f64_split > 64 || (cfg->f64_split & (cfg->f64_split - 1))) return NB_ERR_INVALID;
     int ndev = 0;

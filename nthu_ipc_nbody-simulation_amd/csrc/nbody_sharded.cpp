@@ -394,7 +394,7 @@ int create_impl(nb_sharded** out, const int* devices, int n_devices, int64_t n, 
     *out = nullptr;
     if (!devices || n_devices <= 0 || n_devices > 64 || n <= 0) return fail(nullptr, NB_ERR_INVALID, "nb_sharded_create", "bad argument");
     if (precision != NB_F32 && precision != NB_F32_ACC64) return fail(nullptr, NB_ERR_INVALID, "nb_sharded_create", "precision must be NB_F32 or NB_F32_ACC64");
-    if (!(eps > 0)) return fail(nullptr, NB_ERR_INVALID, "nb_sharded_create", "fp32 kernels need eps > 0");
+    if (!((float)(eps * eps) > 0.f)) return fail(nullptr, NB_ERR_INVALID, "nb_sharded_create", "fp32 kernels need eps > 0 (eps^2 representable in fp32)");
     if (n % n_devices) return fail(nullptr, NB_ERR_INVALID, "nb_sharded_create", "n must be divisible by the number of devices");
     // overlap cuts the sources at shard boundaries: they must fall on whole 256-body tiles
     if ((flags & NB_SHARDED_OVERLAP) && n_devices > 1 && (n / n_devices) % TILE)

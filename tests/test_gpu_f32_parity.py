@@ -173,6 +173,8 @@ def test_spot_check_n2e22(nb, oracle):
 def test_fp32_rejects_eps_zero_and_devices(nb):
     with pytest.raises(nb.capi.NBodyError):
         nb.capi.Context(16, nb.capi.NB_F32, 0, eps=0.0)
+    with pytest.raises(nb.capi.NBodyError):
+        nb.capi.Context(16, nb.capi.NB_F32, 0, eps=1e-23)  # eps^2 underflows fp32: the self pair would be 0 * inf
     with nb.capi.Context(16, nb.capi.NB_F32, 0) as ctx:
         q = np.zeros((3, 16)); q[0] = np.arange(16)
         with pytest.raises(nb.capi.NBodyError):
