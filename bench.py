@@ -37,6 +37,25 @@ ISSUE_CEILING_FRAC = 0.62     # K1 (every ordered pair): what the pair loop's in
 ISSUE_CEILING_FRAC_SYM = 0.92   # K1s (every unordered pair once): 16 packed VALU + 2 v_rsq_f32 per 4 interactions + 14 DPP moves / 32
 
 
+_JSON_FD = None
+
+
+def only_the_json_line_on_stdout():
+    """Rank 0 prints ONE JSON line: libraries that write to the process's stdout on their own (librccl prints a banner — ROCm
+    version, hostname, library path — when it is loaded) are sent to stderr at the file-descriptor level; emit() writes
+    the line to the real stdout."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line):
+    sys.stdout.flush()
+    os.write(_JSON_FD if _JSON_FD is not None else 1, (line + "\n").encode())
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -546,7 +565,7 @@ def main_native(args):
                                         "kernel": kname},
                            **ab, "note": "same system, few steps, each variant its own child process after the timed region"}
         out["replicas"] = replicas_check(devices)
-    print(json.dumps(out), flush=True)
+    emit(json.dumps(out))
 
 
 def conservation(torch, sysm, n, sample=1024):
@@ -626,6 +645,7 @@ def main():
                     "the multi-rank path on a one-GPU box (RCCL refuses two ranks on one device)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     args = ap.parse_args()
+    only_the_json_line_on_stdout()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.host == "native" or (args.host == "auto" and args.gpus > 1 and world == 1):
@@ -993,7 +1013,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(n)
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 
