@@ -27,9 +27,9 @@ def _env():
 
 def _line(p):
     assert p.returncode == 0, (p.returncode, p.stderr[-3000:])
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, p.stdout[-2000:]  # ONE JSON line
-    return json.loads(lines[0])
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), p.stdout[-2000:]  # ONE JSON line and nothing else on stdout (librccl's
+    return json.loads(lines[0])                                             # load banner goes to stderr)
 
 
 def _free_port():
