@@ -111,7 +111,7 @@ class ShardedSystem:
     """N bodies sharded by index over the ranks of the default process group (or unsharded when world == 1)."""
 
     def __init__(self, n, pos_shard, vel_shard, eps, dt, device, compute=None, acc64=False, group=None, trace=False,
-                 exchange="in_place", overlap=False, shared_pairs=None):
+                 exchange="in_place", overlap=False, shared_pairs=None, pair_steps=None):
         self.dist_on = dist.is_initialized()  # a one-rank group still runs the collective (tests the in-place call)
         self.world = dist.get_world_size(group) if self.dist_on else 1
         self.rank = dist.get_rank(group) if self.dist_on else 0
@@ -138,9 +138,14 @@ class ShardedSystem:
         # share the unordered pairs of the system among the ranks (K1s + reduce-scatter of partial forces)?  Default: yes
         # where it applies — several ranks, the all-gather form, no two-phase step, the product's HIP compute (an injected
         # `compute`, as the CPU tests use, keeps the ordered form), device tensors, whole superblocks per shard
-        can = (self.world > 1 and not self.ring and not self.overlap and torch.device(device).type == "cuda"
-               and (compute is None or (getattr(compute, "is_hip_compute", False) and not compute.forced))
-               and capi.workspace_bytes_shared_pairs_f32(n, self.world, acc64) > 0)
+        # `pair_steps` = (pair_forces, kick_drift) injects the two launches of that step, as `compute` injects the ordered one:
+        # the CPU tests pass oracle stand-ins (tests/test_distributed_gloo.py) — test infrastructure, not a product fallback
+        self._pair_steps = pair_steps
+        can = (self.world > 1 and not self.ring and not self.overlap and
+               (pair_steps is not None or
+                (torch.device(device).type == "cuda"
+                 and (compute is None or (getattr(compute, "is_hip_compute", False) and not compute.forced))
+                 and capi.workspace_bytes_shared_pairs_f32(n, self.world, acc64) > 0)))
         if shared_pairs and not can:
             raise ValueError("shared_pairs needs >= 2 ranks, HIP tensors, the all-gather exchange without overlap, "
                              "n % (4096 * world) == 0 and n >= 49152")
@@ -188,7 +193,7 @@ class ShardedSystem:
         self.pos[0][self.lo:self.hi] = pos_shard.to(device=device, dtype=torch.float32)
         self._exchange(self.pos[0])
         self.pos[1].copy_(self.pos[0])  # G*m column of the other buffer for slots this rank never writes
-        if self.shared_pairs:
+        if self.shared_pairs and self._pair_steps is None:
             self._alloc_shared_pairs(self.pos[0].device)  # not inside somebody's timed first step
 
     @property
@@ -308,10 +313,30 @@ class ShardedSystem:
             self._pair_ws = torch.empty(capi.workspace_bytes_shared_pairs_f32(self.n, self.world, self.acc64),
                                         dtype=torch.uint8, device=dev)
 
+    def _reduce_scatter_forces(self):
+        """Sum of the ranks' partial forces, every rank keeping its own shard of it."""
+        if dist.get_backend(self.group) == "nccl":
+            dist.reduce_scatter_tensor(self._facc, self._fpart, op=dist.ReduceOp.SUM, group=self.group)
+        else:  # gloo (CPU tests, rehearsal on one GPU): the same sum through host memory
+            host = self._fpart.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            self._facc.copy_(host[self.lo:self.hi])
+
     def _step_shared_pairs(self, src, out):
         """K1s on this rank's share of the unordered pairs -> partial force on all N bodies -> reduce-scatter -> kick-drift
         of the own shard -> all-gather of the positions."""
         dev = src.device
+        if self._pair_steps is not None:  # injected stand-ins (CPU tests): same sequence, same collectives
+            pair_forces, kick_drift = self._pair_steps
+            fdt = torch.float64 if self.acc64 else torch.float32
+            if self._fpart is None:
+                self._fpart = torch.zeros((self.n, 4), dtype=fdt, device=dev)
+                self._facc = torch.zeros((self.n_tgt, 4), dtype=fdt, device=dev)
+            pair_forces(src, self.lo, self.n_tgt, self.eps2, self._fpart)
+            self._reduce_scatter_forces()
+            kick_drift(src, out, self.vel, self.lo, self.n_tgt, self.dt, self._facc, self.pos64, self.vel64)
+            self._exchange(out)
+            return
         self._alloc_shared_pairs(dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
         if self.kernel_events is not None:
@@ -322,12 +347,7 @@ class ShardedSystem:
         if self.kernel_events is not None:
             e1.record()
             self.kernel_events.append((e0, e1))
-        if dist.get_backend(self.group) == "nccl":
-            dist.reduce_scatter_tensor(self._facc, self._fpart, op=dist.ReduceOp.SUM, group=self.group)
-        else:  # gloo rehearsal on one GPU: the same sum through host memory
-            host = self._fpart.cpu()
-            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
-            self._facc.copy_(host[self.lo:self.hi])
+        self._reduce_scatter_forces()
         capi.launch_kick_drift_f32(src.data_ptr(), out.data_ptr(), self.n, self.lo, self.n_tgt, self.dt, stream,
                                    self._facc.data_ptr(), parts=1, vel_ptr=self.vel.data_ptr(),
                                    pos64_ptr=self.pos64.data_ptr() if self.pos64 is not None else 0,

@@ -53,6 +53,68 @@ def _oracle_compute(O, G, eps):
     return compute
 
 
+def _oracle_pair_steps(G, eps, n, world):
+    """Stand-ins for the two launches of the shared-pairs step (K1s share + kick-drift), same rule at the size of one body:
+    the unordered pair {i, j} belongs to body i when (j - i) mod n is in 1..n/2-1, or is n/2 with i in the first half — the
+    cyclic schedule of csrc/nbody_kernels.h (sym_rounds) with superblocks of one body — and to the rank whose shard holds i.
+    The owner adds +f to i's row and -f to j's row of its partial force on ALL n bodies."""
+    i = np.arange(n)[:, None]
+    d = (np.arange(n)[None, :] - i) % n
+    owned_by_i = ((d >= 1) & (d < n // 2)) | ((d == n // 2) & (i < n // 2)) if n % 2 == 0 else ((d >= 1) & (d <= n // 2))
+    assert np.array_equal(owned_by_i | owned_by_i.T, ~np.eye(n, dtype=bool)) and not (owned_by_i & owned_by_i.T).any()
+
+    def pair_forces(src, lo, n_tgt, eps2, fpart):
+        p = src.numpy().astype(np.float64)
+        dvec = p[None, :, :3] - p[:, None, :3]                       # [i, j] = q_j - q_i
+        w = (np.square(dvec).sum(axis=2) + eps * eps) ** -1.5
+        pull = w[:, :, None] * dvec                                  # [i, j] * G m_j = acceleration of i towards j
+        gm = p[:, 3]
+        mine = np.zeros((n, n), dtype=bool)
+        mine[lo:lo + n_tgt] = owned_by_i[lo:lo + n_tgt]              # the pairs this rank evaluates
+        a = (np.where(mine[:, :, None], pull, 0.0) * gm[None, :, None]).sum(axis=1)          # +f on the owner side
+        a -= (np.where(mine[:, :, None], pull, 0.0) * gm[:, None, None]).sum(axis=0)         # -f on the partner's row
+        f = fpart.numpy()
+        f[:, :3] = a.astype(f.dtype)
+        f[:, 3] = 0
+
+    def kick_drift(src, out, vel, lo, n_tgt, dt, facc, pos64, vel64):
+        p = src.numpy().astype(np.float64)
+        v = vel.numpy()
+        v[:, :3] = (v[:, :3].astype(np.float64) + facc.numpy()[:, :3].astype(np.float64) * dt).astype(np.float32)
+        o = out.numpy()
+        o[lo:lo + n_tgt, :3] = (p[lo:lo + n_tgt, :3] + v[:, :3].astype(np.float64) * dt).astype(np.float32)
+        o[lo:lo + n_tgt, 3] = p[lo:lo + n_tgt, 3].astype(np.float32)
+    return pair_forces, kick_drift
+
+
+def _run_shared(rank, world, port, result_path, acc64):
+    """The default multi-rank step (ranks share the unordered pairs): partial force on all bodies -> sum over ranks, each
+    keeping its shard -> kick-drift -> all-gather; arithmetic injected as above."""
+    sys.path.insert(0, ROOT)
+    import nbody_amd  # noqa: F401
+    from nbody_amd import synthetic
+    from nbody_amd.distributed import ShardedSystem, shard_range
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    lo, hi = shard_range(N, rank, world)
+    pos, vel = synthetic.body4_f32(N, lo, hi)
+    sysm = ShardedSystem(N, torch.from_numpy(pos), torch.from_numpy(vel), synthetic.EPS, 1e-2, torch.device("cpu"),
+                         acc64=acc64, pair_steps=_oracle_pair_steps(synthetic.G, synthetic.EPS, N, world))
+    assert sysm.shared_pairs and sysm.exchange_mode == "list"
+    for _ in range(STEPS):
+        sysm.step()
+    assert sysm._fpart.dtype == (torch.float64 if acc64 else torch.float32) and sysm._facc.shape == (hi - lo, 4)
+    full = sysm.positions.clone()
+    ref = full.clone()
+    dist.broadcast(ref, 0)
+    assert torch.equal(ref, full), "ranks disagree on gathered positions"
+    vels = [torch.zeros_like(sysm.vel) for _ in range(world)]
+    dist.all_gather(vels, sysm.vel)
+    if rank == 0:
+        np.savez(result_path, pos=full.numpy(), vel=torch.cat(vels).numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def _run(rank, world, port, result_path, overlap=False, exchange="in_place", ckpt=None):
     sys.path.insert(0, ROOT)
     import nbody_amd  # noqa: F401
@@ -111,6 +173,34 @@ def test_two_ranks_equal_one_rank(oracle, tmp_path):
     from nbody_amd import synthetic
     p0, _ = synthetic.body4_f32(N)
     assert not np.array_equal(p0[:, :3], b["pos"][:, :3]) and np.array_equal(p0[:, 3], b["pos"][:, 3])
+
+
+@pytest.mark.parametrize("world,acc64", [(2, False), (2, True), (4, False)])
+def test_ranks_sharing_the_unordered_pairs_equal_one_rank(oracle, tmp_path, world, acc64):
+    """What bench.py --gpus P runs by default from two ranks up: every unordered pair evaluated once, by one rank; the
+    partial forces summed across the ranks.  Same trajectory as the one-rank run to the rounding of the partial forces
+    (fp32 partials: a few ulp of the acceleration; fp64 partials: the last bit of the fp32 state)."""
+    one, two = str(tmp_path / "one.npz"), str(tmp_path / "shared.npz")
+    _run(0, 1, 0, one)
+    mp.spawn(_run_shared, args=(world, _free_port(), two, acc64), nprocs=world, join=True)
+    a, b = np.load(one), np.load(two)
+    scale = np.abs(a["vel"][:, :3]).max()
+    tol_v = (1e-9 if acc64 else 3e-6) * max(scale, 1.0)
+    assert np.abs(a["vel"] - b["vel"]).max() <= tol_v, np.abs(a["vel"] - b["vel"]).max()
+    assert np.abs(a["pos"] - b["pos"]).max() <= (1.2e-7 if acc64 else 5e-7), np.abs(a["pos"] - b["pos"]).max()
+    assert np.array_equal(a["pos"][:, 3], b["pos"][:, 3])
+
+
+def test_shared_pairs_is_refused_where_it_cannot_run():
+    """One rank, or the two-phase / ring steps: asking for shared pairs explicitly is an error, not a silent other path."""
+    sys.path.insert(0, ROOT)
+    import nbody_amd  # noqa: F401
+    from nbody_amd import synthetic
+    from nbody_amd.distributed import ShardedSystem
+    pos, vel = synthetic.body4_f32(N)
+    with pytest.raises(ValueError, match="shared_pairs needs"):
+        ShardedSystem(N, torch.from_numpy(pos), torch.from_numpy(vel), synthetic.EPS, 1e-2, torch.device("cpu"),
+                      shared_pairs=True, pair_steps=(None, None))
 
 
 def test_overlapped_two_phase_step_equals_plain_step(oracle, tmp_path):
