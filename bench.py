@@ -38,6 +38,7 @@ ISSUE_CEILING_FRAC_SYM = 0.92   # K1s (every unordered pair once): 16 packed VAL
 
 
 _JSON_FD = None
+_T0 = time.perf_counter()  # process start, for the line's wall_s
 
 
 def only_the_json_line_on_stdout():
@@ -49,6 +50,15 @@ def only_the_json_line_on_stdout():
         sys.stdout.flush()
         _JSON_FD = os.dup(1)
         os.dup2(2, 1)
+
+
+def with_wall(out):
+    """What a clock around the whole command sees next to what the line's value is computed from."""
+    out["wall_s"] = {"process": round(time.perf_counter() - _T0, 2),
+                     "timed_region": round(out["ms_per_step"] * out["steps"] * 1e-3, 3),
+                     "note": "process = imports, set-up, warm-up, the timed region (the K steps `value` and `ms_per_step` come "
+                             "from) and the diagnostics after it (parity_spot, cpu_baseline, PMC passes, variants, ...)"}
+    return out
 
 
 def emit(line):
@@ -565,7 +575,7 @@ def main_native(args):
                                         "kernel": kname},
                            **ab, "note": "same system, few steps, each variant its own child process after the timed region"}
         out["replicas"] = replicas_check(devices)
-    emit(json.dumps(out))
+    emit(json.dumps(with_wall(out)))
 
 
 def conservation(torch, sysm, n, sample=1024):
@@ -1013,7 +1023,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(n)
-        emit(json.dumps(out))
+        emit(json.dumps(with_wall(out)))
     if world > 1:
         dist.destroy_process_group()
 

@@ -47,6 +47,7 @@ def test_native_host_line_without_a_launcher(nb):
     assert r["n_gpus"] == 2 and r["host"] == "native" and r["steps"] == 3 and r["unit"] == "pairs/s"
     assert r["config"]["bodies"] == 131072 and r["scaling"] == "strong" and r["exchange"] == "copy-one-gpu"
     assert r["value"] == pytest.approx(131072 * 131071 * 3 / (r["ms_per_step"] * 3e-3), rel=1e-9)
+    assert r["wall_s"]["process"] > r["wall_s"]["timed_region"] == pytest.approx(r["ms_per_step"] * 3e-3, abs=1e-3)
     # who ran: two ranks, one device here (they share it), each with its own shard
     rk = r["ranks"]
     assert rk["count"] == 2 and rk["distinct_devices"] == 1 and rk["exchange"] == "copy"
