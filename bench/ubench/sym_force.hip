@@ -51,6 +51,7 @@ struct SymArgs {
     long n;             // multiple of SB
     int B;              // superblocks
     float eps2;
+    unsigned long long* clk;  // V = 8: per wave {cycles inside the rotation loops, cycles of the whole kernel, rotation steps}
 };
 
 // V = 0: as the product kernel.  V = 1: the travelling POSITIONS come from an LDS copy of the wave's tile (two ds_read_b128
@@ -82,6 +83,9 @@ __global__ __launch_bounds__(WGS, V == 2 ? 4 : 1) void sym_force(SymArgs a) {
         ax[p] = ay[p] = az[p] = sx[p] = sy[p] = sz[p] = cx[p] = cy[p] = cz[p] = splat(0.f);
     }
     const v2f eps2 = splat(a.eps2);
+    // V = 8: where the time goes — shader-clock stamps around every 64-step rotation loop and around the kernel
+    unsigned long long loop_cycles = 0, loop_steps = 0, k0 = 0;
+    if (V == 8) k0 = __builtin_amdgcn_s_memtime();
     auto flush = [&]() {
         if (V == 2) return;
 #pragma unroll
@@ -100,12 +104,17 @@ __global__ __launch_bounds__(WGS, V == 2 ? 4 : 1) void sym_force(SymArgs a) {
         v2f xj = (v2f){j0.x, j1.x}, yj = (v2f){j0.y, j1.y}, zj = (v2f){j0.z, j1.z}, gj = (v2f){j0.w, j1.w};
         ajx = ajy = ajz = splat(0.f);
         float4 n0 = j0, n1 = j1;
+        unsigned long long c0 = 0;
+        if (V == 8) c0 = __builtin_amdgcn_s_memtime();
         if (V == 1) {  // (wave-private rows of jt: no barrier, the wave runs in lock step)
             jt[w][lane] = j0; jt[w][64 + lane] = j1;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             n0 = jt[w][(lane - 1) & 63]; n1 = jt[w][64 + ((lane - 1) & 63)];
         }
-#pragma unroll 1
+#ifndef SYM_ROT_UNROLL
+#define SYM_ROT_UNROLL 1  // -DSYM_ROT_UNROLL=2: half the taken branches of the rotation loop (A/B: +0.4 %)
+#endif
+#pragma unroll SYM_ROT_UNROLL
         for (int s = 0; s < 64; ++s) {
             float4 m0 = n0, m1 = n1;
             if (V == 1) { m0 = jt[w][(lane - s - 2) & 63]; m1 = jt[w][64 + ((lane - s - 2) & 63)]; }  // for step s + 2
@@ -175,6 +184,7 @@ __global__ __launch_bounds__(WGS, V == 2 ? 4 : 1) void sym_force(SymArgs a) {
             if (SYM && V == 3) { ajx = rowrot(ajx); ajy = rowrot(ajy); ajz = rowrot(ajz); }
             else if (SYM && V != 4) { ajx = rot(ajx); ajy = rot(ajy); ajz = rot(ajz); }
         }
+        if (V == 8) { loop_cycles += __builtin_amdgcn_s_memtime() - c0; loop_steps += 64; }
     };
 
     using T = std::true_type;
@@ -225,6 +235,10 @@ __global__ __launch_bounds__(WGS, V == 2 ? 4 : 1) void sym_force(SymArgs a) {
         if (V == 2) { sx[p] = ax[p]; sy[p] = ay[p]; sz[p] = az[p]; }
         own[ibase + (long)(2 * p) * WGS + t] = make_float4(sx[p].x, sy[p].x, sz[p].x, 0.f);
         own[ibase + (long)(2 * p + 1) * WGS + t] = make_float4(sx[p].y, sy[p].y, sz[p].y, 0.f);
+    }
+    if (V == 8 && lane == 0) {
+        unsigned long long* c = a.clk + ((long)blockIdx.x * NW + w) * 3;
+        c[0] = loop_cycles; c[1] = __builtin_amdgcn_s_memtime() - k0; c[2] = loop_steps;
     }
 }
 
@@ -277,7 +291,10 @@ static void run(long n, int reps, int C) {
     CK(hipMalloc(&acc, n * sizeof(float4)));
     CK(hipMemcpy(src, h.data(), n * sizeof(float4), hipMemcpyHostToDevice));
     CK(hipMemset(partial, 0, (size_t)nslots * n * sizeof(float4)));
-    SymArgs a{src, partial, n, B, 1e-6f};
+    unsigned long long* clk = nullptr;
+    const long nwaves = (long)B * C * (WGS / 64);
+    if (V == 8) { CK(hipMalloc(&clk, nwaves * 3 * sizeof(unsigned long long))); CK(hipMemset(clk, 0, nwaves * 3 * sizeof(unsigned long long))); }
+    SymArgs a{src, partial, n, B, 1e-6f, clk};
     hipEvent_t e0, e1, e2;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
     float best = 1e30f, best_red = 0;
@@ -298,6 +315,21 @@ static void run(long n, int reps, int C) {
     printf("V=%d C=%d P=%d WGS=%d SB=%d B=%d slots=%d (workspace %.2f GB): force %.3f ms + reduce %.3f ms -> %.4e pairs/s = %.3f of 157.3 TF at 20 flop/pair\n",
            V, C, P, WGS, SB, B, nslots, (double)nslots * n * 16 / 1e9, best, best_red, pairs / ((best + best_red) * 1e-3),
            pairs * 20 / ((best + best_red) * 1e-3) / 157.3e12);
+    if (V == 8) {  // per wave: cycles per rotation step inside the loop, and the loop's share of the wave's life
+        std::vector<unsigned long long> c(nwaves * 3);
+        CK(hipMemcpy(c.data(), clk, c.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        std::vector<double> per_step, share;
+        for (long i = 0; i < nwaves; ++i) if (c[3 * i + 2]) {
+            per_step.push_back((double)c[3 * i] / (double)c[3 * i + 2]);
+            share.push_back((double)c[3 * i] / (double)c[3 * i + 1]);
+        }
+        std::sort(per_step.begin(), per_step.end()); std::sort(share.begin(), share.end());
+        const size_t m = per_step.size();
+        printf("  stamps (%zu waves): shader-clock cycles per rotation step of one wave, inside the loop: min %.1f  median %.1f  max %.1f"
+               "  (two waves share a SIMD: ideal 2 x 696 = 1392);\n  share of a wave's life inside the rotation loops: min %.4f  median %.4f  max %.4f\n",
+               m, per_step[0], per_step[m / 2], per_step[m - 1], share[0], share[m / 2], share[m - 1]);
+        CK(hipFree(clk));
+    }
     // check 16 rows against fp64 on the host
     std::vector<float4> out(n);
     CK(hipMemcpy(out.data(), acc, n * sizeof(float4), hipMemcpyDeviceToHost));
@@ -334,6 +366,7 @@ int main(int argc, char** argv) {
     else if (P == 4 && wgs == 512 && V == 5) run<4, 512, 5>(n, reps, C);
     else if (P == 4 && wgs == 512 && V == 6) run<4, 512, 6>(n, reps, C);
     else if (P == 4 && wgs == 512 && V == 4) run<4, 512, 4>(n, reps, C);
+    else if (P == 4 && wgs == 512 && V == 8) run<4, 512, 8>(n, reps, C);
     else if (P == 4 && wgs == 256 && V == 0) run<4, 256, 0>(n, reps, C);
     else if (P == 2 && wgs == 512 && V == 0) run<2, 512, 0>(n, reps, C);
     else if (P == 2 && wgs == 1024 && V == 0) run<2, 1024, 0>(n, reps, C);
