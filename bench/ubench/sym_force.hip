@@ -58,6 +58,9 @@ struct SymArgs {
 // per step, issued one step ahead) instead of 8 of the 14 DPP moves; the accumulators still rotate.  V = 2: no second
 // summation level (sums stay in the tile registers) and compiled for two workgroups per CU — not a product candidate
 // (accuracy), the upper bound of what 4 waves per SIMD would buy.
+#ifndef SYM_STAMPS
+#define SYM_STAMPS 0  // -DSYM_STAMPS=1: the stamps of V = 8 in every variant
+#endif
 template <int P, int WGS, int V>
 __global__ __launch_bounds__(WGS, V == 2 ? 4 : 1) void sym_force(SymArgs a) {
     constexpr int NW = WGS / 64, R = 2 * P, SB = WGS * R, NT = SB / 128;
@@ -84,8 +87,9 @@ __global__ __launch_bounds__(WGS, V == 2 ? 4 : 1) void sym_force(SymArgs a) {
     }
     const v2f eps2 = splat(a.eps2);
     // V = 8: where the time goes — shader-clock stamps around every 64-step rotation loop and around the kernel
+    if (V == 9 && w < NW / 2) __builtin_amdgcn_s_setprio(3);  // V = 9: the two waves of a SIMD (w, w + 4) at different priorities
     unsigned long long loop_cycles = 0, loop_steps = 0, k0 = 0;
-    if (V == 8) k0 = __builtin_amdgcn_s_memtime();
+    if (V == 8 || SYM_STAMPS) k0 = __builtin_amdgcn_s_memtime();
     auto flush = [&]() {
         if (V == 2) return;
 #pragma unroll
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(WGS, V == 2 ? 4 : 1) void sym_force(SymArgs a) {
         ajx = ajy = ajz = splat(0.f);
         float4 n0 = j0, n1 = j1;
         unsigned long long c0 = 0;
-        if (V == 8) c0 = __builtin_amdgcn_s_memtime();
+        if (V == 8 || SYM_STAMPS) c0 = __builtin_amdgcn_s_memtime();
         if (V == 1) {  // (wave-private rows of jt: no barrier, the wave runs in lock step)
             jt[w][lane] = j0; jt[w][64 + lane] = j1;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -114,8 +118,27 @@ __global__ __launch_bounds__(WGS, V == 2 ? 4 : 1) void sym_force(SymArgs a) {
 #ifndef SYM_ROT_UNROLL
 #define SYM_ROT_UNROLL 1  // -DSYM_ROT_UNROLL=2: half the taken branches of the rotation loop (A/B: +0.4 %)
 #endif
+        // V = 11: the SIMD's arbiter serves its waves strictly oldest first, so of the two waves that share a SIMD the older
+        // one runs its 64 steps at the speed of a lone wave while the younger one only fills its gaps — and then finishes
+        // alone, with nobody to fill ITS gaps, while the older one waits at the phase barrier.  Lowering the own priority as
+        // the pass advances (s_setprio 3, 2, 1, 0 from steps 0, B0, B1, B2) hands the SIMD to whichever wave is behind.
+#ifndef SYM_PRIO_B0
+#define SYM_PRIO_B0 30
+#define SYM_PRIO_B1 50
+#define SYM_PRIO_B2 61
+#endif
+        int s = 0;
+#pragma unroll 1
+        for (int seg = 0; seg < (V == 11 ? 4 : 1); ++seg) {
+        int s_end = 64;
+        if (V == 11) {
+            if (seg == 0) { __builtin_amdgcn_s_setprio(3); s_end = SYM_PRIO_B0; }
+            else if (seg == 1) { __builtin_amdgcn_s_setprio(2); s_end = SYM_PRIO_B1; }
+            else if (seg == 2) { __builtin_amdgcn_s_setprio(1); s_end = SYM_PRIO_B2; }
+            else { __builtin_amdgcn_s_setprio(0); }
+        }
 #pragma unroll SYM_ROT_UNROLL
-        for (int s = 0; s < 64; ++s) {
+        for (; s < s_end; ++s) {
             float4 m0 = n0, m1 = n1;
             if (V == 1) { m0 = jt[w][(lane - s - 2) & 63]; m1 = jt[w][64 + ((lane - s - 2) & 63)]; }  // for step s + 2
             if (V == 5) {
@@ -157,7 +180,8 @@ __global__ __launch_bounds__(WGS, V == 2 ? 4 : 1) void sym_force(SymArgs a) {
                 ST(r2[g] = pk_fma(dx[g], dx[g], eps2))
                 ST(r2[g] = pk_fma(dy[g], dy[g], r2[g]))
                 ST(r2[g] = pk_fma(dz[g], dz[g], r2[g]))
-                ST(rinv[g] = ((v2f){__builtin_amdgcn_rsqf(r2[g].x), __builtin_amdgcn_rsqf(r2[g].y)}))
+                if (V == 10) { ST(rinv[g] = r2[g]) }  // timing only: no v_rsq_f32 (WRONG results)
+                else { ST(rinv[g] = ((v2f){__builtin_amdgcn_rsqf(r2[g].x), __builtin_amdgcn_rsqf(r2[g].y)})) }
                 ST(r3[g] = rinv[g] * rinv[g])
                 ST(r3[g] = r3[g] * rinv[g])
                 si[0] = gj * r3[0];      si[1] = swp(gj) * r3[1];
@@ -184,7 +208,8 @@ __global__ __launch_bounds__(WGS, V == 2 ? 4 : 1) void sym_force(SymArgs a) {
             if (SYM && V == 3) { ajx = rowrot(ajx); ajy = rowrot(ajy); ajz = rowrot(ajz); }
             else if (SYM && V != 4) { ajx = rot(ajx); ajy = rot(ajy); ajz = rot(ajz); }
         }
-        if (V == 8) { loop_cycles += __builtin_amdgcn_s_memtime() - c0; loop_steps += 64; }
+        }
+        if (V == 8 || SYM_STAMPS) { loop_cycles += __builtin_amdgcn_s_memtime() - c0; loop_steps += 64; }
     };
 
     using T = std::true_type;
@@ -236,7 +261,7 @@ __global__ __launch_bounds__(WGS, V == 2 ? 4 : 1) void sym_force(SymArgs a) {
         own[ibase + (long)(2 * p) * WGS + t] = make_float4(sx[p].x, sy[p].x, sz[p].x, 0.f);
         own[ibase + (long)(2 * p + 1) * WGS + t] = make_float4(sx[p].y, sy[p].y, sz[p].y, 0.f);
     }
-    if (V == 8 && lane == 0) {
+    if ((V == 8 || SYM_STAMPS) && lane == 0) {
         unsigned long long* c = a.clk + ((long)blockIdx.x * NW + w) * 3;
         c[0] = loop_cycles; c[1] = __builtin_amdgcn_s_memtime() - k0; c[2] = loop_steps;
     }
@@ -293,7 +318,7 @@ static void run(long n, int reps, int C) {
     CK(hipMemset(partial, 0, (size_t)nslots * n * sizeof(float4)));
     unsigned long long* clk = nullptr;
     const long nwaves = (long)B * C * (WGS / 64);
-    if (V == 8) { CK(hipMalloc(&clk, nwaves * 3 * sizeof(unsigned long long))); CK(hipMemset(clk, 0, nwaves * 3 * sizeof(unsigned long long))); }
+    if (V == 8 || SYM_STAMPS) { CK(hipMalloc(&clk, nwaves * 3 * sizeof(unsigned long long))); CK(hipMemset(clk, 0, nwaves * 3 * sizeof(unsigned long long))); }
     SymArgs a{src, partial, n, B, 1e-6f, clk};
     hipEvent_t e0, e1, e2;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
@@ -315,7 +340,7 @@ static void run(long n, int reps, int C) {
     printf("V=%d C=%d P=%d WGS=%d SB=%d B=%d slots=%d (workspace %.2f GB): force %.3f ms + reduce %.3f ms -> %.4e pairs/s = %.3f of 157.3 TF at 20 flop/pair\n",
            V, C, P, WGS, SB, B, nslots, (double)nslots * n * 16 / 1e9, best, best_red, pairs / ((best + best_red) * 1e-3),
            pairs * 20 / ((best + best_red) * 1e-3) / 157.3e12);
-    if (V == 8) {  // per wave: cycles per rotation step inside the loop, and the loop's share of the wave's life
+    if (V == 8 || SYM_STAMPS) {  // per wave: cycles per rotation step inside the loop, and the loop's share of the wave's life
         std::vector<unsigned long long> c(nwaves * 3);
         CK(hipMemcpy(c.data(), clk, c.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         std::vector<double> per_step, share;
@@ -325,9 +350,14 @@ static void run(long n, int reps, int C) {
         }
         std::sort(per_step.begin(), per_step.end()); std::sort(share.begin(), share.end());
         const size_t m = per_step.size();
-        printf("  stamps (%zu waves): shader-clock cycles per rotation step of one wave, inside the loop: min %.1f  median %.1f  max %.1f"
-               "  (two waves share a SIMD: ideal 2 x 696 = 1392);\n  share of a wave's life inside the rotation loops: min %.4f  median %.4f  max %.4f\n",
-               m, per_step[0], per_step[m / 2], per_step[m - 1], share[0], share[m / 2], share[m - 1]);
+        auto q = [&](const std::vector<double>& v, double f) { return v[(size_t)(f * (v.size() - 1))]; };
+        hipFuncAttributes fa;
+        CK(hipFuncGetAttributes(&fa, (const void*)sym_force<P, WGS, V>));
+        printf("  stamps (%zu waves, %d VGPRs): shader-clock cycles per rotation step of one wave, inside the loop: min %.1f  p10 %.1f  p25 %.1f"
+               "  median %.1f  p75 %.1f  p90 %.1f  max %.1f  (waves sharing a SIMD x 696 at best);\n"
+               "  share of a wave's life inside the rotation loops: min %.4f  median %.4f  max %.4f\n",
+               m, fa.numRegs, per_step[0], q(per_step, .1), q(per_step, .25), per_step[m / 2], q(per_step, .75), q(per_step, .9), per_step[m - 1],
+               share[0], share[m / 2], share[m - 1]);
         CK(hipFree(clk));
     }
     // check 16 rows against fp64 on the host
@@ -367,6 +397,9 @@ int main(int argc, char** argv) {
     else if (P == 4 && wgs == 512 && V == 6) run<4, 512, 6>(n, reps, C);
     else if (P == 4 && wgs == 512 && V == 4) run<4, 512, 4>(n, reps, C);
     else if (P == 4 && wgs == 512 && V == 8) run<4, 512, 8>(n, reps, C);
+    else if (P == 4 && wgs == 512 && V == 9) run<4, 512, 9>(n, reps, C);
+    else if (P == 4 && wgs == 512 && V == 10) run<4, 512, 10>(n, reps, C);
+    else if (P == 4 && wgs == 512 && V == 11) run<4, 512, 11>(n, reps, C);
     else if (P == 4 && wgs == 256 && V == 0) run<4, 256, 0>(n, reps, C);
     else if (P == 2 && wgs == 512 && V == 0) run<2, 512, 0>(n, reps, C);
     else if (P == 2 && wgs == 1024 && V == 0) run<2, 1024, 0>(n, reps, C);

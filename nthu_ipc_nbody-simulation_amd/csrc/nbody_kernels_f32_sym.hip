@@ -52,6 +52,9 @@ __device__ __forceinline__ v2f rot(v2f v) { return (v2f){rot1(v.x), rot1(v.y)}; 
 
 }  // namespace
 
+// rotation steps at which a wave steps down from priority 3 to 2, 1, 0 (a two-wave model of the arbiter puts the optimum near
+// 30 / 50 / 61: long first stretch, short last one, so that the wave that finishes first leaves the other only a few steps)
+constexpr int SYM_PRIO_STEP_1 = 30, SYM_PRIO_STEP_2 = 50, SYM_PRIO_STEP_3 = 61;
 constexpr int P = SYM_P, WGS = SYM_WGS, NW = WGS / 64, R = 2 * P, SB = SYM_SB, NT = SYM_NT;
 static_assert(NT == NW * P && (NT & (NT - 1)) == 0, "tiles per superblock");
 
@@ -107,8 +110,22 @@ __global__ __launch_bounds__(WGS, 1) void nbody_force_sym_f32(F32Args a, F32SymS
         constexpr bool SYM = decltype(sym)::value;
         v2f xj = (v2f){j0.x, j1.x}, yj = (v2f){j0.y, j1.y}, zj = (v2f){j0.z, j1.z}, gj = (v2f){j0.w, j1.w};
         ajx = ajy = ajz = splat(0.f);
+        // The SIMD's arbiter serves its waves strictly oldest first: of the two waves that share a SIMD the older one would
+        // run its 64 steps at the pace of a lone wave (850 cycles per step, it cannot issue back to back) with the younger
+        // one filling its gaps — and the younger one would then finish alone, nobody filling ITS gaps, while the older one
+        // waits at the phase barrier: 756 cycles per step and SIMD, measured, instead of the 696 the instructions need
+        // (bench/ubench/sym_force variants 8 and 11, profiles/r04_sym_loop_stamps.txt).  Lowering the own priority as the
+        // pass advances hands the SIMD to whichever wave is behind: they leapfrog and finish within a few steps of each other.
+        int s = 0;
 #pragma unroll 1
-        for (int s = 0; s < 64; ++s) {
+        for (int seg = 0; seg < 4; ++seg) {
+        int s_end = 64;
+        if (seg == 0) { __builtin_amdgcn_s_setprio(3); s_end = SYM_PRIO_STEP_1; }
+        else if (seg == 1) { __builtin_amdgcn_s_setprio(2); s_end = SYM_PRIO_STEP_2; }
+        else if (seg == 2) { __builtin_amdgcn_s_setprio(1); s_end = SYM_PRIO_STEP_3; }
+        else __builtin_amdgcn_s_setprio(0);
+#pragma unroll 1
+        for (; s < s_end; ++s) {
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 // g = 0: (iA, j0), (iB, j1)        g = 1: (iA, j1), (iB, j0)
@@ -137,6 +154,7 @@ __global__ __launch_bounds__(WGS, 1) void nbody_force_sym_f32(F32Args a, F32SymS
             }
             xj = rot(xj); yj = rot(yj); zj = rot(zj); gj = rot(gj);
             if (SYM) { ajx = rot(ajx); ajy = rot(ajy); ajz = rot(ajz); }
+        }
         }
     };
     using Yes = std::true_type;

@@ -70,8 +70,18 @@ __global__ __launch_bounds__(WGS, 1) void nbody_force_sym_f64(F64LargeArgs a, F3
     auto tile_pass = [&](double xj, double yj, double zj, double gj, auto sym, double& ajx, double& ajy, double& ajz) {
         constexpr bool SYM = decltype(sym)::value;
         ajx = ajy = ajz = 0.0;
+        // waves that share a SIMD are served strictly oldest first; stepping the own priority down as the pass advances lets
+        // the wave that is behind catch up instead of finishing alone (see the fp32 kernel, nbody_kernels_f32_sym.hip)
+        int s = 0;
 #pragma unroll 1
-        for (int s = 0; s < 64; ++s) {
+        for (int seg = 0; seg < 4; ++seg) {
+        int s_end = 64;
+        if (seg == 0) { __builtin_amdgcn_s_setprio(3); s_end = 30; }
+        else if (seg == 1) { __builtin_amdgcn_s_setprio(2); s_end = 50; }
+        else if (seg == 2) { __builtin_amdgcn_s_setprio(1); s_end = 61; }
+        else __builtin_amdgcn_s_setprio(0);
+#pragma unroll 1
+        for (; s < s_end; ++s) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const double dx = xj - xi[r], dy = yj - yi[r], dz = zj - zi[r];
@@ -87,6 +97,7 @@ __global__ __launch_bounds__(WGS, 1) void nbody_force_sym_f64(F64LargeArgs a, F3
             }
             xj = rot(xj); yj = rot(yj); zj = rot(zj); gj = rot(gj);
             if (SYM) { ajx = rot(ajx); ajy = rot(ajy); ajz = rot(ajz); }
+        }
         }
     };
     using Yes = std::true_type;
