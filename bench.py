@@ -197,7 +197,8 @@ def live_pmc(argv_tail, kernels=("nbody_force_f32", "nbody_reduce_update_f32"), 
                           "fetch_kib_raw": f[k]["FETCH_SIZE"], "write_kib": w[k]["WRITE_SIZE"]}
         res = {"hbm_bytes_per_step": sum(v["hbm_bytes"] for v in per.values()),
                "force": per.get(force), "reducer": per.get(red),
-               "valu_busy": q[force]["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * q[force]["GRBM_GUI_ACTIVE"] / 8)}
+               "valu_busy": q[force]["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * q[force]["GRBM_GUI_ACTIVE"] / 8),
+               "shader_cycles_per_launch": q[force]["GRBM_GUI_ACTIVE"] / 8}
     except Exception as e:  # noqa: BLE001  (tool crash, timeout, missing counter: fall back to the committed profile)
         res = {"error": f"{type(e).__name__}: {e}"}
     shutil.rmtree(out, ignore_errors=True)
@@ -404,6 +405,10 @@ def roofline_block(achieved, kname, k_ms, tpl, jsp, wgs, acc64, traffic=None, tr
             "traffic_source": traffic_source,
             "live_pmc": live,
             "valu_busy": valu_busy,
+            # the clock the chip held in the force kernel (cycles of the PMC pass / the timed region's kernel time): the
+            # peak is priced at the nominal 2.4 GHz, the socket's power cap decides what is held (DESIGN.md, K1s ceiling)
+            "clock_ghz_held": (live["shader_cycles_per_launch"] / (k_ms * 1e-3) / 1e9
+                               if live and live.get("shader_cycles_per_launch") else None),
             "kernel": kname, "kernel_ms": k_ms,
             "kernel_ms_spans": [kname] + ([reducer] if (jsp > 1 or sym) else []),
             "pair_evaluation": "each unordered pair once, both bodies served" if sym else "every ordered pair",

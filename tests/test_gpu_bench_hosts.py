@@ -118,7 +118,7 @@ def test_single_gpu_line_reports_the_lds_kernel_and_step_traffic(nb):
         assert live["force"]["hbm_bytes"] > 0 and live["reducer"]["hbm_bytes"] > 0
         assert r["roofline"]["traffic"] == pytest.approx(live["force"]["hbm_bytes"] + live["reducer"]["hbm_bytes"])
         assert r["roofline"]["traffic_detail"]["algorithmic"] == 56 * 262144
-        assert 0.5 < r["roofline"]["valu_busy"] <= 1.0
+        assert 0.5 < r["roofline"]["valu_busy"] <= 1.0 and 1.5 < r["roofline"]["clock_ghz_held"] < 2.6
 
 
 # ---------------------------------------------------------------- two distinct GPUs (skipped on the one-GPU box)
