@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_PAIR = 20            # GPU Gems 3 ch.31 convention
 PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz
+NOMINAL_CLOCK_HZ = 2.4e9       # the clock PEAK_FP32_TFLOPS is priced at
 ISSUE_CEILING_FRAC = 0.62     # K1 (every ordered pair): what the pair loop's instruction mix can issue
 ISSUE_CEILING_FRAC_SYM = 0.92   # K1s (every unordered pair once): 16 packed VALU + 2 v_rsq_f32 per 4 interactions + 14 DPP moves / 32
 
@@ -409,6 +410,8 @@ def roofline_block(achieved, kname, k_ms, tpl, jsp, wgs, acc64, traffic=None, tr
             # peak is priced at the nominal 2.4 GHz, the socket's power cap decides what is held (DESIGN.md, K1s ceiling)
             "clock_ghz_held": (live["shader_cycles_per_launch"] / (k_ms * 1e-3) / 1e9
                                if live and live.get("shader_cycles_per_launch") else None),
+            "frac_at_clock_held": (achieved / PEAK_FP32_TFLOPS / (live["shader_cycles_per_launch"] / (k_ms * 1e-3) / NOMINAL_CLOCK_HZ)
+                                   if live and live.get("shader_cycles_per_launch") else None),
             "kernel": kname, "kernel_ms": k_ms,
             "kernel_ms_spans": [kname] + ([reducer] if (jsp > 1 or sym) else []),
             "pair_evaluation": "each unordered pair once, both bodies served" if sym else "every ordered pair",
