@@ -43,6 +43,10 @@ __device__ __forceinline__ v2f rot(v2f v) { return (v2f){rot1(v.x), rot1(v.y)}; 
 __device__ __forceinline__ float rowrot1(float x) {  // within 16-lane rows only (timing experiment V = 3: WRONG results)
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x121, 0xf, 0xf, true));
 }
+__device__ __forceinline__ float bperm1(int addr, float x) {  // value of the lane whose number x 4 is `addr`: the LDS crossbar, not the VALU
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, x)));
+}
+__device__ __forceinline__ v2f bperm(int addr, v2f v) { return (v2f){bperm1(addr, v.x), bperm1(addr, v.y)}; }
 __device__ __forceinline__ v2f rowrot(v2f v) { return (v2f){rowrot1(v.x), rowrot1(v.y)}; }
 
 struct SymArgs {
@@ -129,9 +133,9 @@ __global__ __launch_bounds__(WGS, V == 2 ? 4 : 1) void sym_force(SymArgs a) {
 #endif
         int s = 0;
 #pragma unroll 1
-        for (int seg = 0; seg < (V == 11 ? 4 : 1); ++seg) {
+        for (int seg = 0; seg < ((V == 11 || V == 12) ? 4 : 1); ++seg) {
         int s_end = 64;
-        if (V == 11) {
+        if (V == 11 || V == 12) {
             if (seg == 0) { __builtin_amdgcn_s_setprio(3); s_end = SYM_PRIO_B0; }
             else if (seg == 1) { __builtin_amdgcn_s_setprio(2); s_end = SYM_PRIO_B1; }
             else if (seg == 2) { __builtin_amdgcn_s_setprio(1); s_end = SYM_PRIO_B2; }
@@ -139,6 +143,12 @@ __global__ __launch_bounds__(WGS, V == 2 ? 4 : 1) void sym_force(SymArgs a) {
         }
 #pragma unroll SYM_ROT_UNROLL
         for (; s < s_end; ++s) {
+            v2f nxj = xj, nyj = yj, nzj = zj, ngj = gj;
+            if (V == 12) {  // V = 12: the travelling POSITIONS of the next step come through ds_bpermute_b32, requested now (a whole
+                            // step of latency to hide), 8 LDS-pipe instructions instead of 8 of the 14 VALU-pipe DPP moves
+                const int from = ((lane - 1) & 63) * 4;
+                nxj = bperm(from, xj); nyj = bperm(from, yj); nzj = bperm(from, zj); ngj = bperm(from, gj);
+            }
             float4 m0 = n0, m1 = n1;
             if (V == 1) { m0 = jt[w][(lane - s - 2) & 63]; m1 = jt[w][64 + ((lane - s - 2) & 63)]; }  // for step s + 2
             if (V == 5) {
@@ -202,6 +212,8 @@ __global__ __launch_bounds__(WGS, V == 2 ? 4 : 1) void sym_force(SymArgs a) {
             } else if (V == 3) {
                 xj = rowrot(xj); yj = rowrot(yj); zj = rowrot(zj); gj = rowrot(gj);
             } else if (V == 4) {  // no rotation at all (timing experiment: WRONG results)
+            } else if (V == 12) {
+                xj = nxj; yj = nyj; zj = nzj; gj = ngj;
             } else {
                 xj = rot(xj); yj = rot(yj); zj = rot(zj); gj = rot(gj);
             }
@@ -400,6 +412,7 @@ int main(int argc, char** argv) {
     else if (P == 4 && wgs == 512 && V == 9) run<4, 512, 9>(n, reps, C);
     else if (P == 4 && wgs == 512 && V == 10) run<4, 512, 10>(n, reps, C);
     else if (P == 4 && wgs == 512 && V == 11) run<4, 512, 11>(n, reps, C);
+    else if (P == 4 && wgs == 512 && V == 12) run<4, 512, 12>(n, reps, C);
     else if (P == 4 && wgs == 256 && V == 0) run<4, 256, 0>(n, reps, C);
     else if (P == 2 && wgs == 512 && V == 0) run<2, 512, 0>(n, reps, C);
     else if (P == 2 && wgs == 1024 && V == 0) run<2, 1024, 0>(n, reps, C);
