@@ -119,6 +119,7 @@ def test_single_gpu_line_reports_the_lds_kernel_and_step_traffic(nb):
         assert r["roofline"]["traffic"] == pytest.approx(live["force"]["hbm_bytes"] + live["reducer"]["hbm_bytes"])
         assert r["roofline"]["traffic_detail"]["algorithmic"] == 56 * 262144
         assert 0.5 < r["roofline"]["valu_busy"] <= 1.0 and 1.5 < r["roofline"]["clock_ghz_held"] < 2.6
+        assert r["roofline"]["frac"] < r["roofline"]["frac_at_clock_held"] < 1.0  # the chip holds less than the nominal 2.4 GHz
 
 
 # ---------------------------------------------------------------- two distinct GPUs (skipped on the one-GPU box)
