@@ -55,11 +55,20 @@ __device__ __forceinline__ v2f rot(v2f v) { return (v2f){rot1(v.x), rot1(v.y)}; 
 // rotation steps at which a wave steps down from priority 3 to 2, 1, 0 (a two-wave model of the arbiter puts the optimum near
 // 30 / 50 / 61: long first stretch, short last one, so that the wave that finishes first leaves the other only a few steps)
 constexpr int SYM_PRIO_STEP_1 = 30, SYM_PRIO_STEP_2 = 50, SYM_PRIO_STEP_3 = 61;
+// Second summation level of NB_F32 (the sums over more than one 128-source tile): fp64 registers since round 5 — state, slots
+// and outputs stay fp32.  Rounds 1-4 carried Kahan-compensated fp32 pairs there; the same registers as doubles are the
+// NB_F32_ACC64 kernel's loop, which measured FASTER than the Kahan one on one box, alternating (168.3 against 169.9 ms per step
+// at N = 2^20, profiles/r04b_priority_ab.txt; the round-5 A/B of exactly this switch: profiles/r05_sums64_ab.txt), and a
+// fp64 sum of fp32 terms is exact where Kahan is only nearly so.  -DNB_SYM_F32_KAHAN=1 builds the old form for that A/B.
+#ifndef NB_SYM_F32_KAHAN
+#define NB_SYM_F32_KAHAN 0
+#endif
 constexpr int P = SYM_P, WGS = SYM_WGS, NW = WGS / 64, R = 2 * P, SB = SYM_SB, NT = SYM_NT;
 static_assert(NT == NW * P && (NT & (NT - 1)) == 0, "tiles per superblock");
 
 template <bool ACC64>
 __global__ __launch_bounds__(WGS, 1) void nbody_force_sym_f32(F32Args a, F32SymShape sh) {
+    constexpr bool SUMS64 = ACC64 || !NB_SYM_F32_KAHAN;  // second-level sums in fp64 registers
     __shared__ float lds[3][SB];  // image of the J-superblock's accelerations (this workgroup's share of them)
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int B = sh.B;
@@ -74,9 +83,9 @@ __global__ __launch_bounds__(WGS, 1) void nbody_force_sym_f32(F32Args a, F32SymS
 
     v2f xi[P], yi[P], zi[P], gi[P];
     v2f ax[P], ay[P], az[P];      // sums over the tile in hand
-    v2f sx[P], sy[P], sz[P];      // NB_F32: running sums ...
+    v2f sx[P], sy[P], sz[P];      // -DNB_SYM_F32_KAHAN: running sums ...
     v2f cx[P], cy[P], cz[P];      // ... and their Kahan compensation
-    double dax[R], day[R], daz[R];  // NB_F32_ACC64: running sums in fp64
+    double dax[R], day[R], daz[R];  // running sums in fp64
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         const float4 b0 = body(ibase + (long)(2 * p) * WGS + t), b1 = body(ibase + (long)(2 * p + 1) * WGS + t);
@@ -90,7 +99,7 @@ __global__ __launch_bounds__(WGS, 1) void nbody_force_sym_f32(F32Args a, F32SymS
     auto flush = [&]() {  // second summation level, as in K1
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            if (ACC64) {
+            if (SUMS64) {
                 dax[2 * p] += (double)ax[p].x; dax[2 * p + 1] += (double)ax[p].y;
                 day[2 * p] += (double)ay[p].x; day[2 * p + 1] += (double)ay[p].y;
                 daz[2 * p] += (double)az[p].x; daz[2 * p + 1] += (double)az[p].y;
@@ -217,7 +226,8 @@ __global__ __launch_bounds__(WGS, 1) void nbody_force_sym_f32(F32Args a, F32SymS
         }
         __syncthreads();
     }
-    // own sums -> slot `chunk` (fp64 sums: two slots, the value split into a float and the float of the remainder)
+    // own sums -> slot `chunk` (NB_F32_ACC64: two slots, the value split into a float and the float of the remainder;
+    // NB_F32: the fp64 sum rounded once to the fp32 the slots carry)
     float* own = (float*)a.partial + ibase;
     const long plane = sh.npad;
 #pragma unroll
@@ -232,7 +242,8 @@ __global__ __launch_bounds__(WGS, 1) void nbody_force_sym_f32(F32Args a, F32SymS
             lo[0] = (float)(dax[r] - (double)hx); lo[plane] = (float)(day[r] - (double)hy); lo[2 * plane] = (float)(daz[r] - (double)hz);
         } else {
             float* o = own + (long)chunk * 3 * plane + i;
-            o[0] = sx[p][h]; o[plane] = sy[p][h]; o[2 * plane] = sz[p][h];
+            if (SUMS64) { o[0] = (float)dax[r]; o[plane] = (float)day[r]; o[2 * plane] = (float)daz[r]; }
+            else { o[0] = sx[p][h]; o[plane] = sy[p][h]; o[2 * plane] = sz[p][h]; }
         }
     }
 }
@@ -248,22 +259,24 @@ __global__ __launch_bounds__(WG) void nbody_reduce_sym_f32(F32Args a, F32SymShap
     const int J = (int)(i / SB);
     const float* ws = (const float*)a.partial + i;  // slot s, component c of this body: ws[(3 s + c) * npad]
     const long plane = sh.npad;
-    double dx = 0, dy = 0, dz = 0;                          // ACC64
-    float rx = 0, ry = 0, rz = 0, kx = 0, ky = 0, kz = 0;   // F32: Kahan
+    constexpr bool SUMS64 = ACC64 || !NB_SYM_F32_KAHAN;    // the slots of a body are added in fp64 (NB_F32: rounded once at the end)
+    double dx = 0, dy = 0, dz = 0;
+    float rx = 0, ry = 0, rz = 0, kx = 0, ky = 0, kz = 0;   // -DNB_SYM_F32_KAHAN: compensated fp32
     if (carry) {
         if (ACC64) { const double4 c = ((const double4*)carry)[i]; dx = c.x; dy = c.y; dz = c.z; }
-        else { const float4 c = ((const float4*)carry)[i]; rx = c.x; ry = c.y; rz = c.z; }
+        else { const float4 c = ((const float4*)carry)[i]; rx = c.x; ry = c.y; rz = c.z; dx = c.x; dy = c.y; dz = c.z; }
     }
     auto add = [&](long slot) {
         const float* p = ws + slot * 3 * plane;
         const float x = p[0], y = p[plane], z = p[2 * plane];
-        if (ACC64) { dx += (double)x; dy += (double)y; dz += (double)z; return; }
+        if (SUMS64) { dx += (double)x; dy += (double)y; dz += (double)z; return; }
         float u, v;
         u = x - kx; v = rx + u; kx = (v - rx) - u; rx = v;
         u = y - ky; v = ry + u; ky = (v - ry) - u; ry = v;
         u = z - kz; v = rz + u; kz = (v - rz) - u; rz = v;
     };
     sym_for_each_slot_of(sh, ACC64, J, add);
+    if (SUMS64 && !ACC64) { rx = (float)dx; ry = (float)dy; rz = (float)dz; }
     if (MODE == 2) {
         if (ACC64) ((double4*)a.acc)[i] = make_double4(dx, dy, dz, 0.0);
         else ((float4*)a.acc)[i] = make_float4(rx, ry, rz, 0.f);
@@ -290,7 +303,8 @@ __global__ __launch_bounds__(WG) void nbody_kick_drift_f32(F32Args a, int parts)
         }
         finish_target<true, false>(a, i, x, y, z, me.x, me.y, me.z, me.w);
     } else {
-        float rx = 0, ry = 0, rz = 0, kx = 0, ky = 0, kz = 0;  // Kahan, like every other second-level sum of the fp32 mode
+#if NB_SYM_F32_KAHAN
+        float rx = 0, ry = 0, rz = 0, kx = 0, ky = 0, kz = 0;
         for (int q = 0; q < parts; ++q) {
             const float4 f = ((const float4*)a.acc)[(long)q * a.n_tgt + i];
             float u, v;
@@ -298,6 +312,14 @@ __global__ __launch_bounds__(WG) void nbody_kick_drift_f32(F32Args a, int parts)
             u = f.y - ky; v = ry + u; ky = (v - ry) - u; ry = v;
             u = f.z - kz; v = rz + u; kz = (v - rz) - u; rz = v;
         }
+#else
+        double x = 0, y = 0, z = 0;  // fp64, like every other second-level sum of the fp32 mode; rounded once
+        for (int q = 0; q < parts; ++q) {
+            const float4 f = ((const float4*)a.acc)[(long)q * a.n_tgt + i];
+            x += (double)f.x; y += (double)f.y; z += (double)f.z;
+        }
+        const float rx = (float)x, ry = (float)y, rz = (float)z;
+#endif
         finish_target<false, false>(a, i, rx, ry, rz, me.x, me.y, me.z, me.w);
     }
 }
