@@ -12,7 +12,7 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-result
 LIB      ?= $(PKG)/libnbody_amd.so
 
 KSRC := $(SRC)/nbody_kernels_f32.hip $(SRC)/nbody_kernels_f32_sym.hip $(SRC)/nbody_kernels_f64.hip $(SRC)/nbody_kernels_f64_sym.hip
-HDR  := $(SRC)/nbody_kernels.h $(SRC)/nbody_f32_common.h include/nbody_amd.h include/nbody_amd_debug.h
+HDR  := $(SRC)/nbody_kernels.h $(SRC)/nbody_f32_common.h include/nbody_amd.h include/nbody_amd_ext.h include/nbody_amd_debug.h
 
 .PHONY: all lib hw5 nbody_bench nbconv oracle ubench asan clean stamps
 all: lib hw5 nbody_bench nbconv stamps

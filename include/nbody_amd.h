@@ -9,6 +9,11 @@
  * host round trip per step.  bin/hw5 (csrc/main_hw5.cpp) is the CLI drop-in built on it; INTEGRATION.md
  * shows the two-line change that makes the reference's own main() call it.
  *
+ * This file is the run_step boundary and nothing else: lifecycle, state, nb_step / nb_accel, the scenario drivers,
+ * nb_solve and the state files.  What a host needs only when it owns device memory, collectives or several GPUs itself
+ * — raw launches, the shared-pairs launches, nb_sharded_*, nb_solve_ex's options, the pair-schedule self-test — lives in
+ * include/nbody_amd_ext.h (since ABI 5; the library exports both).
+ *
  * Conventions
  *  - every function returns int: 0 = NB_OK, <0 = nb_status error; no exception crosses the boundary;
  *  - host arrays are caller-owned SoA `double[n]`, exactly run_step's vectors; the library copies and never
@@ -26,7 +31,7 @@
 extern "C" {
 #endif
 
-#define NB_ABI_VERSION 4
+#define NB_ABI_VERSION 5
 
 typedef enum nb_status {
     NB_OK = 0,
@@ -52,11 +57,20 @@ typedef struct nb_config {
     int32_t device;    /* HIP device ordinal */
     int32_t f64_large_min; /* NB_F64: from this many bodies on, nb_step/nb_accel use the large-n kernel; 0 = default (32768) */
     int32_t f64_split;     /* NB_F64: lanes of a wave that share one target in the step kernel; 0 = auto, else a power of two <= 64 */
-    int32_t reserved;      /* must be 0 (ABI 3 carried a measurement knob here; it lives in nbody_amd_debug.h now) */
+    int32_t flags;         /* nb_config_flags, 0 = defaults (ABI 3 carried a measurement knob here, ABI 4 required 0) */
     double G;   /* 6.674e-11 */
     double eps; /* 1e-3  (Plummer softening; r2 + eps*eps) */
     double dt;  /* 60 */
 } nb_config;
+typedef enum nb_config_flags {
+    NB_CFG_ORDERED_PAIRS = 1 /* fp32 modes: nb_step / nb_accel evaluate every ORDERED pair (kernel K1, 288 B of workspace per
+                                body) even where the default applies.  Default from 49152 bodies on: every UNORDERED pair once
+                                (kernel K1s, 1.35x faster), which needs a pair-slot workspace that grows with n^2 — 12 B x
+                                (n/8192 + 8) per body: 1.7 GB at n = 2^20, 26 GB at 2^22, 52 GB from 2^23 on.  That workspace
+                                is allocated by the FIRST nb_step / nb_accel, not by nb_create; if the device cannot give it
+                                (hipMalloc fails, or it would take more than 3/4 of the free memory) the context falls back to
+                                K1 for its lifetime and nb_last_error(ctx) says so once — it is not an error */
+} nb_config_flags;
 
 /* scenario drivers — the loops main() runs around run_step */
 typedef enum nb_scenario_kind {
@@ -110,7 +124,7 @@ int nb_create(nb_context** out, const nb_config* cfg);
 int nb_destroy(nb_context* ctx);
 const char* nb_strerror(int code);
 /* text of the last failure on this context; ctx == NULL: of the last failed context-free call made by the calling
- * thread (raw launches, state files, nb_solve, nb_sharded_create) */
+ * thread (state files, nb_solve; nbody_amd_ext.h: raw launches, nb_sharded_create) */
 const char* nb_last_error(const nb_context* ctx);
 
 /* ---- state: the seven vectors of run_step + the `type[j]=="device"` predicate (nbody.cc:62) ---- */
@@ -182,7 +196,7 @@ int nb_write_state_file(const char* path, const nb_state_header* hdr, const doub
  * n > 128: the per-step engine instead — P1, P2 and the Problem-3 runs each replay their own graph of launches on their
  * own stream (one shared graph per GPU up to 256 bodies); a Problem-3 run starts from the snapshot P2 takes at its
  * missile's arrival (hw5.cu:265-287,482-489) as soon as P2's monitor shows it, one per GPU at a time in arrival order.
- * Tuning and test hooks travel in nb_solve_options (nb_solve_ex); the library reads ONE environment variable,
+ * Tuning and test hooks travel in nb_solve_options (nb_solve_ex, nbody_amd_ext.h); the library reads ONE environment variable,
  * NB_SOLVE_TRACE=1: a timeline of the driver's phases on stderr, no change of behaviour.  bin/hw5 maps its NB_SOLVE_* /
  * NB_GRAPH_CHUNK environment onto the options (csrc/main_hw5.cpp). */
 typedef struct nb_answer {
@@ -194,179 +208,6 @@ typedef struct nb_answer {
 int nb_solve(int n, int planet, int asteroid, const double* qx, const double* qy, const double* qz,
              const double* vx, const double* vy, const double* vz, const double* m, const uint8_t* is_device,
              const int* devices /* HIP ordinals to spread scenarios over */, int n_devices, nb_answer* out);
-typedef struct nb_solve_options { /* zero-initialise; every 0 = the default nb_solve uses */
-    int32_t max_batch;   /* persistent engine: scenarios per launch, 2..8 (default 8); fewer queues the other devices */
-    int32_t engine;      /* 0 = by system size; 1 = per-step engine (graph replay); 2 = persistent engine (n <= 128) */
-    int32_t streams;     /* per-step engine: 0 = by system size; 1 = one shared graph per GPU; 2 = a stream per scenario */
-    int32_t p3_parallel; /* per-step engine: Problem-3 runs at a time; 0 = one per listed GPU (hw5.cu:587-588) */
-    int32_t graph_chunk; /* per-step engine: launches per replayed graph; 0 = 1000, else even, 2..4000 */
-    int32_t handoff;     /* nb_solve_handoff: how P2's arrival snapshot reaches a Problem-3 run (hw5.cu:482-484) */
-    int32_t reserved[2];
-} nb_solve_options;
-typedef enum nb_solve_handoff {
-    NB_HANDOFF_AUTO = 0,       /* device copy on the same GPU ordinal, through host memory between different ones */
-    NB_HANDOFF_HOST_STAGED = 1 /* through host memory whenever the run sits on another entry of `devices` than P2, even if
-                                  both entries name the same GPU: executes the cross-GPU path on a one-GPU box */
-} nb_solve_handoff;
-int nb_solve_ex(int n, int planet, int asteroid, const double* qx, const double* qy, const double* qz,
-                const double* vx, const double* vy, const double* vz, const double* m, const uint8_t* is_device,
-                const int* devices, int n_devices, const nb_solve_options* options /* NULL = defaults */, nb_answer* out);
-
-/* ---- raw launches on caller-owned HBM (device pointers + a hipStream_t as void*) ----
- * For hosts that own device memory and the exchange step themselves (one process per GPU with
- * torch.distributed/RCCL: bench.py, nbody_amd.distributed).  fp32 body record = float4 {x, y, z, G*m}.
- *
- *   src      float4[n_src]   all source bodies (the gathered array every rank holds)
- *   tgt_off  first target index in src; targets are src[tgt_off .. tgt_off+n_tgt)   (unless `tgt` is given)
- *   out      float4[n_src]   the OTHER (ping-pong) gathered array; only [tgt_off, tgt_off+n_tgt) is written
- *   vel      float4[n_tgt]   this rank's velocities, in place ({vx,vy,vz,unused})
- *   F32_ACC64 additionally keeps fp64 masters: pos64/vel64 = double4[n_tgt] ({x,y,z,G*m} / {vx,vy,vz,0})
- */
-typedef struct nb_launch_f32 {
-    const void* src;
-    void* out;
-    void* vel;
-    void* pos64; /* NULL unless acc64 */
-    void* vel64; /* NULL unless acc64 */
-    void* acc;   /* nb_launch_accel_f32 only: float4[n_tgt] {ax,ay,az,0} (acc64: double4[n_tgt]) */
-    void* workspace; /* optional scratch for source slicing (partial + running sums); NULL -> never slice */
-    int64_t workspace_bytes; /* its size; must be >= nb_workspace_bytes_f32() (18 records per target: running sum,
-                                compensation, 16 partial-sum slots) or the sources are not sliced.  A larger one — up to 66
-                                records — gives a launch as many slots, so that a step of up to 64 slices is ONE force launch +
-                                ONE reducer instead of j_split/16 of each (results are bit for bit the same).  The running sum
-                                and its compensation are records 0 and 1 whatever the size, so the FIRST / MIDDLE / LAST
-                                launches of one step may pass different sizes of the same buffer */
-    int64_t n_src;
-    int64_t tgt_off;
-    int64_t n_tgt;
-    float eps2;
-    float dt;
-    int32_t acc64;            /* 0 = NB_F32, 1 = NB_F32_ACC64 */
-    int32_t targets_per_lane; /* 0 = auto; 2, 4 or 8 (packed pairs of targets per lane) */
-    int32_t j_split;          /* 0 = auto; 1..1024 source slices (~1 MiB each when auto): workgroups sharing a target
-                                 block each take one slice; 16 slices per launch, partial sums folded by a reducer */
-    int32_t source_path;      /* 0 = auto; 1 = sources through the LDS tile; 2 = sources through scalar loads/SGPRs (both: every
-                                 ORDERED pair, kernel K1); 3 = every UNORDERED pair once, Newton's third law (kernel K1s: the
-                                 sources travel through the wave by DPP rotation) — needs the whole system in this one launch
-                                 (n_tgt == n_src, tgt_off 0, phase WHOLE), n_src >= 49152 and a workspace of
-                                 nb_workspace_bytes_sym_f32(); auto picks it whenever that holds and nothing else is forced;
-                                 j_split then = workgroups per 4096-body superblock (0 = auto) */
-    int32_t wg_size;          /* 0 = auto; 256, 512 (targets_per_lane 8) or 1024 (targets_per_lane 4) */
-    int32_t phase;            /* nb_launch_phase: a step may be cut into several launches over disjoint source ranges
-                                 (own shard while the all-gather of the other shards is still in flight);
-                                 the running sums live in `workspace` between them (required unless NB_PHASE_WHOLE) */
-    int64_t src_begin;        /* sources of this launch: src[src_begin .. src_end); 0,0 = all n_src.  src_begin must be */
-    int64_t src_end;          /* a multiple of 256, src_end a multiple of 256 or n_src */
-    const void* tgt;          /* NULL: the targets are src[tgt_off .. tgt_off+n_tgt).  Otherwise float4[n_tgt], the targets'
-                                 own records, for hosts whose sources travel in blocks (ring pass: `src` is the block in
-                                 hand, tgt_off then only places the result in `out`, and may exceed n_src) */
-} nb_launch_f32;
-typedef enum nb_launch_phase {
-    NB_PHASE_WHOLE = 0,  /* the whole step in one call: start the sums, run the epilogue */
-    NB_PHASE_FIRST = 1,  /* start the sums, keep them in the workspace */
-    NB_PHASE_LAST = 2,   /* continue the sums, then the epilogue (accelerations out / kick-drift) */
-    NB_PHASE_MIDDLE = 3  /* continue the sums, keep them */
-} nb_launch_phase;
-int nb_launch_step_f32(const nb_launch_f32* a, void* hip_stream);  /* force + fused kick-drift */
-int nb_launch_accel_f32(const nb_launch_f32* a, void* hip_stream); /* force only -> a->acc */
-/* name of the kernel symbol the two launches above resolve to for these arguments (for matching rocprofv3 rows) */
-const char* nb_kernel_name_f32(const nb_launch_f32* a, int accel_only);
-/* the register blocking, source split and workgroup size the launches above will use for these arguments */
-int nb_plan_f32(const nb_launch_f32* a, int* targets_per_lane, int* j_split, int* wg_size);
-/* workspace size that allows source slicing for n_tgt targets: 18 records per target (2 + 16 slots) */
-int64_t nb_workspace_bytes_f32(int64_t n_tgt, int acc64);
-/* workspace size that lets a whole-system launch of n bodies use K1s (source_path 3): three floats per body and
- * superblock round plus three (six with acc64) per workgroup of a superblock — 12 B x (n/8192 + 8) per body: 1.7 GB at
- * n = 2^20, 26 GB at 2^22; larger systems are stepped in batches of superblocks with a running force behind the slots: 52 GB
- * at 2^23 and 2^24, 107 GB at 2^26; 0 = K1s does not apply to this n (fewer than 49152 bodies, or no batch fits 128 GiB) */
-int64_t nb_workspace_bytes_sym_f32(int64_t n, int acc64);
-
-/* ---- K1s over several GPUs, for hosts that own the collectives themselves (one process per GPU: nbody_amd.distributed).
- * The GPUs share the UNORDERED pairs of the system: rank r = tgt_off / n_tgt of P = n_src / n_tgt takes the 4096-body
- * superblocks of its shard against the half of the system behind each.  Needs whole superblocks per shard
- * (n_src % (P * 4096) == 0) and n_src >= 49152: nb_workspace_bytes_shared_pairs_f32 answers 0 otherwise (use the ordered
- * launches above).  Per step and rank:
- *   nb_launch_pair_forces_f32   a->acc = float4[n_src] (double4 with acc64): this rank's partial force on ALL bodies
- *   reduce-scatter (sum) of a->acc over the ranks -> the force on the rank's own shard
- *   nb_launch_kick_drift_f32    a->acc = that force as float4[parts][n_tgt] (double4 with acc64), the pieces added in order
- *                               (1 after a reduce-scatter; P when the host gathered the ranks' pieces itself); kick + drift
- *                               of [tgt_off, tgt_off + n_tgt) into a->out / a->vel (pos64 / vel64), as nb_launch_step_f32 does
- *   all-gather of the positions, as with the ordered launches */
-int nb_launch_pair_forces_f32(const nb_launch_f32* a, void* hip_stream);
-int nb_launch_kick_drift_f32(const nb_launch_f32* a, int parts, void* hip_stream);
-int64_t nb_workspace_bytes_shared_pairs_f32(int64_t n_src, int ranks, int acc64);
-/* host-only replay of K1s' pair schedule for n bodies on `ranks` GPUs of n_cus compute units (ranks 1 = the one-GPU launch),
- * with the index arithmetic the kernels share: every unordered pair of 4096-body superblocks met exactly once in every tile
- * phase over all ranks and workgroups, no slot region written twice, the reducer's slot list equal to what was written.
- * Needs no GPU — it is how the 8-GPU shapes are checked on machines that have one or none.  NB_OK, or NB_ERR_STATE with the
- * first inconsistency in msg */
-int nb_selftest_pair_schedule(int64_t n, int n_cus, int ranks, int acc64, char* msg, int msg_len);
-
-/* ---- index-sharded multi-GPU stepping: ONE process, P GPUs of a node, RCCL over xGMI (csrc/nbody_sharded.cpp) ----
- * The reference's only multi-GPU use is task parallelism (hw5.cu:564-567,587-588); this is the data-parallel scheme of
- * GPU r owns targets [r*n/P, (r+1)*n/P) (velocities, fp64 masters), every GPU holds all positions twice
- * (ping-pong float4[n] {x,y,z,G*m}).  Per step and GPU, on its own stream:
- *   default (whole 4096-body superblocks per shard, n >= 131072, no overlap): its share of the UNORDERED pairs of the system
- *     (kernel K1s) -> a partial force on all n bodies -> ONE ncclReduceScatter (sum) to the shard owners -> kick-drift;
- *   otherwise / NB_SHARDED_ORDERED_PAIRS: every ordered pair of its own targets with the kick-drift fused (kernel K1);
- *   then ONE in-place ncclAllGather(sendbuff = recvbuff + r*4n/P, ncclFloat) of the positions.
- * RCCL is loaded (dlopen) by the first nb_sharded_create.  The same scheme with one process per GPU: nbody_amd.distributed
- * (torch.distributed).  n must be divisible by n_devices; precision NB_F32 or NB_F32_ACC64; with one device the trajectory
- * equals nb_step's bit for bit. */
-typedef struct nb_sharded nb_sharded;
-#define NB_SHARDED_OVERLAP 1 /* two-phase step: own-shard sources while the all-gather of the other shards is in flight
-                                on a second stream, remote sources after it; n/P must be a multiple of 256 */
-#define NB_SHARDED_COPY_EXCHANGE 2 /* the per-step all-gather as P-1 peer copies per GPU (hipMemcpyPeerAsync on the exchange
-                                stream: SDMA engines over xGMI, no CU taken from the force kernel, RCCL not loaded) instead of
-                                ncclAllGather.  The only exchange that accepts an ordinal more than once in `devices` — ranks
-                                sharing a GPU, each with its own streams and arrays — which is how a one-GPU box executes the
-                                P > 1 host logic (tests/test_gpu_sharded_native.py) */
-#define NB_SHARDED_ORDERED_PAIRS 4 /* every GPU evaluates every ordered pair of its targets (kernel K1) even where the default
-                                applies: when every shard is a whole number of 4096-body superblocks, n >= 49152 and the step is
-                                not overlapped, the GPUs share the UNORDERED pairs of the system instead (kernel K1s: GPU r takes
-                                the superblocks of its shard against the half of the system behind each), which leaves every GPU
-                                with a partial force on all n bodies — one reduce-scatter per step (ncclReduceScatter, or peer
-                                copies + an ordered sum with NB_SHARDED_COPY_EXCHANGE) in front of the kick-drift and the all-gather */
-int nb_sharded_create(nb_sharded** out, const int* devices, int n_devices, int64_t n, int precision, double G,
-                      double eps, double dt, int flags);
-int nb_sharded_destroy(nb_sharded* s);
-const char* nb_sharded_last_error(const nb_sharded* s); /* s == NULL: the calling thread's last failed create */
-/* host arrays of ALL n bodies, as nb_set_state / nb_get_state (no `device` bodies in the fp32 modes) */
-int nb_sharded_set_state(nb_sharded* s, const double* qx, const double* qy, const double* qz, const double* vx,
-                         const double* vy, const double* vz, const double* m);
-int nb_sharded_get_state(nb_sharded* s, double* qx, double* qy, double* qz, double* vx, double* vy, double* vz);
-int nb_sharded_step(nb_sharded* s, int count); /* `count` run_steps of the whole system; returns with all GPUs idle */
-/* as nb_sharded_step, and reports the host wall time per step in milliseconds (all GPUs idle on both sides) */
-int nb_sharded_step_timed(nb_sharded* s, int count, double* ms_per_step);
-/* as nb_sharded_step_timed, and additionally reports — per rank — the mean GPU time of one step's launch sequence
- * (force kernels + reducers), from HIP events recorded on that rank's own compute stream around the launches of every step,
- * the exchange excluded (with NB_SHARDED_OVERLAP the span contains the wait for the gathered remote shards between the
- * own-shard phase and the remote phases).  kernel_ms: float[n_devices].  count <= 1024 (two events per step and rank). */
-int nb_sharded_step_profiled(nb_sharded* s, int count, double* wall_ms_per_step, float* kernel_ms);
-/* shard size and the launch plan each GPU uses for a whole step (any pointer may be NULL) */
-int nb_sharded_info(const nb_sharded* s, int* n_devices, int64_t* targets_per_device, int* targets_per_lane,
-                    int* j_split, int* wg_size);
-/* symbol name of the force kernel a rank's step launches (for matching rocprofv3 rows, like nb_kernel_name_f32) */
-const char* nb_sharded_kernel_name(const nb_sharded* s);
-/* who rank `rank` is: which GPU it drives (ordinal, PCI bus id, UUID, name), which targets it owns, and what its exchange
- * is — for RCCL straight from the rank's communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice), so that
- * "the collective ran over N ranks on N distinct GPUs" is a fact read back from RCCL, not an echo of the arguments */
-typedef enum nb_sharded_exchange { NB_EXCHANGE_RCCL = 1, NB_EXCHANGE_COPY = 2 } nb_sharded_exchange;
-typedef struct nb_sharded_rank {
-    int32_t device;        /* HIP ordinal */
-    int32_t compute_units;
-    int64_t first_target;  /* owns targets [first_target, first_target + targets) */
-    int64_t targets;
-    int32_t exchange;      /* nb_sharded_exchange */
-    int32_t comm_ranks;    /* RCCL: ncclCommCount of this rank's communicator; copy exchange: n_devices */
-    int32_t comm_rank;     /* RCCL: ncclCommUserRank; copy exchange: rank */
-    int32_t comm_device;   /* RCCL: ncclCommCuDevice; copy exchange: device */
-    char pci_bus_id[16];   /* "0000:05:00.0" */
-    char uuid[36];         /* hipDeviceGetUuid, 32 hex digits */
-    char name[64];
-} nb_sharded_rank;
-int nb_sharded_rank_info(const nb_sharded* s, int rank, nb_sharded_rank* out);
-
 #ifdef __cplusplus
 }
 #endif

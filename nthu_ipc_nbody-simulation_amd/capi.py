@@ -1,4 +1,4 @@
-"""ctypes binding of libnbody_amd.so (include/nbody_amd.h).  No compute happens in Python and there is no
+"""ctypes binding of libnbody_amd.so (include/nbody_amd.h + include/nbody_amd_ext.h).  No compute happens in Python and there is no
 fallback: a missing library raises at import of the symbol table, a missing GPU raises NBodyError(NB_ERR_NO_DEVICE)."""
 import ctypes as C
 import os
@@ -17,7 +17,7 @@ _u8p = C.POINTER(C.c_uint8)
 
 class NbConfig(C.Structure):
     _fields_ = [("n", C.c_int32), ("precision", C.c_int32), ("device", C.c_int32), ("f64_large_min", C.c_int32),
-                ("f64_split", C.c_int32), ("reserved", C.c_int32), ("G", C.c_double), ("eps", C.c_double),
+                ("f64_split", C.c_int32), ("flags", C.c_int32), ("G", C.c_double), ("eps", C.c_double),
                 ("dt", C.c_double)]
 
 
@@ -64,7 +64,8 @@ class NbLaunchF32(C.Structure):
                 ("tgt", C.c_void_p)]
 
 
-# every symbol include/nbody_amd.h declares: (restype, argtypes)
+# every symbol include/nbody_amd.h (the run_step boundary) and include/nbody_amd_ext.h (raw launches, shared pairs, nb_sharded_*,
+# nb_solve_ex) declare: (restype, argtypes)
 SYMBOLS = {
     "nb_abi_version": (C.c_int, []),
     "nb_device_count": (C.c_int, [C.POINTER(C.c_int)]),
@@ -102,10 +103,13 @@ SYMBOLS = {
     "nb_launch_pair_forces_f32": (C.c_int, [C.POINTER(NbLaunchF32), C.c_void_p]),
     "nb_launch_kick_drift_f32": (C.c_int, [C.POINTER(NbLaunchF32), C.c_int, C.c_void_p]),
     "nb_workspace_bytes_shared_pairs_f32": (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
+    "nb_plan_shared_pairs_f32": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "nb_context_kernel_name": (C.c_char_p, [C.c_void_p]),
     "nb_selftest_pair_schedule": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]),
     "nb_sharded_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int64, C.c_int, C.c_double,
                                    C.c_double, C.c_double, C.c_int]),
     "nb_sharded_destroy": (C.c_int, [C.c_void_p]),
+    "nb_sharded_set_deadline": (C.c_int, [C.c_void_p, C.c_double]),
     "nb_sharded_last_error": (C.c_char_p, [C.c_void_p]),
     "nb_sharded_set_state": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
     "nb_sharded_get_state": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _dp, _dp]),
@@ -129,6 +133,7 @@ NB_CU_ALL, NB_CU_LOW, NB_CU_HIGH, NB_CU_EVEN, NB_CU_ODD = 0, 1, 2, 3, 4
 NB_HANDOFF_AUTO, NB_HANDOFF_HOST_STAGED = 0, 1
 NB_SHARDED_COPY_EXCHANGE = 2
 NB_SHARDED_ORDERED_PAIRS = 4
+NB_CFG_ORDERED_PAIRS = 1
 
 
 class NBodyError(RuntimeError):
@@ -253,11 +258,12 @@ class Context:
     """One nb_context: a system of n bodies resident on one GPU."""
 
     def __init__(self, n, precision=NB_F64, device=0, G=None, eps=None, dt=None, f64_large_min=0, f64_split=0,
-                 cu_mask=NB_CU_ALL):
+                 cu_mask=NB_CU_ALL, ordered_pairs=False):
         cfg = NbConfig()
         _check(lib().nb_config_default(C.byref(cfg)), "nb_config_default")
         cfg.n, cfg.precision, cfg.device = n, precision, device
         cfg.f64_large_min, cfg.f64_split = f64_large_min, f64_split
+        cfg.flags = NB_CFG_ORDERED_PAIRS if ordered_pairs else 0
         if G is not None:
             cfg.G = G
         if eps is not None:
@@ -325,6 +331,14 @@ class Context:
         a = np.empty((3, self.n))
         _check(lib().nb_accel(self._h, step, *[a[k].ctypes.data_as(_dp) for k in range(3)]), "nb_accel", self._h)
         return a
+
+    def kernel_name(self):
+        """Force kernel nb_step / nb_accel of this fp32 context launch (asks for K1s' workspace like the first step would)."""
+        return lib().nb_context_kernel_name(self._h).decode()
+
+    def last_error(self):
+        """Text of the context's last failure — or note: a context that had to fall back from K1s to K1 says so here."""
+        return lib().nb_last_error(self._h).decode()
 
     def enable_step_stamps(self, slots):
         _check(_debug_symbol("nb_enable_step_stamps")(self._h, slots), "nb_enable_step_stamps", self._h)
@@ -452,7 +466,7 @@ class Sharded:
     engines — the form that lets several ranks share one GPU)."""
 
     def __init__(self, n, devices=(0,), precision=NB_F32, G=6.674e-11, eps=1e-3, dt=60.0, overlap=False,
-                 exchange="rccl", ordered_pairs=False):
+                 exchange="rccl", ordered_pairs=False, deadline=0.0):
         if exchange not in ("rccl", "copy"):
             raise ValueError("exchange must be 'rccl' or 'copy'")
         self.n = n
@@ -468,6 +482,14 @@ class Sharded:
             if h:
                 lib().nb_sharded_destroy(h)
             raise NBodyError(rc, "nb_sharded_create", detail)
+        self.note = lib().nb_sharded_last_error(self._h).decode()  # "" or why the unordered-pair step was not taken
+        if deadline:
+            self.set_deadline(deadline)
+
+    def set_deadline(self, seconds):
+        """Bound every wait: a step that has not finished `seconds` after the host started waiting for it fails the call with
+        NBodyError(NB_ERR_HIP, "... timed out ...") instead of blocking; 0 = wait as long as it takes."""
+        self._check(lib().nb_sharded_set_deadline(self._h, float(seconds)), "nb_sharded_set_deadline")
 
     def _check(self, rc, where):
         if rc != NB_OK:
@@ -570,6 +592,15 @@ def launch_kick_drift_f32(src_ptr, out_ptr, n_src, tgt_off, n_tgt, dt, stream, a
 def workspace_bytes_shared_pairs_f32(n_src, ranks, acc64=False):
     """Workspace of nb_launch_pair_forces_f32; 0 = the ranks cannot share the unordered pairs of this system."""
     return lib().nb_workspace_bytes_shared_pairs_f32(n_src, ranks, int(acc64))
+
+
+def plan_shared_pairs_f32(n_src, ranks, acc64=False):
+    """-> (superblocks per rank, workgroups per superblock, sub-launches per rank) of launch_pair_forces_f32 on the current
+    device — what the kernel will do, from the library (not re-derived here)."""
+    nb, wg, sub = C.c_int(), C.c_int(), C.c_int()
+    _check(lib().nb_plan_shared_pairs_f32(n_src, ranks, int(acc64), C.byref(nb), C.byref(wg), C.byref(sub)),
+           "nb_plan_shared_pairs_f32")
+    return nb.value, wg.value, sub.value
 
 
 def selftest_pair_schedule(n, n_cus=256, ranks=1, acc64=False):

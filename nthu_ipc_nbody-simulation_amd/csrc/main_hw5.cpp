@@ -16,7 +16,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/nbody_amd.h"
+#include "../../include/nbody_amd_ext.h"  // nb_solve_ex and its options (includes nbody_amd.h)
 #include "nbody_io.h"
 
 int main(int argc, char** argv) {

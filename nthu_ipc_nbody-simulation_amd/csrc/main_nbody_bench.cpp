@@ -15,7 +15,7 @@
 #include <cstring>
 #include <vector>
 
-#include "../../include/nbody_amd.h"
+#include "../../include/nbody_amd_ext.h"  // nb_sharded_* (includes nbody_amd.h)
 
 static inline uint64_t splitmix64(uint64_t x) {
     x += 0x9E3779B97F4A7C15ull;

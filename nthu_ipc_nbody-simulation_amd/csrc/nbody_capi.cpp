@@ -145,11 +145,44 @@ F32Args f32_args(nb_context* c) {
     return a;
 }
 
-// the context's launch plan: K1s (every unordered pair once) when the system is large enough for it and the workspace
-// was sized for it at creation, else K1
+// K1s' pair-slot workspace, on the first step / accel that would use it (not in nb_create: 26 GB at n = 2^22 is a heavy
+// default for a context that may only hold state, and several contexts may share a GPU).  If the device cannot give it —
+// more than 3/4 of what is free, or hipMalloc fails — the context keeps K1's workspace (288 B per body, allocated at
+// creation) and evaluates every ordered pair for the rest of its life; nb_last_error(ctx) says so, no call fails.
+void ensure_sym_workspace(nb_context* c) {
+    if (!c->sym_bytes || c->sym_tried) return;
+    c->sym_tried = true;
+    const size_t need = std::max(c->partial_bytes, c->sym_bytes);
+    size_t free_b = 0, total_b = 0;
+    const bool known = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+    if (!known) (void)hipGetLastError();
+    void* ws = nullptr;
+    const char* why = nullptr;
+    if (known && (double)need > 0.75 * (double)(free_b + c->partial_bytes)) why = "more than 3/4 of the free device memory";
+    else if (hipMalloc(&ws, need) != hipSuccess) {
+        (void)hipGetLastError();  // not an error of this context: the fallback below is the answer
+        ws = nullptr;
+        why = "hipMalloc failed";
+    }
+    if (!ws) {
+        snprintf(c->err, sizeof c->err, "note: the %.1f GB pair-slot workspace of the unordered-pair kernel (K1s) was not allocated (%s, "
+                 "%.1f GB free): this context evaluates every ordered pair (K1) instead", need / 1e9, why, free_b / 1e9);
+        c->sym_bytes = 0;
+        return;
+    }
+    (void)hipStreamSynchronize(c->stream);  // nothing in flight may still be reading the slice workspace
+    free_dev(c->partial);
+    c->partial = ws;
+    c->partial_bytes = need;
+}
+
+// the context's launch plan: K1s (every unordered pair once) when the system is large enough for it and its workspace
+// could be had, else K1
 F32Plan context_plan_f32(nb_context* c) {
+    ensure_sym_workspace(c);
     F32Plan plan = plan_f32(c->n, c->n, c->n_cus, 0, 0, c->partial != nullptr);
-    (void)plan_symmetric(plan, c->n, c->n, true, c->partial_bytes, c->cfg.precision == NB_F32_ACC64, c->n_cus, 0, 0);
+    if (c->sym_bytes)
+        (void)plan_symmetric(plan, c->n, c->n, true, c->partial_bytes, c->cfg.precision == NB_F32_ACC64, c->n_cus, 0, 0);
     return plan;
 }
 
@@ -220,9 +253,10 @@ int nb_create_cu_masked(nb_context** out, const nb_config* cfg, int cu_mask) {
 int nbi::create_context(nb_context** out, const nb_config* cfg, hipStream_t borrowed, int cu_mask) {
     if (!out || !cfg || cfg->n <= 0) return NB_ERR_INVALID;
     if (cfg->precision < NB_F64 || cfg->precision > NB_F32_ACC64) return NB_ERR_INVALID;
-    // fp32 kernels evaluate the self pair: eps^2 must survive the rounding to fp32 (1e-23 squared would not)
-    if (cfg->precision != NB_F64 && !((float)(cfg->eps * cfg->eps) > 0.f)) return NB_ERR_INVALID;
-    if (cfg->reserved != 0) return NB_ERR_INVALID;
+    // fp32 kernels evaluate the self pair as 0 * G*m*eps2^-1.5: eps^2 must be a normal fp32 number with a finite inverse cube
+    if (cfg->precision != NB_F64 && !((float)(cfg->eps * cfg->eps) >= F32_EPS2_MIN))
+        return set_error(NB_ERR_INVALID, "nb_create: the fp32 modes need eps >= 1e-12");
+    if (cfg->flags & ~NB_CFG_ORDERED_PAIRS) return NB_ERR_INVALID;
     if (cfg->f64_split < 0 || cfg->f64_split > 64 || (cfg->f64_split & (cfg->f64_split - 1))) return NB_ERR_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return NB_ERR_NO_DEVICE;
@@ -279,7 +313,7 @@ int nbi::create_context(nb_context** out, const nb_config* cfg, hipStream_t borr
             if (c->slices_large > 1)
                 NB_HIP(c, hipMalloc(&c->partial_large, (size_t)c->slices_large * 3 * n * sizeof(double)));
             // every unordered pair once (K1s-f64) where its slots are affordable and eps > 0 (the self pair then adds +0)
-            if (cfg->eps > 0 && sym64_workspace_bytes(c->n, c->n_cus) > 0)
+            if (cfg->eps * cfg->eps >= F64_EPS2_MIN && sym64_workspace_bytes(c->n, c->n_cus) > 0)
                 NB_HIP(c, hipMalloc(&c->sym64_slots, sym64_workspace_bytes(c->n, c->n_cus)));
         }
     } else {
@@ -295,9 +329,11 @@ int nbi::create_context(nb_context** out, const nb_config* cfg, hipStream_t borr
             c->partial_slots = (int)std::max<long>(SLICES_PER_LAUNCH, std::min<long>(std::min<long>(js, MAX_SLICES_PER_LAUNCH), cap));
             c->partial_bytes = (size_t)(c->partial_slots + 2) * n * rec;
         }
-        if (c->n >= SYM_MIN_N) {  // K1s: a slot per superblock round (1.6 GB at 2^20), in batches beyond 32 GiB of them
+        if (c->n >= SYM_MIN_N && !(cfg->flags & NB_CFG_ORDERED_PAIRS)) {
+            // K1s: a slot per superblock round (1.6 GB at 2^20), in batches beyond 32 GiB of them — wanted, not yet allocated
+            // (ensure_sym_workspace, on the first step)
             const F32SymBatches kb = sym_batches(c->n, c->n_cus, cfg->precision == NB_F32_ACC64);
-            if (kb.count >= 1 && kb.bytes <= SYM_MAX_WORKSPACE) c->partial_bytes = std::max(c->partial_bytes, kb.bytes);
+            if (kb.count >= 1 && kb.bytes <= SYM_MAX_WORKSPACE) c->sym_bytes = kb.bytes;
         }
         if (c->partial_bytes) NB_HIP(c, hipMalloc(&c->partial, c->partial_bytes));
         if (cfg->precision == NB_F32_ACC64) {
@@ -442,6 +478,12 @@ int nb_read_step_stamps(nb_context* c, uint64_t* out, int slots) {
     return NB_OK;
 }
 #endif  // NB_ABI_DEBUG
+
+const char* nb_context_kernel_name(nb_context* c) {
+    if (!c || c->cfg.precision == NB_F64) return "";
+    if (bind(c)) return "";
+    return kernel_name_f32(context_plan_f32(c), c->cfg.precision == NB_F32_ACC64, false);
+}
 
 int nb_step(nb_context* c, int first_step, int count) {
     if (!c || count < 0) return NB_ERR_INVALID;

@@ -1,5 +1,5 @@
 // nbody_internal.h — what the translation units behind the C ABI share (not installed; the public surface is
-// include/nbody_amd.h, the kernel interface nbody_kernels.h):
+// include/nbody_amd.h + include/nbody_amd_ext.h, the kernel interface nbody_kernels.h):
 //   nbody_capi.cpp       contexts, state, nb_step / nb_accel                          run_step call sites, nbody.cc:116,129
 //   nbody_launch.cpp     raw launches on caller-owned HBM (nb_launch_*_f32, shared-pairs pair)
 //   nbody_scenario.cpp   scenario drivers: persistent engine, per-step engine, graph replay, the Problem-3 follower queue
@@ -15,7 +15,7 @@
 #include <cstdio>
 #include <vector>
 
-#include "../../include/nbody_amd.h"
+#include "../../include/nbody_amd_ext.h"  // (includes nbody_amd.h)
 #include "nbody_kernels.h"
 
 #ifndef NB_ABI_DEBUG
@@ -73,10 +73,13 @@ struct nb_context {
     double4* pos64 = nullptr;
     double4* vel64 = nullptr;
     void* acc32 = nullptr;
-    void* partial = nullptr;  // workspace: source slices [2 + partial_slots][n] float4 (double4 for ACC64), and — large
-                              // enough for it from SYM_MIN_N bodies on — the pair slots of the symmetric kernel K1s
+    void* partial = nullptr;  // workspace: source slices [2 + partial_slots][n] float4 (double4 for ACC64) — allocated by
+                              // nb_create — or, from the first nb_step / nb_accel of a system of SYM_MIN_N bodies or more, the
+                              // (larger) pair-slot workspace of the symmetric kernel K1s, which holds the slices too
     int partial_slots = 0;
     size_t partial_bytes = 0;
+    size_t sym_bytes = 0;     // what K1s needs (0: does not apply, NB_CFG_ORDERED_PAIRS, or given up)
+    bool sym_tried = false;   // the pair-slot workspace was asked for once (lazily: ensure_sym_workspace)
 };
 
 namespace nbi {

@@ -39,6 +39,10 @@ struct F32Args {
     int slice0;            // ... and the index of the slice blockIdx.y == 0 works on
     float eps2, dt;
 };
+// The fp32 kernels evaluate the self pair and the zero-mass padding as d = 0 times G*m*rinv^3: that is exactly +0 only while
+// rinv^3 = eps2^-1.5 is finite in fp32 (eps2 >= 4.4e-26) and eps2 is a normal number (v_rsq_f32 flushes denormals); below
+// it every body would get 0 * inf = NaN.  Refused at the ABI: eps >= 1e-12.
+constexpr float F32_EPS2_MIN = 1e-24f;
 constexpr int F32_PHASE_WHOLE = 0;   // all of the step: start the sums, run the epilogue
 constexpr int F32_PHASE_FIRST = 1;   // start the sums, keep them in the workspace
 constexpr int F32_PHASE_LAST = 2;    // continue the sums, then the epilogue (store accelerations / kick-drift)
@@ -178,6 +182,10 @@ int launch_f32(const F32Args& a, const F32Plan& plan, bool acc64, bool accel_onl
 const char* kernel_name_f32(const F32Plan& plan, bool acc64, bool accel_only);
 
 // ---------------------------------------------------------------- fp64 (testcases, n <= a few thousand)
+// The fp64 kernels drop the `j == i` compare when the self pair adds +0 by itself — d = 0 times G*m_j * (eps2)^-1.5, which
+// needs that product finite: eps2 >= 1e-160 leaves 1e240 x G*m up to 1e68.  Below (eps = 0 included) the SELFCHECK
+// instantiations run, which skip the self pair explicitly like the reference (nbody.cc:59).
+constexpr double F64_EPS2_MIN = 1e-160;
 struct F64Monitor {  // device-resident scenario state, written by workgroup 0 only
     double min_d2;
     int hit_step;

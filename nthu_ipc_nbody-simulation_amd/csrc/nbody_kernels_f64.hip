@@ -494,7 +494,7 @@ __global__ __launch_bounds__(SMALL_N_MAX * S) void nbody_scenario_small_f64_batc
 template <int S>
 static int launch_small_s(const F64SmallArgs& a, int threads, hipStream_t stream) {
     const bool few = a.scn.n_watch <= SMALL_FEW;
-    if (a.eps2 > 0.0) {
+    if (a.eps2 >= F64_EPS2_MIN) {
         if (few) hipLaunchKernelGGL((nbody_scenario_small_f64<S, false, true>), dim3(1), dim3(threads), 0, stream, a);
         else hipLaunchKernelGGL((nbody_scenario_small_f64<S, false, false>), dim3(1), dim3(threads), 0, stream, a);
     } else {
@@ -520,7 +520,7 @@ int launch_f64_small_batched(const F64SmallBatchArgs& b, int n, hipStream_t stre
     const int threads = ((n * S + 63) / 64) * 64;
     bool eps_positive = true, few = true;
     for (int k = 0; k < b.count; ++k) {
-        eps_positive &= (b.item[k].n <= 0 || b.item[k].eps2 > 0.0);
+        eps_positive &= (b.item[k].n <= 0 || b.item[k].eps2 >= F64_EPS2_MIN);
         few &= (b.item[k].n <= 0 || b.item[k].scn.n_watch <= SMALL_FEW);
     }
     const dim3 grid(b.count), block(threads);
@@ -680,7 +680,7 @@ static int launch_large(const F64LargeArgs& a, hipStream_t stream) {
 }
 
 int launch_f64_large(const F64LargeArgs& a, hipStream_t stream) {
-    const bool accel = a.acc_out != nullptr, selfcheck = !(a.eps2 > 0.0);
+    const bool accel = a.acc_out != nullptr, selfcheck = !(a.eps2 >= F64_EPS2_MIN);
     if (accel) return selfcheck ? launch_large<true, true>(a, stream) : launch_large<true, false>(a, stream);
     return selfcheck ? launch_large<false, true>(a, stream) : launch_large<false, false>(a, stream);
 }
@@ -690,7 +690,7 @@ static int launch_s(const F64Args& a, hipStream_t stream) {
     constexpr int TPB = K2_WG / S;
     // a monitor-only launch (do_update == 0) still needs every owner lane when a missile-arrival snapshot may be due
     int blocks = (a.do_update || a.snap_q) ? (a.n + TPB - 1) / TPB : 1;
-    if (a.eps2 > 0.0) hipLaunchKernelGGL((nbody_step_f64<S, false>), dim3(blocks), dim3(K2_WG), 0, stream, a);
+    if (a.eps2 >= F64_EPS2_MIN) hipLaunchKernelGGL((nbody_step_f64<S, false>), dim3(blocks), dim3(K2_WG), 0, stream, a);
     else hipLaunchKernelGGL((nbody_step_f64<S, true>), dim3(blocks), dim3(K2_WG), 0, stream, a);
     return (int)hipGetLastError();
 }
@@ -699,7 +699,7 @@ template <int S>
 static int launch_batched_s(const F64BatchArgs& b, int n, hipStream_t stream) {
     constexpr int TPB = K2_WG / S;
     bool eps_positive = true;
-    for (int k = 0; k < b.count; ++k) eps_positive &= (b.item[k].n <= 0 || b.item[k].eps2 > 0.0);
+    for (int k = 0; k < b.count; ++k) eps_positive &= (b.item[k].n <= 0 || b.item[k].eps2 >= F64_EPS2_MIN);
     if (eps_positive) hipLaunchKernelGGL((nbody_step_f64_batched<S, false>), dim3((n + TPB - 1) / TPB, b.count), dim3(K2_WG), 0, stream, b);
     else hipLaunchKernelGGL((nbody_step_f64_batched<S, true>), dim3((n + TPB - 1) / TPB, b.count), dim3(K2_WG), 0, stream, b);
     return (int)hipGetLastError();

@@ -187,7 +187,7 @@ size_t sym64_workspace_bytes(int n, int n_cus) {
 }
 
 int launch_f64_large_sym(const F64LargeArgs& a, int n_cus, hipStream_t stream) {
-    if (!a.sym_slots || !a.gm || !(a.eps2 > 0.0) || a.n < 16 * SB) return (int)hipErrorInvalidValue;
+    if (!a.sym_slots || !a.gm || !(a.eps2 >= F64_EPS2_MIN) || a.n < 16 * SB) return (int)hipErrorInvalidValue;
     const F32SymShape sh = sym_shape(a.n, n_cus, 0, 0, 0, SB);
     const unsigned b1 = (unsigned)((a.n + WG - 1) / WG);
     hipLaunchKernelGGL(nbody_gm_f64, dim3(b1), dim3(WG), 0, stream, a.m, a.coef, a.gm, a.n, a.fst, a.G);

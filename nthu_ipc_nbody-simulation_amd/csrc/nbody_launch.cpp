@@ -18,7 +18,7 @@ extern "C" {
 static int check_launch(const nb_launch_f32* a, bool accel_only) {
     if (!a || !a->src || a->n_src <= 0 || a->n_tgt <= 0 || a->tgt_off < 0) return NB_ERR_INVALID;
     if (!a->tgt && a->tgt_off + a->n_tgt > a->n_src) return NB_ERR_INVALID;  // targets are a window of the sources
-    if (!(a->eps2 > 0.f)) return NB_ERR_INVALID;
+    if (!(a->eps2 >= F32_EPS2_MIN)) return set_error(NB_ERR_INVALID, "fp32 kernels need eps2 >= 1e-24 (eps >= 1e-12): the self pair is 0 * G*m*eps2^-1.5");
     if (accel_only ? !a->acc : (!a->out || (a->acc64 ? (!a->pos64 || !a->vel64) : !a->vel))) return NB_ERR_INVALID;
     const int r = a->targets_per_lane;
     if (r != 0 && r != 2 && r != 4 && r != 8) return NB_ERR_INVALID;
@@ -135,7 +135,7 @@ static bool shared_pairs_shape(const nb_launch_f32* a, F32SymShape* sh) {
 
 int nb_launch_pair_forces_f32(const nb_launch_f32* a, void* hip_stream) {
     F32SymShape sh{};
-    if (!a || !a->src || !a->acc || !a->workspace || !(a->eps2 > 0.f) || a->tgt || a->phase != NB_PHASE_WHOLE || a->src_begin ||
+    if (!a || !a->src || !a->acc || !a->workspace || !(a->eps2 >= F32_EPS2_MIN) || a->tgt || a->phase != NB_PHASE_WHOLE || a->src_begin ||
         a->src_end || !shared_pairs_shape(a, &sh))
         return set_error(NB_ERR_INVALID, "nb_launch_pair_forces_f32: the shard must be whole 4096-body superblocks of a system of "
                          ">= 49152 bodies (n_src = ranks * n_tgt, tgt_off = rank * n_tgt), with acc and a workspace");
@@ -161,6 +161,24 @@ int64_t nb_workspace_bytes_shared_pairs_f32(int64_t n_src, int ranks, int acc64)
     a.acc64 = acc64;
     F32SymShape sh{};
     return shared_pairs_shape(&a, &sh) ? (int64_t)sym_partial_workspace_bytes(sh, acc64 != 0) : 0;
+}
+
+int nb_plan_shared_pairs_f32(int64_t n_src, int ranks, int acc64, int* superblocks_per_rank, int* workgroups_per_superblock,
+                             int* sub_launches) {
+    if (ranks < 2 || n_src <= 0 || n_src % ranks) return NB_ERR_INVALID;
+    nb_launch_f32 a{};
+    a.n_src = n_src;
+    a.n_tgt = n_src / ranks;
+    a.acc64 = acc64;
+    F32SymShape sh{};
+    if (!shared_pairs_shape(&a, &sh)) return set_error(NB_ERR_INVALID, "nb_plan_shared_pairs_f32: these ranks cannot share the pairs of this system");
+    // the grid of the (first) launch: a share that goes out in sub-launches is re-cut for the smaller superblock count
+    const int sub = sym_sub_batch(sh, acc64 != 0);
+    const F32SymShape first = sub >= sh.nb ? sh : sym_sub_shape(sh, sh.b0, sub);
+    if (superblocks_per_rank) *superblocks_per_rank = sh.nb;
+    if (workgroups_per_superblock) *workgroups_per_superblock = first.chunks;
+    if (sub_launches) *sub_launches = (sh.nb + sub - 1) / sub;
+    return NB_OK;
 }
 
 // Host-only replay of K1s' pair schedule for `n` bodies on `ranks` GPUs of `n_cus` compute units each (ranks = 1: the

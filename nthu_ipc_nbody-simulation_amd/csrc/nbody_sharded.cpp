@@ -31,9 +31,10 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
-#include "../../include/nbody_amd.h"
+#include "../../include/nbody_amd_ext.h"
 #include "nbody_kernels.h"
 
 using namespace nbk;
@@ -103,7 +104,11 @@ struct Rank {
     void* facc = nullptr;
     hipEvent_t forced = nullptr;  // copy exchange: fpart is complete
     ncclComm_t comm = nullptr;
+    // bounded waits (nb_sharded_set_deadline): `done[i % STEPS_IN_FLIGHT]` is recorded behind step i's last enqueue on every
+    // stream the step used; the host waits for it — with the deadline — before it enqueues step i + STEPS_IN_FLIGHT
+    std::vector<hipEvent_t> done;
 };
+constexpr int STEPS_IN_FLIGHT = 16;
 
 }  // namespace
 
@@ -121,6 +126,10 @@ struct nb_sharded {
     F32SymShape shape{};  // of rank 0 (rank r: b0 = r * nb)
     bool ready = false;  // creation went through: streams, buffers and (RCCL) communicators exist
     const RcclApi* api = nullptr;  // null with NB_SHARDED_COPY_EXCHANGE
+    double deadline_s = 0;   // > 0: no wait blocks inside the runtime; a step gets this long once the host waits for it
+    long enqueued = 0;       // steps enqueued since the streams were last drained (the `done` ring is indexed by it)
+    long awaited = 0;        // ... of which the first `awaited` are known to have finished
+    bool dead = false;       // a wait timed out: the GPUs may still be busy with what was enqueued; nothing may be enqueued
     char err[512] = {0};
 };
 
@@ -143,6 +152,37 @@ int fail(nb_sharded* s, int code, const char* what, const char* detail) {
         ncclResult_t r_ = (call);                                                             \
         if (r_ != ncclSuccess) return fail(s, NB_ERR_HIP, #call, (s)->api->GetErrorString(r_)); \
     } while (0)
+
+// ---- bounded waits.  Without a deadline: the runtime's blocking calls, as always.  With one: poll, sleeping 50 us between
+// looks once the first thousand have failed (a step of the bench is milliseconds: the poll costs nothing against it), and
+// give the awaited thing `deadline_s` from the moment the host starts to wait for it.
+template <class Query>
+int wait_until(nb_sharded* s, Query&& query, const char* what) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (long spin = 0;; ++spin) {
+        const hipError_t e = query();
+        if (e == hipSuccess) return NB_OK;
+        if (e != hipErrorNotReady) return fail(s, NB_ERR_HIP, what, hipGetErrorString(e));
+        (void)hipGetLastError();  // hipErrorNotReady is sticky in the last-error slot on some runtimes: not an error here
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > s->deadline_s) {
+            s->dead = true;
+            char detail[160];
+            snprintf(detail, sizeof detail, "timed out after %.3g s: %s", s->deadline_s, what);
+            return fail(s, NB_ERR_HIP, "exchange timed out", detail);
+        }
+        if (spin > 1000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+}
+int wait_stream(nb_sharded* s, hipStream_t st, const char* what) {
+    if (s->deadline_s <= 0) SH_HIP(s, hipStreamSynchronize(st));
+    else return wait_until(s, [&] { return hipStreamQuery(st); }, what);
+    return NB_OK;
+}
+int wait_event(nb_sharded* s, hipEvent_t ev, const char* what) {
+    if (s->deadline_s <= 0) SH_HIP(s, hipEventSynchronize(ev));
+    else return wait_until(s, [&] { return hipEventQuery(ev); }, what);
+    return NB_OK;
+}
 
 bool acc64(const nb_sharded* s) { return s->precision == NB_F32_ACC64; }
 bool overlapped(const nb_sharded* s) { return (s->flags & NB_SHARDED_OVERLAP) && s->P > 1; }
@@ -343,8 +383,22 @@ int launch_rank(nb_sharded* s, Rank& k, bool ov) {
     return NB_OK;
 }
 
+// bounded waits: step `i` of the steps enqueued since the last drain has finished on every GPU
+int await_step(nb_sharded* s, long i) {
+    for (Rank& k : s->rank) {
+        SH_HIP(s, hipSetDevice(k.device));
+        if (int rc = wait_event(s, k.done[(size_t)(i % STEPS_IN_FLIGHT)], "a step of the sharded system (kernels + exchange)")) return rc;
+    }
+    return NB_OK;
+}
+
 int step_once(nb_sharded* s, StepEvents* ev = nullptr, size_t step = 0) {
     const bool ov = overlapped(s);
+    if (s->deadline_s > 0)  // never more than STEPS_IN_FLIGHT steps ahead of the GPUs: the oldest one gets the deadline
+        while (s->enqueued - s->awaited >= STEPS_IN_FLIGHT) {
+            if (int rc = await_step(s, s->awaited)) return rc;
+            ++s->awaited;
+        }
     for (size_t r = 0; r < s->rank.size(); ++r) {
         Rank& k = s->rank[r];
         SH_HIP(s, hipSetDevice(k.device));
@@ -359,24 +413,52 @@ int step_once(nb_sharded* s, StepEvents* ev = nullptr, size_t step = 0) {
     if (int rc = copy_exchange(s) ? exchange_copy(s, nxt, ov) : exchange_rccl(s, nxt, ov)) return rc;
     s->gather_pending = ov;
     s->cur = nxt;
+    if (s->deadline_s > 0) {  // (an overlapped step's gather sits on the comm stream: the NEXT step's kernels wait for it, and
+                              // the final drain looks at both streams)
+        for (Rank& k : s->rank) {
+            SH_HIP(s, hipSetDevice(k.device));
+            SH_HIP(s, hipEventRecord(k.done[(size_t)(s->enqueued % STEPS_IN_FLIGHT)], k.stream));
+        }
+        ++s->enqueued;
+    }
     return NB_OK;
 }
 
 int sync_all(nb_sharded* s) {
+    if (s->deadline_s > 0)  // step by step, each with its own allowance; then whatever else sits on the streams
+        for (; s->awaited < s->enqueued; ++s->awaited)
+            if (int rc = await_step(s, s->awaited)) return rc;
     for (Rank& k : s->rank) {
         SH_HIP(s, hipSetDevice(k.device));
-        SH_HIP(s, hipStreamSynchronize(k.stream));
-        if (k.comm_stream) SH_HIP(s, hipStreamSynchronize(k.comm_stream));
+        if (int rc = wait_stream(s, k.stream, "a GPU's compute stream to drain")) return rc;
+        if (k.comm_stream)
+            if (int rc = wait_stream(s, k.comm_stream, "a GPU's exchange stream to drain")) return rc;
     }
+    s->enqueued = s->awaited = 0;
     s->gather_pending = false;
     return NB_OK;
 }
 
 void release(nb_sharded* s) {
+    if (s->dead) {
+        // a wait timed out.  One more allowance for the GPUs to drain; if they do not, everything they may still be reading or
+        // writing — buffers, streams, events, communicators — is abandoned rather than freed (hipFree and ncclCommDestroy
+        // would block on the wedged work for ever); the process is about to report the failure and exit
+        bool idle = true;
+        for (Rank& k : s->rank) {
+            (void)hipSetDevice(k.device);
+            for (hipStream_t st : {k.stream, k.comm_stream})
+                if (st && wait_stream(s, st, "the streams to drain before the system is destroyed") != NB_OK) idle = false;
+            if (!idle) break;
+        }
+        if (!idle) return;
+    }
     for (Rank& k : s->rank) {
         (void)hipSetDevice(k.device);
         if (k.stream) (void)hipStreamSynchronize(k.stream);
         if (k.comm_stream) (void)hipStreamSynchronize(k.comm_stream);
+        for (hipEvent_t e : k.done)
+            if (e) (void)hipEventDestroy(e);
         if (k.comm && s->api) (void)s->api->CommDestroy(k.comm);
         for (void* p : {(void*)k.pos[0], (void*)k.pos[1], (void*)k.vel, (void*)k.pos64, (void*)k.vel64, k.ws, k.fpart, k.facc})
             if (p) (void)hipFree(p);
@@ -394,7 +476,7 @@ int create_impl(nb_sharded** out, const int* devices, int n_devices, int64_t n, 
     *out = nullptr;
     if (!devices || n_devices <= 0 || n_devices > 64 || n <= 0) return fail(nullptr, NB_ERR_INVALID, "nb_sharded_create", "bad argument");
     if (precision != NB_F32 && precision != NB_F32_ACC64) return fail(nullptr, NB_ERR_INVALID, "nb_sharded_create", "precision must be NB_F32 or NB_F32_ACC64");
-    if (!((float)(eps * eps) > 0.f)) return fail(nullptr, NB_ERR_INVALID, "nb_sharded_create", "fp32 kernels need eps > 0 (eps^2 representable in fp32)");
+    if (!((float)(eps * eps) >= F32_EPS2_MIN)) return fail(nullptr, NB_ERR_INVALID, "nb_sharded_create", "fp32 kernels need eps >= 1e-12 (eps^2 a normal fp32 number with a finite inverse cube)");
     if (n % n_devices) return fail(nullptr, NB_ERR_INVALID, "nb_sharded_create", "n must be divisible by the number of devices");
     // overlap cuts the sources at shard boundaries: they must fall on whole 256-body tiles
     if ((flags & NB_SHARDED_OVERLAP) && n_devices > 1 && (n / n_devices) % TILE)
@@ -455,17 +537,53 @@ int create_impl(nb_sharded** out, const int* devices, int n_devices, int64_t n, 
             k.ws_slots = workspace_slots(s, k.n_cus);
             k.ws_bytes = (size_t)workspace_bytes(s, k.ws_slots);
         }
-        if (n_devices == 1 && n >= SYM_MIN_N && !(flags & NB_SHARDED_ORDERED_PAIRS)) {  // room for K1s' pair slots (as nb_create)
-            const F32SymBatches kb = sym_batches(n, k.n_cus, acc64(s));
-            if (kb.count >= 1 && kb.bytes <= SYM_MAX_WORKSPACE) k.ws_bytes = std::max(k.ws_bytes, kb.bytes);
+    }
+    // Every unordered pair once (K1s) wants more memory than the ordered-pair step: pair slots (n^2-ish: 1.7 GB for one GPU at
+    // n = 2^20, 6.6 GB per GPU of 8 at 2^22, 52 GB at 2^24) and, with several GPUs, a partial force on all n bodies.  It is a
+    // preference, not a requirement: if any GPU cannot give it — more than 3/4 of its free memory, or hipMalloc fails — every
+    // GPU gives back what it got and the system steps with ordered pairs (K1); `note` (nb_sharded_last_error after a
+    // successful create) says so.  Ranks that share a GPU (copy exchange) see each other's allocations in the free figure.
+    const bool want_one = n_devices == 1 && n >= SYM_MIN_N && !(flags & NB_SHARDED_ORDERED_PAIRS);
+    if (s->sym || want_one) {
+        const char* why = nullptr;
+        size_t need = 0, free_b = 0, total_b = 0;
+        for (Rank& k : s->rank) {
+            SH_HIP(s, hipSetDevice(k.device));
+            size_t ws = 0;
+            if (want_one) {
+                const F32SymBatches kb = sym_batches(n, k.n_cus, acc64(s));
+                if (kb.count >= 1 && kb.bytes <= SYM_MAX_WORKSPACE) ws = kb.bytes;
+            } else ws = sym_partial_workspace_bytes(s->shape, acc64(s));
+            if (!ws) { why = "does not apply"; break; }
+            ws = std::max(ws, k.ws_bytes);
+            const size_t fp = s->sym ? N * force_rec(s) : 0, fa = s->sym ? (copy_exchange(s) ? (size_t)n_devices : 1) * per * force_rec(s) : 0;
+            need = ws + fp + fa;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+            else if ((double)need > 0.75 * (double)free_b) { why = "more than 3/4 of a GPU's free memory"; break; }
+            if (hipMalloc(&k.ws, ws) != hipSuccess || (fp && hipMalloc(&k.fpart, fp) != hipSuccess) || (fa && hipMalloc(&k.facc, fa) != hipSuccess)) {
+                (void)hipGetLastError();
+                why = "hipMalloc failed";
+                break;
+            }
+            k.ws_bytes = ws;
+            if (s->sym && copy_exchange(s)) SH_HIP(s, hipEventCreateWithFlags(&k.forced, hipEventDisableTiming));
         }
-        if (s->sym) {
-            k.ws_bytes = std::max(k.ws_bytes, sym_partial_workspace_bytes(s->shape, acc64(s)));
-            SH_HIP(s, hipMalloc(&k.fpart, N * force_rec(s)));
-            SH_HIP(s, hipMalloc(&k.facc, (copy_exchange(s) ? (size_t)n_devices : 1) * per * force_rec(s)));
-            if (copy_exchange(s)) SH_HIP(s, hipEventCreateWithFlags(&k.forced, hipEventDisableTiming));
+        if (why) {
+            for (Rank& k : s->rank) {
+                (void)hipSetDevice(k.device);
+                for (void** p : {&k.ws, &k.fpart, &k.facc})
+                    if (*p) { (void)hipFree(*p); *p = nullptr; }
+                k.ws_bytes = k.ws_slots ? (size_t)workspace_bytes(s, k.ws_slots) : 0;
+            }
+            if (strcmp(why, "does not apply"))
+                snprintf(s->err, sizeof s->err, "note: the unordered-pair step (K1s) needs %.1f GB per GPU (%s, %.1f GB free): stepping with "
+                         "ordered pairs (K1) instead", need / 1e9, why, free_b / 1e9);
+            s->sym = false;
         }
-        if (k.ws_bytes) SH_HIP(s, hipMalloc(&k.ws, k.ws_bytes));
+    }
+    for (Rank& k : s->rank) {
+        SH_HIP(s, hipSetDevice(k.device));
+        if (k.ws_bytes && !k.ws) SH_HIP(s, hipMalloc(&k.ws, k.ws_bytes));
     }
     if (copy_exchange(s)) {
         // direct xGMI copies between distinct GPUs; without peer access the runtime stages through the host, which is
@@ -504,7 +622,7 @@ int set_state_impl(nb_sharded* s, const double* qx, const double* qy, const doub
         SH_HIP(s, hipMemcpyAsync(k.pos[0], p.data(), N * sizeof(float4), hipMemcpyHostToDevice, k.stream));
         SH_HIP(s, hipMemcpyAsync(k.pos[1], p.data(), N * sizeof(float4), hipMemcpyHostToDevice, k.stream));
         SH_HIP(s, hipMemcpyAsync(k.vel, v.data(), per * sizeof(float4), hipMemcpyHostToDevice, k.stream));
-        SH_HIP(s, hipStreamSynchronize(k.stream));  // `v` is refilled for the next GPU
+        if (int rc = wait_stream(s, k.stream, "the upload of the state")) return rc;  // `v` is refilled for the next GPU
         if (acc64(s)) {
             for (size_t i = 0; i < per; ++i) {
                 p64[i] = make_double4(qx[lo + i], qy[lo + i], qz[lo + i], s->G * m[lo + i]);
@@ -512,7 +630,7 @@ int set_state_impl(nb_sharded* s, const double* qx, const double* qy, const doub
             }
             SH_HIP(s, hipMemcpyAsync(k.pos64, p64.data(), per * sizeof(double4), hipMemcpyHostToDevice, k.stream));
             SH_HIP(s, hipMemcpyAsync(k.vel64, v64.data(), per * sizeof(double4), hipMemcpyHostToDevice, k.stream));
-            SH_HIP(s, hipStreamSynchronize(k.stream));
+            if (int rc = wait_stream(s, k.stream, "the upload of the state")) return rc;
         }
     }
     s->cur = 0;
@@ -530,7 +648,7 @@ int get_state_impl(nb_sharded* s, double* qx, double* qy, double* qz, double* vx
             SH_HIP(s, hipSetDevice(k.device));
             SH_HIP(s, hipMemcpyAsync(p.data(), k.pos64, per * sizeof(double4), hipMemcpyDeviceToHost, k.stream));
             SH_HIP(s, hipMemcpyAsync(v.data(), k.vel64, per * sizeof(double4), hipMemcpyDeviceToHost, k.stream));
-            SH_HIP(s, hipStreamSynchronize(k.stream));
+            if (int rc = wait_stream(s, k.stream, "the download of the state")) return rc;
             const size_t lo = (size_t)k.lo;
             for (size_t i = 0; i < per; ++i) {
                 qx[lo + i] = p[i].x; qy[lo + i] = p[i].y; qz[lo + i] = p[i].z;
@@ -545,12 +663,12 @@ int get_state_impl(nb_sharded* s, double* qx, double* qy, double* qz, double* vx
     Rank& last = s->rank.back();
     SH_HIP(s, hipSetDevice(last.device));
     SH_HIP(s, hipMemcpyAsync(p.data(), last.pos[s->cur], N * sizeof(float4), hipMemcpyDeviceToHost, last.stream));
-    SH_HIP(s, hipStreamSynchronize(last.stream));
+    if (int rc = wait_stream(s, last.stream, "the download of the state")) return rc;
     for (size_t i = 0; i < N; ++i) { qx[i] = p[i].x; qy[i] = p[i].y; qz[i] = p[i].z; }
     for (Rank& k : s->rank) {
         SH_HIP(s, hipSetDevice(k.device));
         SH_HIP(s, hipMemcpyAsync(v.data(), k.vel, per * sizeof(float4), hipMemcpyDeviceToHost, k.stream));
-        SH_HIP(s, hipStreamSynchronize(k.stream));
+        if (int rc = wait_stream(s, k.stream, "the download of the state")) return rc;
         const size_t lo = (size_t)k.lo;
         for (size_t i = 0; i < per; ++i) { vx[lo + i] = v[i].x; vy[lo + i] = v[i].y; vz[lo + i] = v[i].z; }
     }
@@ -579,10 +697,32 @@ int nb_sharded_destroy(nb_sharded* s) {
 
 const char* nb_sharded_last_error(const nb_sharded* s) { return s ? s->err : g_err; }
 
+int nb_sharded_set_deadline(nb_sharded* s, double seconds) {
+    if (!s || !(seconds >= 0)) return NB_ERR_INVALID;
+    if (!s->ready || s->dead) return NB_ERR_STATE;
+    if (int rc = sync_all(s)) return rc;  // under the old rule; the step counters restart at zero
+    try {
+        if (seconds > 0)
+            for (Rank& k : s->rank) {
+                SH_HIP(s, hipSetDevice(k.device));
+                k.done.reserve(STEPS_IN_FLIGHT);
+                while ((int)k.done.size() < STEPS_IN_FLIGHT) {
+                    hipEvent_t e = nullptr;
+                    SH_HIP(s, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                    k.done.push_back(e);
+                }
+            }
+    } catch (...) {
+        return NB_ERR_NOMEM;
+    }
+    s->deadline_s = seconds;
+    return NB_OK;
+}
+
 int nb_sharded_set_state(nb_sharded* s, const double* qx, const double* qy, const double* qz, const double* vx,
                          const double* vy, const double* vz, const double* m) {
     if (!s || !qx || !qy || !qz || !vx || !vy || !vz || !m) return NB_ERR_INVALID;
-    if (!s->ready) return NB_ERR_STATE;  // creation failed half way
+    if (!s->ready || s->dead) return NB_ERR_STATE;  // creation failed half way / a wait timed out
     try {
         return set_state_impl(s, qx, qy, qz, vx, vy, vz, m);
     } catch (...) {
@@ -592,7 +732,7 @@ int nb_sharded_set_state(nb_sharded* s, const double* qx, const double* qy, cons
 
 int nb_sharded_get_state(nb_sharded* s, double* qx, double* qy, double* qz, double* vx, double* vy, double* vz) {
     if (!s || !qx || !qy || !qz || !vx || !vy || !vz) return NB_ERR_INVALID;
-    if (!s->have_state) return NB_ERR_STATE;
+    if (!s->have_state || s->dead) return NB_ERR_STATE;
     try {
         return get_state_impl(s, qx, qy, qz, vx, vy, vz);
     } catch (...) {
@@ -602,7 +742,7 @@ int nb_sharded_get_state(nb_sharded* s, double* qx, double* qy, double* qz, doub
 
 int nb_sharded_step(nb_sharded* s, int count) {
     if (!s || count < 0) return NB_ERR_INVALID;
-    if (!s->have_state) return NB_ERR_STATE;
+    if (!s->have_state || s->dead) return NB_ERR_STATE;
     for (int i = 0; i < count; ++i)
         if (int rc = step_once(s)) return rc;
     return sync_all(s);
@@ -610,7 +750,7 @@ int nb_sharded_step(nb_sharded* s, int count) {
 
 int nb_sharded_step_timed(nb_sharded* s, int count, double* ms_per_step) {
     if (!s || count <= 0 || !ms_per_step) return NB_ERR_INVALID;
-    if (!s->have_state) return NB_ERR_STATE;
+    if (!s->have_state || s->dead) return NB_ERR_STATE;
     if (int rc = sync_all(s)) return rc;
     const auto t0 = std::chrono::steady_clock::now();
     for (int i = 0; i < count; ++i)
@@ -668,7 +808,7 @@ static int step_profiled_impl(nb_sharded* s, int count, double* wall_ms_per_step
 
 int nb_sharded_step_profiled(nb_sharded* s, int count, double* wall_ms_per_step, float* kernel_ms) {
     if (!s || count <= 0 || count > 1024 || !wall_ms_per_step || !kernel_ms) return NB_ERR_INVALID;
-    if (!s->have_state) return NB_ERR_STATE;
+    if (!s->have_state || s->dead) return NB_ERR_STATE;
     try {
         return step_profiled_impl(s, count, wall_ms_per_step, kernel_ms);
     } catch (...) {

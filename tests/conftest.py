@@ -32,6 +32,8 @@ def pytest_configure(config):
     _CONFIG = config
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long CPU-only oracle runs, opt in with NB_SLOW=1")
+    config.addinivalue_line("markers", "heavy: GPU tests of about a minute each (full-size 8-rank shapes); part of -m gpu, "
+                                       "deselect with -m 'gpu and not heavy' when the suite must be short")
 
 
 @pytest.fixture(scope="session")

@@ -1,4 +1,5 @@
-"""The C-ABI library loads and exports every symbol include/nbody_amd.h declares (no compute without a GPU)."""
+"""The C-ABI library loads and exports every symbol include/nbody_amd.h (the run_step boundary) and include/nbody_amd_ext.h
+(raw launches, shared pairs, nb_sharded_*, nb_solve_ex) declare (no compute without a GPU)."""
 import os
 import re
 
@@ -13,14 +14,29 @@ def _declared_symbols(header="nbody_amd.h"):
     return sorted(set(re.findall(r"\b(nb_[a-z0-9_]+)\s*\(", text)))
 
 
+# what a caller of run_step needs and nothing else ("thin C-ABI"): lifecycle, state, nb_step / nb_accel,
+# scenarios, nb_solve, state files
+CORE = {"nb_abi_version", "nb_device_count", "nb_config_default", "nb_create", "nb_destroy", "nb_strerror", "nb_last_error",
+        "nb_set_state", "nb_get_state", "nb_set_mass", "nb_step", "nb_accel", "nb_step_timed", "nb_run_scenario",
+        "nb_run_scenarios_batched", "nb_restore_snapshot", "nb_save_state", "nb_load_state", "nb_state_file_info",
+        "nb_read_state_file", "nb_write_state_file", "nb_solve"}
+
+
 def test_header_and_binding_agree(nb):
-    declared = _declared_symbols()
-    assert declared, "no declarations parsed"
+    core, ext = _declared_symbols(), _declared_symbols("nbody_amd_ext.h")
+    assert set(core) == CORE, sorted(set(core) ^ CORE)   # the core header stays the run_step boundary
+    assert ext and not set(core) & set(ext)
+    for name in ("nb_launch_step_f32", "nb_launch_pair_forces_f32", "nb_sharded_create", "nb_sharded_set_deadline", "nb_solve_ex",
+                 "nb_selftest_pair_schedule", "nb_plan_shared_pairs_f32", "nb_context_kernel_name"):
+        assert name in ext, name
+    declared = sorted(core + ext)
     assert sorted(nb.capi.SYMBOLS) == declared
     L = nb.capi.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.nb_abi_version() == 4
+    assert L.nb_abi_version() == 5
+    text = open(os.path.join(ROOT, "include", "nbody_amd.h")).read()
+    assert "nb_launch_f32" not in text and "typedef struct nb_sharded" not in text and "nb_solve_options {" not in text
     # the measurement hooks live in their own header and are NOT exported by the product library
     debug = _declared_symbols("nbody_amd_debug.h")
     assert sorted(nb.capi.DEBUG_SYMBOLS) == debug and len(debug) == 3
@@ -140,7 +156,7 @@ def test_header_is_plain_c_and_links_from_c(nb, tmp_path):
     src = tmp_path / "abi.c"
     src.write_text(r"""
 #include <stdio.h>
-#include "nbody_amd.h"
+#include "nbody_amd_ext.h"
 int main(void) {
     nb_config cfg;
     nb_scenario scn; nb_scenario_result res; nb_answer ans; nb_launch_f32 l; nb_state_header h; nb_solve_options o;
@@ -165,6 +181,21 @@ int main(void) {
     p = subprocess.run([str(exe)], capture_output=True, text=True)
     assert p.returncode == 0, (p.returncode, p.stderr)
     assert p.stdout.startswith("ok|no usable HIP device")
+    # the core header by itself is a complete C99 translation unit too — what INTEGRATION.md's binding includes
+    core = tmp_path / "core.c"
+    core.write_text(r"""
+#include "nbody_amd.h"
+int main(void) {
+    nb_config cfg; nb_answer ans; nb_scenario scn; (void)ans; (void)scn;
+    if (nb_config_default(&cfg) != NB_OK || cfg.flags != 0 || NB_CFG_ORDERED_PAIRS != 1) return 1;
+    return nb_abi_version() == 5 ? 0 : 2;
+}
+""")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                    "-o", str(exe), str(core), "-L", libdir, "-lnbody_amd", f"-Wl,-rpath,{libdir}"], check=True)
+    assert subprocess.run([str(exe)]).returncode == 0
+    binding = open(os.path.join(ROOT, "oracle", "ref_gpu_binding.cc")).read()
+    assert "nbody_amd.h" in binding and "nbody_amd_ext.h" not in binding  # the reference-side binding needs the core only
 
 
 def test_instrumented_build_exports_the_same_abi(nb):
@@ -178,7 +209,7 @@ def test_instrumented_build_exports_the_same_abi(nb):
     for name in list(nb.capi.SYMBOLS) + list(nb.capi.DEBUG_SYMBOLS):
         assert hasattr(L, name), name
     L.nb_abi_version.restype = C.c_int
-    assert L.nb_abi_version() == 4
+    assert L.nb_abi_version() == 5
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only", "-x", "c",
                     os.path.join(ROOT, "include", "nbody_amd_debug.h")], check=True)
 
@@ -321,3 +352,39 @@ def test_pair_schedule_of_the_symmetric_kernel_on_shapes_no_box_here_can_run(nb)
 
     one_gpu()
     several_gpus()
+
+
+def test_fp32_modes_refuse_an_eps_whose_inverse_cube_overflows(nb):
+    """K1 / K1s evaluate the self pair and the zero-mass padding as d = 0 times G*m*(eps^2)^-1.5: exactly +0 only while that
+    power is finite in fp32 and eps^2 is a normal number.  eps = 1e-15 (eps^2 = 1e-30 -> rinv^3 = inf -> 0 * inf = NaN on every
+    body) passed round 4's `eps^2 > 0` guard; the ABI now refuses eps < 1e-12 — argument checks, no GPU needed."""
+    import ctypes as C
+    c = nb.capi
+    for eps, ok in ((1e-15, False), (9e-13, False), (1e-23, False), (0.0, False), (1.1e-12, True), (1e-3, True)):
+        for prec in (c.NB_F32, c.NB_F32_ACC64):
+            try:
+                c.Context(64, prec, 0, eps=eps).close()
+                refused = False
+            except c.NBodyError as e:
+                refused = e.code == c.NB_ERR_INVALID   # (NB_ERR_NO_DEVICE on a CPU box = the argument was accepted)
+            assert refused == (not ok), (eps, prec)
+        try:
+            c.Sharded(4096, [0], c.NB_F32, eps=eps).close()
+            refused = False
+        except c.NBodyError as e:
+            refused = e.code == c.NB_ERR_INVALID
+        assert refused == (not ok), eps
+    # raw launches carry eps^2 as a float
+    a = c._launch_struct(1, 1, 4096, 0, 4096, 1e-30, 1e-2, vel_ptr=1)
+    assert c.lib().nb_launch_step_f32(C.byref(a), None) == c.NB_ERR_INVALID and "eps2 >= 1e-24" in c.lib().nb_last_error(None).decode()
+    # the fp64 mode takes any eps >= 0 (tiny ones run the kernels that skip the self pair explicitly, like nbody.cc:59)
+    try:
+        c.Context(64, c.NB_F64, 0, eps=1e-15).close()
+    except c.NBodyError as e:
+        assert e.code == c.NB_ERR_NO_DEVICE
+    # unknown nb_config.flags bits are refused; NB_CFG_ORDERED_PAIRS is known
+    cfg = c.NbConfig()
+    c.lib().nb_config_default(C.byref(cfg))
+    cfg.n, cfg.flags = 64, 2
+    h = C.c_void_p()
+    assert c.lib().nb_create(C.byref(h), C.byref(cfg)) == c.NB_ERR_INVALID

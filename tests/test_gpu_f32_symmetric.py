@@ -254,3 +254,105 @@ def test_symmetric_on_a_clustered_system_with_a_wide_mass_range(nb, oracle):
         assert e_sym < (TOL_ACC64 if acc64 else TOL_F32), out
         assert e_sym < 10 * max(e_k1, 3e-8), out  # no worse than the ordered-pair kernel by more than its own noise level
     print("clustered: max err / sum|a_ij|  (K1s, K1)  fp32:", out[False], " fp64-accumulated:", out[True])
+
+
+# ---------------------------------------------------------------- the default 8-rank shapes of the BASELINE configs, on one GPU
+
+def _eight_rank_shares_vs_oracle(nb, oracle, n, acc64, tol):
+    """What eight GPUs compute for ONE step of `n` bodies when they share the unordered pairs (the default of both hosts):
+    rank r = 0..7 runs nb_launch_pair_forces_f32 on the superblocks of its shard — here one after the other on the one GPU —
+    and the reduce-scatter adds the eight partial forces.  NaN-prefilled outputs prove that every rank's launch writes every
+    body; the sum is checked on 24 rows, three from every rank's shard, against the fp64 oracle (samples/nbody.cc:57-73)."""
+    import torch
+    c, syn = nb.capi, nb.synthetic
+    ranks = 8
+    per = n // ranks
+    c.selftest_pair_schedule(n, 256, ranks, acc64)
+    ws_bytes = c.workspace_bytes_shared_pairs_f32(n, ranks, acc64)
+    nb_, wg, sub = c.plan_shared_pairs_f32(n, ranks, acc64)
+    assert nb_ == per // SB and wg >= 1 and sub >= 1
+    pos, _ = syn.body4_f32(n)
+    src = torch.from_numpy(pos).cuda()
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+    dt_acc = torch.float64 if acc64 else torch.float32
+    part = torch.empty((n, 4), dtype=dt_acc, device="cuda")
+    total = torch.zeros((n, 4), dtype=torch.float64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    for r in range(ranks):
+        part.fill_(float("nan"))
+        c.launch_pair_forces_f32(src.data_ptr(), n, r * per, per, syn.EPS ** 2, stream, part.data_ptr(), ws.data_ptr(),
+                                 ws.numel(), acc64=acc64)
+        total += part  # (the reduce-scatter sums in the collective's own order; fp64 here so that the check sees the shares)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(total[:, :3]).all()), "a rank's launch left bodies unwritten"
+    rows = np.array([r * per + off for r in range(ranks) for off in (0, per // 2 + 37 * r + 1, per - 1)])
+    a = total[torch.from_numpy(rows).cuda(), :3].cpu().numpy().T
+    ref, s = _oracle_rows(oracle, syn, pos, rows)
+    err = (np.abs(a - ref).max(axis=0) / s).max()
+    assert err < tol, err
+    return (nb_, wg, sub), ws_bytes, err
+
+
+def test_configs3_eight_rank_shares_against_the_oracle(nb, oracle):
+    """BASELINE configs[3]: N = 2^22 over 8 GPUs, fp32.  128 superblocks per rank, 2 workgroups each, 6.6 GB of slots."""
+    plan, ws_bytes, err = _eight_rank_shares_vs_oracle(nb, oracle, 1 << 22, False, TOL_F32)
+    assert plan == (128, 2, 1) and 6e9 < ws_bytes < 8e9 and err < 2e-7, (plan, ws_bytes, err)
+
+
+@pytest.mark.heavy
+def test_configs4_eight_rank_shares_against_the_oracle(nb, oracle):
+    """BASELINE configs[4]: N = 2^24 over 8 GPUs, fp32 pair math / fp64 sums.  512 superblocks per rank = 103 GB of slots, so
+    every rank's share goes out as two sub-launches of 256 (52 GB), the second adding to the first's partial force.  ~45 s of
+    kernels (an eighth of the step each); `-m "gpu and not heavy"` deselects it."""
+    plan, ws_bytes, err = _eight_rank_shares_vs_oracle(nb, oracle, 1 << 24, True, TOL_ACC64)
+    assert plan == (512, 1, 2) and 50e9 < ws_bytes < 60e9 and err < 2e-7, (plan, ws_bytes, err)
+
+
+# ---------------------------------------------------------------- the context's K1s workspace: lazy, optional, never fatal
+
+def test_context_workspace_is_lazy_optional_and_never_fatal(nb, oracle):
+    """nb_create no longer allocates K1s' pair slots (1.7 GB at N = 2^20, 26 GB at 2^22): the first nb_step / nb_accel does.
+    NB_CFG_ORDERED_PAIRS opts out (K1 for the context's life).  A device that cannot spare the slots makes the context fall
+    back to K1 — said in nb_last_error, no call fails."""
+    import torch
+    c, syn = nb.capi, nb.synthetic
+    n = 1 << 20
+    q, v, m = syn.bodies(n)
+    torch.cuda.synchronize()
+    used = lambda: torch.cuda.mem_get_info(0)[1] - torch.cuda.mem_get_info(0)[0]  # noqa: E731  (device-wide, not torch's)
+    u0 = used()
+    ctx = c.Context(n, c.NB_F32, 0, G=syn.G, eps=syn.EPS, dt=1e-2)
+    ctx.set_state(q, v, m)
+    u1 = used()
+    assert u1 - u0 < 0.6e9, u1 - u0                       # positions x2, velocities, accel scratch, K1's 18 records per body
+    assert ctx.kernel_name() == "nbody_force_sym_f32<false>"   # asks for the slots, like the first step
+    u2 = used()
+    assert 1.2e9 < u2 - u1 < 2.2e9, u2 - u1
+    a_sym = ctx.accel(1)
+    ctx.close()
+    with c.Context(n, c.NB_F32, 0, G=syn.G, eps=syn.EPS, dt=1e-2, ordered_pairs=True) as k1:
+        k1.set_state(q, v, m)
+        assert k1.kernel_name().startswith("nbody_force_f32<")
+        a_k1 = k1.accel(1)
+        assert used() - u0 < 0.6e9
+    rows = np.array([0, 4097, n // 2 + 5, n - 1])
+    pos, _ = syn.body4_f32(n)
+    ref, s = _oracle_rows(oracle, syn, pos, rows)
+    for a in (a_sym, a_k1):
+        assert (np.abs(a[:, rows] - ref).max(axis=0) / s).max() < TOL_F32
+    assert not np.array_equal(a_sym, a_k1)  # two kernels, two summation orders
+    # a GPU with 1 GB to spare: the context is created, steps with K1 and says so
+    free, _ = torch.cuda.mem_get_info(0)
+    ctx = c.Context(n, c.NB_F32, 0, G=syn.G, eps=syn.EPS, dt=1e-2)
+    ctx.set_state(q, v, m)
+    hog = torch.empty(max(0, torch.cuda.mem_get_info(0)[0] - (1 << 30)), dtype=torch.uint8, device="cuda:0")
+    try:
+        assert ctx.kernel_name().startswith("nbody_force_f32<")
+        assert "note:" in ctx.last_error() and "every ordered pair (K1) instead" in ctx.last_error()
+        a_fb = ctx.accel(1)
+    finally:
+        del hog
+        torch.cuda.empty_cache()
+        ctx.close()
+    assert np.array_equal(a_fb, a_k1)  # the fallback IS the ordered-pair context
+    assert free > 0

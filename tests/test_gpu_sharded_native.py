@@ -217,3 +217,76 @@ def test_sharded_host_under_host_asan(nb, args):
     r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert r["gpus"] == int(args[4]) and r["pairs_per_s"] > 1e9
     assert r["kernel"].startswith("nbody_force_sym_f32" if args[0] == "131072" else "nbody_force_f32<")
+
+
+# ---------------------------------------------------------------- bounded waits (nb_sharded_set_deadline)
+
+def test_a_generous_deadline_changes_nothing(nb):
+    """With a deadline the host never blocks inside the runtime: it polls, and keeps at most 16 steps in flight.  40 steps
+    (more than one lap of that ring) of 2 ranks, plain and overlapped, must equal the run without a deadline bit for bit."""
+    c, syn = nb.capi, nb.synthetic
+    n = 16384
+    q, v, m = syn.bodies(n)
+    for overlap in (False, True):
+        out = []
+        for deadline in (0.0, 120.0):
+            with c.Sharded(n, [0, 0], c.NB_F32, G=syn.G, eps=syn.EPS, dt=1e-2, overlap=overlap, exchange="copy",
+                           deadline=deadline) as sh:
+                sh.set_state(q, v, m)
+                sh.step(23)
+                _, kms = sh.step_profiled(17)
+                assert all(k > 0 for k in kms)
+                out.append(sh.get_state())
+        assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+def test_an_expired_deadline_is_an_error_not_a_hang(nb):
+    """The allowance is per awaited step: 0.1 ms for steps of ~12 ms each can only expire.  The call returns NB_ERR_HIP with
+    "timed out", the system refuses every later call (NB_ERR_STATE), and destroying it returns (it abandons what the GPU may
+    still be using instead of blocking in hipFree).  This is what ends a bench leg whose collective never completes."""
+    import time
+    c, syn = nb.capi, nb.synthetic
+    n = 1 << 18
+    q, v, m = syn.bodies(n)
+    sh = c.Sharded(n, [0, 0], c.NB_F32, G=syn.G, eps=syn.EPS, dt=1e-2, exchange="copy")
+    sh.set_state(q, v, m)
+    sh.step(1)  # (first-launch costs out of the way)
+    sh.set_deadline(1e-4)
+    t0 = time.perf_counter()
+    with pytest.raises(c.NBodyError, match="timed out after 0.0001 s") as e:
+        sh.step(20)
+    assert e.value.code == c.NB_ERR_HIP and time.perf_counter() - t0 < 5.0
+    with pytest.raises(c.NBodyError) as e2:
+        sh.step(1)
+    assert e2.value.code == c.NB_ERR_STATE
+    with pytest.raises(c.NBodyError):
+        sh.get_state()
+    t0 = time.perf_counter()
+    sh.close()
+    assert time.perf_counter() - t0 < 5.0
+    # the GPU drains the abandoned steps by itself; a fresh system works
+    with c.Sharded(16384, [0, 0], c.NB_F32, G=syn.G, eps=syn.EPS, dt=1e-2, exchange="copy", deadline=60.0) as ok:
+        qq, vv, mm = syn.bodies(16384)
+        ok.set_state(qq, vv, mm)
+        ok.step(2)
+        assert np.isfinite(ok.get_state()[0]).all()
+
+
+def test_the_unordered_pair_step_is_a_preference_not_a_requirement(nb):
+    """nb_sharded_create on a GPU that cannot spare K1s' memory (here: most of the HBM is taken first) falls back to ordered
+    pairs for every rank — create succeeds, `note` says why — instead of failing."""
+    import torch
+    c, syn = nb.capi, nb.synthetic
+    n = 1 << 21   # one GPU: 6.9 GB of pair slots; two ranks: 3.3 GB + 2 x 32 MB each
+    free, _ = torch.cuda.mem_get_info(0)
+    hog = torch.empty(max(0, free - (5 << 30)), dtype=torch.uint8, device="cuda:0")  # leave 5 GB
+    try:
+        with c.Sharded(n, [0], c.NB_F32, G=syn.G, eps=syn.EPS, dt=1e-2) as sh:
+            assert sh.kernel_name().startswith("nbody_force_f32<") and "ordered pairs (K1) instead" in sh.note
+        with c.Sharded(n, [0, 0], c.NB_F32, G=syn.G, eps=syn.EPS, dt=1e-2, exchange="copy") as sh:
+            assert sh.kernel_name().startswith("nbody_force_f32<") and "3/4" in sh.note
+    finally:
+        del hog
+        torch.cuda.empty_cache()
+    with c.Sharded(n, [0, 0], c.NB_F32, G=syn.G, eps=syn.EPS, dt=1e-2, exchange="copy") as sh:
+        assert sh.kernel_name() == "nbody_force_sym_f32<false>" and sh.note == ""
