@@ -241,6 +241,49 @@ def parity_spot(torch, sysm, n, acc64, compute_kw, rows=64):
             "what": "accel-only launch (same plan as the timed step) on the final positions vs oracle/ fp64 rows"}
 
 
+PEAK_FP64_TFLOPS = 78.6      # MI355X_MICROARCH.md: fp64 vector FMA, half the packed-fp32 rate
+
+
+def other_precision_path(torch, n, device, mode, rows=64, steps=5):
+    """N = 1, after the timed region: the same synthetic system in another arithmetic mode through the plain C-ABI context
+    (nb_create / nb_set_state / nb_step_timed — what INTEGRATION.md binds), `steps` untimed-region steps timed with HIP events
+    on the context's stream, then nb_accel on the state it ended on against `rows` oracle rows.
+      f32acc64  BASELINE configs[4]'s arithmetic: fp32 pair math, fp64 sums, fp64 q,v masters (tolerance 1e-6 of sum|a_ij|)
+      f64       the testcases' arithmetic at large n: K1s-f64, every unordered pair once in fp64 (tolerance 1e-12), priced
+                against the 78.6 TFLOP/s fp64 vector peak."""
+    import numpy as np
+    from nbody_amd import capi, synthetic
+    from oracle import oracle as O
+    prec, tol, peak = {"f32acc64": (capi.NB_F32_ACC64, 1e-6, PEAK_FP32_TFLOPS), "f64": (capi.NB_F64, 1e-12, PEAK_FP64_TFLOPS)}[mode]
+    q, v, m = synthetic.bodies(n)
+    dev = device.index or 0
+    with capi.Context(n, prec, dev, G=synthetic.G, eps=synthetic.EPS, dt=synthetic.DT) as ctx:
+        ctx.set_state(q, v, m)
+        ctx.step(1, 1)
+        ms = ctx.step_timed(2, steps)
+        kernel = ctx.kernel_name() if mode != "f64" else "nbody_force_sym_f64 (K1s-f64: every unordered pair once, fp64) + its reducer"
+        q1, _ = ctx.get_state()
+        a = ctx.accel(2 + steps)
+    idx = [(k * (n // rows) + (k * 37) % (n // rows)) % n for k in range(rows)]
+    idx[0], idx[-1] = 0, n - 1
+    if mode == "f64":
+        qs, ms_ = np.ascontiguousarray(q1), m
+    else:  # the pair loop reads the fp32 copies of the fp64 masters, and G*m rounded once
+        qs = np.ascontiguousarray(q1.astype(np.float32).astype(np.float64))
+        ms_ = (synthetic.G * m).astype(np.float32).astype(np.float64) / synthetic.G
+    worst = 0.0
+    t0 = time.perf_counter()
+    for i in idx:
+        ref, ab = O.accel_rows(qs, ms_, synthetic.G, synthetic.EPS, i, i + 1, want_abs=True, omp=True)
+        worst = max(worst, float(np.abs(a[:, i] - ref[:, 0]).max() / ab[0]))
+    return {"ms_per_step": ms, "frac": FLOP_PER_PAIR * n * (n - 1) / (ms * 1e-3) / 1e12 / peak, "peak": peak,
+            "pairs_per_s": n * (n - 1) / (ms * 1e-3), "bodies": n, "kernel": kernel, "steps": steps, "dtype": mode,
+            "parity": {"rows": rows, "max_err_over_sum_abs": worst, "tol": tol, "ok": bool(worst < tol),
+                       "oracle_s": round(time.perf_counter() - t0, 2)},
+            "what": ("nb_step_timed of a C-ABI context on the same synthetic bodies (HIP events on the context's stream), then "
+                     "nb_accel of the final state vs oracle/ fp64 rows")}
+
+
 def sharded_check(torch, dist, world, rank, device, dev_index, backend):
     """world > 1 only, after the timed region: the same sharded stepper (index shards, tgt_off != 0 launches, in-place
     RCCL all-gather, ping-pong) on a small system, against the UNSHARDED run of the same bodies on rank 0's GPU through
@@ -329,22 +372,135 @@ def child_env(**extra):
     return env
 
 
-def run_bench_child(argv, timeout):
-    """This program again as a bounded child (its own HIP contexts; a hang or crash costs `timeout` seconds and a
-    recorded error, never the parent's measurement).  -> parsed JSON line, or {"error": ...}."""
+def run_process(cmd, timeout, env=None, should_abort=None):
+    """A bounded child in its own session: -> (rc | None on timeout or abort, stdout, stderr).  On timeout the whole process
+    group is killed and what the child had written so far is still returned (a leg prints its line as soon as the timed
+    region closes, so diagnostics that hang afterwards cost the diagnostics, not the measurement).  `should_abort()` is
+    polled twice a second: the ranks of one leg stop together when one of them has failed."""
+    import signal
     import subprocess
+    import tempfile
+    with tempfile.TemporaryFile(mode="w+", dir="/tmp") as fo, tempfile.TemporaryFile(mode="w+", dir="/tmp") as fe:
+        p = subprocess.Popen(cmd, stdout=fo, stderr=fe, text=True, env=env if env is not None else child_env(), cwd=ROOT,
+                             start_new_session=True)
+        t0 = time.perf_counter()
+        rc, note = None, ""
+        while True:
+            rc = p.poll()
+            if rc is not None:
+                break
+            if time.perf_counter() - t0 > timeout:
+                note = ""
+                break
+            if should_abort is not None and should_abort():
+                note = "[stopped: another rank of this leg failed]\n"
+                break
+            time.sleep(0.05 if time.perf_counter() - t0 < 2 else 0.5)
+        if rc is None:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)  # the exact group this call started
+            except OSError:
+                pass
+            try:
+                p.wait(timeout=15)
+            except subprocess.TimeoutExpired:
+                pass
+        fo.seek(0)
+        fe.seek(0)
+        return rc, fo.read(), note + fe.read()
+
+
+def last_json_line(text):
+    for ln in reversed([ln for ln in text.splitlines() if ln.startswith("{")]):
+        try:
+            return json.loads(ln)
+        except ValueError:
+            continue
+    return None
+
+
+def leg_record(name, rc, out, err, timeout, seconds, what=""):
+    """What one leg left behind: its JSON line (the last complete one) and/or how it ended."""
+    line = last_json_line(out)
+    rec = {"name": name, "seconds": round(seconds, 1)}
+    if what:
+        rec["what"] = what
+    if rc is None and "[stopped: another rank of this leg failed]" in err:
+        rec["error"] = "stopped: another rank of this leg failed"
+    elif rc is None:
+        rec["timeout"] = f"killed after {timeout:.0f} s"
+    elif rc != 0:
+        rec["error"] = f"rc={rc}"
+    if rc != 0 or line is None:
+        tail = [ln for ln in err.strip().splitlines() if ln.strip()][-6:]
+        rec["stderr_tail"] = " | ".join(tail)[-600:]
+        if line is None and "error" not in rec and "timeout" not in rec:
+            rec["error"] = "no JSON line"
+    rec["ok"] = line is not None and "value" in line  # a line from the timed region counts even if the diagnostics died
+    if rec["ok"] and (rc != 0 or line.get("stage") != "complete"):
+        rec["diagnostics_incomplete"] = True
+    return rec, line
+
+
+def run_ladder(legs, runner, budget_s, leg_timeout_s, log=None, sync=None):
+    """The measured step of a multi-GPU line, as a LADDER of fresh child processes: legs in order until one yields a line;
+    a leg that fails or hangs is recorded ({name, error | timeout, stderr_tail}) and the next form of the same step is tried
+    — shared pairs over RCCL, then north_star's literal scheme (ordered pairs, all-gather only), then the copy-engine
+    exchange.  `runner(leg, timeout) -> (rc | None, stdout, stderr)`.  -> (records, index of the leg whose line counts | None,
+    that line | None).  Never raises for a failing leg: the first real 8-GPU contact must come back with a JSON line.
+    `sync(x) -> x of rank 0`: when several parent processes walk the ladder together (one per rank under torch.distributed.run)
+    every decision that depends on a clock is rank 0's."""
+    t0 = time.perf_counter()
+    records, chosen, line = [], None, None
+    for i, leg in enumerate(legs):
+        if leg.get("skip"):
+            records.append({"name": leg["name"], "skipped": leg["skip"], "ok": False})
+            continue
+        left = budget_s - (time.perf_counter() - t0)
+        if sync:
+            left = sync(left)
+        if left < min(20.0, leg_timeout_s):
+            records.append({"name": leg["name"], "skipped": "out of time budget", "ok": False})
+            continue
+        timeout = min(leg_timeout_s, left)
+        t1 = time.perf_counter()
+        if log:
+            log(f"leg {i} {leg['name']}: starting (limit {timeout:.0f} s)")
+        try:
+            rc, out, err = runner(leg, timeout)
+        except Exception as e:  # noqa: BLE001  (could not even start the child)
+            rc, out, err = -1, "", f"{type(e).__name__}: {e}"
+        rec, ln = leg_record(leg["name"], rc, out, err, timeout, time.perf_counter() - t1, leg.get("what", ""))
+        records.append(rec)
+        if log:
+            log(f"leg {i} {leg['name']}: " + ("ok" if rec["ok"] else rec.get("error") or rec.get("timeout") or "failed"))
+        if rec["ok"]:
+            chosen, line = i, ln
+            break
+    return records, chosen, line
+
+
+def summarise_leg_line(r):
+    """The part of another leg's line worth keeping beside the one that counts."""
+    if not r:
+        return None
+    keep = {k: r[k] for k in ("value", "ms_per_step", "steps", "kernel_ms_per_rank", "non_kernel_ms_per_step", "exchange", "overlap",
+                              "host", "pairs") if k in r}
+    if "roofline" in r:
+        keep["kernel"], keep["roofline_frac"] = r["roofline"].get("kernel"), r["roofline"].get("frac")
+    if "parity_spot" in r:
+        keep["parity_spot_ok"] = r["parity_spot"].get("ok")
+    return keep
+
+
+def probe_device_count(timeout=120):
+    """GPUs this box shows, asked of a throw-away child (the orchestrating parent never initialises HIP)."""
+    rc, out, _ = run_process([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import nbody_amd; "
+                              "from nbody_amd import capi; print(capi.device_count())" % ROOT], timeout)
     try:
-        p = subprocess.run([sys.executable, os.path.abspath(__file__)] + list(argv), stdout=subprocess.PIPE,
-                           stderr=subprocess.PIPE, text=True, timeout=timeout, env=child_env(), cwd=ROOT)
-    except subprocess.TimeoutExpired:
-        return {"error": f"timeout after {timeout} s", "argv": list(argv)}
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    if p.returncode != 0 or not lines:
-        return {"error": f"rc={p.returncode}", "stderr_tail": p.stderr[-400:], "argv": list(argv)}
-    try:
-        return json.loads(lines[-1])
-    except ValueError as e:
-        return {"error": f"unparsable line: {e}", "argv": list(argv)}
+        return int(out.strip().splitlines()[-1]) if rc == 0 else 0
+    except (ValueError, IndexError):
+        return 0
 
 
 def replicas_check(devices, cases=("b1024", "b200"), timeout=60):
@@ -417,6 +573,11 @@ def roofline_block(achieved, kname, k_ms, tpl, jsp, wgs, acc64, traffic=None, tr
             "pair_evaluation": "each unordered pair once, both bodies served" if sym else "every ordered pair",
             "reduce_share_of_span": reduce_share,
             "targets_per_lane": tpl, "j_split": jsp, "wg_size": wgs, "flop_per_pair": FLOP_PER_PAIR,
+            # flops the hardware executes per COUNTED (ordered) interaction: K1s serves two of them with one evaluation of
+            # 3 sub + 6 r2 + 1 rsq + 2 cube + 2 scale + 12 accumulate = 26 -> 13; K1 executes the convention's 20 itself
+            # (3 + 6 + 1 rsq + 3 + 6 = 19 ops, counted as 20 like everyone since GPU Gems 3).  `frac` uses flop_per_pair
+            "flop_per_pair_executed": 13 if sym else 20,
+            "frac_executed": achieved / PEAK_FP32_TFLOPS * (13 if sym else 20) / FLOP_PER_PAIR,
             "issue_ceiling_frac": ceiling,
             "frac_of_issue_ceiling": achieved / PEAK_FP32_TFLOPS / ceiling,
             "issue_ceiling_detail": detail,
@@ -433,12 +594,26 @@ def workload_config(n, world, how):
             "parallelism": how if world > 1 else "single GPU"}
 
 
+def native_parallelism(P, sym, exchange):
+    """config.parallelism of a native-host line, from what actually ran."""
+    coll = {"rccl": ("ncclReduceScatter", "in-place ncclAllGather"),
+            "copy": ("copy-engine reduce-scatter (hipMemcpyPeerAsync pulls + ordered sum)", "copy-engine all-gather (hipMemcpyPeerAsync)"),
+            "copy-one-gpu": ("same-device copy reduce-scatter (all ranks on GPU 0: rehearsal)",
+                             "same-device copy all-gather (all ranks on GPU 0: rehearsal)")}[exchange]
+    return (f"index-sharded x{P}, one process, "
+            + (f"unordered pairs shared by the GPUs, 1 {coll[0]} of partial forces + " if sym else "")
+            + f"1 {coll[1]} of float4 positions/step")
+
+
 def main_native(args):
-    """`python3 bench.py --gpus P` typed as is (no launcher): the C-ABI host.  ONE process drives the P GPUs through
-    nb_sharded_* (csrc/nbody_sharded.cpp): per step and GPU one force + fused kick-drift launch sequence on the GPU's own
-    stream and ONE in-place ncclAllGather(sendbuff = recvbuff + r*4N/P) — RCCL over xGMI, ncclCommInitAll, no torch, no
-    launcher.  --exchange copy = the all-gather as peer copies on the copy engines; copy-one-gpu = the same with every rank
-    on device 0 (rehearsal of the whole P > 1 host on a one-GPU box; the ranks then share the chip)."""
+    """The C-ABI host: ONE process drives the P GPUs through nb_sharded_* (csrc/nbody_sharded.cpp): per step and GPU its share
+    of the unordered pairs (K1s) + ONE ncclReduceScatter of partial forces + kick-drift — or, with --ordered-pairs, every
+    ordered pair of its own targets (K1) — and ONE in-place ncclAllGather(sendbuff = recvbuff + r*4N/P) of the positions:
+    RCCL over xGMI, ncclCommInitAll, no torch, no launcher.  --exchange copy = both collectives as peer copies on the copy
+    engines; copy-one-gpu = the same with every rank on device 0 (rehearsal of the whole P > 1 host on a one-GPU box; the ranks
+    then share the chip).  Runs as a LEG of `bench.py --gpus P` (a bounded child of the orchestrating parent, see
+    orchestrate_native), or directly with --host native.  Every wait is bounded (nb_sharded_set_deadline): a collective that
+    never completes ends this process with a message and rc != 0 instead of hanging it."""
     import numpy as np
     import nbody_amd  # noqa: F401
     from nbody_amd import capi, synthetic
@@ -457,7 +632,7 @@ def main_native(args):
     kw = dict(G=synthetic.G, eps=synthetic.EPS, dt=synthetic.DT)
     try:
         sh = capi.Sharded(n, devices, prec, overlap=args.overlap, exchange="rccl" if exchange == "rccl" else "copy",
-                          ordered_pairs=args.ordered_pairs, **kw)
+                          ordered_pairs=args.ordered_pairs, deadline=args.deadline, **kw)
     except capi.NBodyError as e:  # no GPU (NB_ERR_NO_DEVICE), fewer than P GPUs, RCCL missing: fail loudly, no fallback
         raise SystemExit(f"bench.py --gpus {P} (native host, devices {devices}): {e}")
     q, v, m = synthetic.bodies(n)
@@ -504,14 +679,13 @@ def main_native(args):
         "vs_baseline": None,
         "dtype": "f32" if not acc64 else "f32 pair math / f64 accumulate",
         "data": "synthetic",
-        "config": workload_config(n, P, f"index-sharded x{P}, one process, "
-                                  + (f"unordered pairs shared by the GPUs, 1 {'ncclReduceScatter' if exchange == 'rccl' else 'copy-engine reduce-scatter'} "
-                                     f"of partial forces + " if sym else "")
-                                  + f"1 in-place {'ncclAllGather' if exchange == 'rccl' else 'copy-engine all-gather'} of float4 positions/step"),
+        "config": workload_config(n, P, native_parallelism(P, sym, exchange)),
         "host": "native",
         "host_detail": "nb_sharded_* (csrc/nbody_sharded.cpp): ONE process, one stream per GPU, "
-                       + ("ncclCommInitAll + one in-place ncclAllGather per GPU per step (RCCL over xGMI)" if exchange == "rccl"
-                          else "P-1 peer copies per GPU per step on the copy engines (NB_SHARDED_COPY_EXCHANGE)"),
+                       + ("ncclCommInitAll; per GPU and step " + ("one ncclReduceScatter of partial forces + " if sym else "")
+                          + "one in-place ncclAllGather (RCCL over xGMI)" if exchange == "rccl"
+                          else "P-1 peer copies per GPU per step and collective on the copy engines (NB_SHARDED_COPY_EXCHANGE)")
+                       + f"; every wait bounded at {args.deadline:g} s per step (nb_sharded_set_deadline)",
         "exchange": exchange,
         "overlap": bool(args.overlap),
         "pairs": ("every unordered pair once, shared by the GPUs (K1s); every GPU's partial force on all bodies is "
@@ -526,8 +700,15 @@ def main_native(args):
         "kernel_ms_per_rank": kern,
         "non_kernel_ms_per_step": wall / steps_done * 1e3 - k_ms,
     }
+    if sh.note:
+        out["shared_pairs_note"] = sh.note
+    if exchange == "copy-one-gpu":
+        out["rehearsal"] = f"all {P} ranks on GPU 0 (they share the chip): the P > 1 host logic, not a {P}-GPU measurement"
     out["roofline"]["kernel_ms_detail"] = ("slowest rank's mean per step, HIP events on each rank's own compute stream "
                                            "around its launch sequence (nb_sharded_step_profiled); all ranks in kernel_ms_per_rank")
+    if args.leg_child:  # the measurement is safe with the parent from here on, whatever the checks below do
+        out["stage"] = "timed_region"
+        emit(json.dumps(with_wall(out)))
     # ---- untimed: the line carries its own proof
     if not args.no_parity_spot:
         try:
@@ -541,14 +722,17 @@ def main_native(args):
             del q0, v0, v1, q32
         except Exception as e:  # noqa: BLE001
             out["parity_spot"] = {"ok": False, "error": f"{type(e).__name__}: {e}"}
-    sh.close()
+    try:
+        sh.close()
+    except Exception as e:  # noqa: BLE001
+        out.setdefault("diagnostics_errors", []).append(f"close: {type(e).__name__}: {e}")
     if not args.no_diagnostics:
         # agreement with the unsharded stepper on a small system (the oracle check is parity_spot above)
         try:
             nn, steps, dt = 32768, 3, 1e-2
             q, v, mm = synthetic.bodies(nn)
             with capi.Sharded(nn, devices, capi.NB_F32, G=synthetic.G, eps=synthetic.EPS, dt=dt, overlap=args.overlap,
-                              exchange="rccl" if exchange == "rccl" else "copy") as s2:
+                              exchange="rccl" if exchange == "rccl" else "copy", deadline=args.deadline) as s2:
                 s2.set_state(q, v, mm)
                 s2.step(steps)
                 q2, _ = s2.get_state()
@@ -561,29 +745,282 @@ def main_native(args):
                                     "max_displacement": moved, "ok": bool(diff < 5e-7 and moved > 1e-6)}
         except Exception as e:  # noqa: BLE001
             out["sharded_check"] = {"ok": False, "error": f"{type(e).__name__}: {e}"}
-        # the other settings of the same run, each as a bounded child: overlap toggled, the other exchange
-        base = ["--gpus", str(P), "--bodies", str(n), "--precision", args.precision, "--steps", str(min(5, max(2, args.steps))),
-                "--warmup", "1", "--no-diagnostics", "--no-parity-spot"]
-        keep = (["--overlap"] if args.overlap else []) + (["--ordered-pairs"] if args.ordered_pairs else [])
-        ab = {}
-        for name, extra in (("overlap_" + ("off" if args.overlap else "on"), ["--exchange", exchange] + ([] if args.overlap else ["--overlap"])),
-                            ("exchange_" + ("copy" if exchange == "rccl" else "rccl"),
-                             ["--exchange", "copy" if exchange == "rccl" else "rccl"] + keep),
-                            ("pairs_" + ("unordered" if args.ordered_pairs else "ordered"),
-                             ["--exchange", exchange] + (["--overlap"] if args.overlap else []) + ([] if args.ordered_pairs else ["--ordered-pairs"]))):
-            if name == "exchange_rccl" and exchange == "copy-one-gpu":
-                continue  # RCCL takes one rank per GPU
-            if name.startswith("overlap") and per % 256:
-                continue
-            r = run_bench_child(base + extra, timeout=240)
-            ab[name] = ({"ms_per_step": r["ms_per_step"], "kernel_ms_per_rank": r.get("kernel_ms_per_rank"),
-                         "non_kernel_ms_per_step": r.get("non_kernel_ms_per_step"),
-                         "kernel": r.get("roofline", {}).get("kernel")} if "error" not in r else r)
-        out["variants"] = {"this_run": {"ms_per_step": out["ms_per_step"], "overlap": bool(args.overlap), "exchange": exchange,
-                                        "kernel": kname},
-                           **ab, "note": "same system, few steps, each variant its own child process after the timed region"}
-        out["replicas"] = replicas_check(devices)
+    out["stage"] = "complete"
     emit(json.dumps(with_wall(out)))
+
+
+# ---------------------------------------------------------------- `--gpus P`: the measured step as a ladder of bounded children
+
+def passthrough_args(args, steps=None, diagnostics=True, parity=None):
+    """What every leg child of this run inherits."""
+    parity = diagnostics if parity is None else parity
+    a = ["--gpus", str(args.gpus), "--bodies", str(args.bodies), "--precision", args.precision,
+         "--steps", str(steps if steps is not None else args.steps), "--warmup", str(args.warmup if steps is None else 1),
+         "--deadline", str(args.deadline), "--leg-child"]
+    if args.lib:
+        a += ["--lib", args.lib]
+    if steps is None:
+        if args.report_every:
+            a += ["--report-every", str(args.report_every)]
+        if args.time_box:
+            a += ["--time-box", str(args.time_box)]
+    if args.no_parity_spot or not parity:
+        a += ["--no-parity-spot"]
+    if args.no_diagnostics or not diagnostics:
+        a += ["--no-diagnostics"]
+    return a
+
+
+def native_legs(args, ndev):
+    """The ladder of the native host, the request first: (exchange, ordered pairs).  Default order: shared pairs over RCCL
+    (reduce-scatter + all-gather), north_star's literal scheme (ordered pairs, ONE RCCL all-gather), the copy-engine exchange
+    (no RCCL at all: shared, then ordered).  A box with fewer than P GPUs can only rehearse: the copy exchange with every rank
+    on GPU 0 (said in the line: `rehearsal`)."""
+    P = args.gpus
+    req = (args.exchange or "rccl", bool(args.ordered_pairs or args.overlap))
+    if req[0] not in ("rccl", "copy", "copy-one-gpu"):
+        raise SystemExit(f"--exchange {req[0]}: the native host takes rccl, copy or copy-one-gpu "
+                         f"(in_place/staged/ring belong to the torch host: launch with torch.distributed.run)")
+    order = [req]
+    if req[0] != "copy-one-gpu":
+        order += [x for x in (("rccl", False), ("rccl", True), ("copy", False), ("copy", True)) if x != req and not (args.overlap and not x[1])]
+    if ndev < P or req[0] == "copy-one-gpu":
+        order += [x for x in (("copy-one-gpu", False), ("copy-one-gpu", True)) if x not in order and not (args.overlap and not x[1])]
+    legs = []
+    for k, (ex, ordered) in enumerate(order):
+        name = ("ordered_pairs" if ordered else "shared_pairs") + "_" + ex.replace("-", "_") + ("_overlap" if args.overlap else "")
+        argv = ["--host", "native", "--exchange", ex] + (["--ordered-pairs"] if ordered else []) + (["--overlap"] if args.overlap else [])
+        what = {"rccl": "RCCL: " + ("in-place all-gather of positions only (north_star's scheme)" if ordered else
+                                    "reduce-scatter of partial forces + in-place all-gather of positions"),
+                "copy": "copy engines (hipMemcpyPeerAsync), no RCCL", "copy-one-gpu": f"all {P} ranks on GPU 0 (rehearsal)"}[ex]
+        leg = {"name": name, "argv": argv, "what": ("every ordered pair of a GPU's own targets (K1); " if ordered else
+                                                   "the GPUs share the unordered pairs (K1s); ") + what, "exchange": ex, "ordered": ordered}
+        if k > 0 and ex != "copy-one-gpu" and ndev < P:
+            leg["skip"] = f"needs {P} GPUs, this box shows {ndev}"
+        legs.append(leg)
+    return legs
+
+
+def failed_line(args, records, host):
+    """No leg produced a measurement: still ONE JSON line, saying what was tried (value null, rc 1)."""
+    return {"metric": "body-pair interactions/sec", "value": None, "unit": "pairs/s", "n_gpus": args.gpus, "steps": 0,
+            "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32" if args.precision == "f32" else "f32 pair math / f64 accumulate", "data": "synthetic",
+            "config": workload_config(args.bodies, args.gpus, "no leg of the ladder completed"), "host": host,
+            "error": "every leg of the ladder failed", "legs": records}
+
+
+def finish_ladder_line(args, line, records, chosen, legs, extras, replicas):
+    line["leg"] = legs[chosen]["name"]
+    line["legs"] = records
+    line["legs_note"] = ("the measured step ran as a ladder of bounded fresh child processes; `value`, `ms_per_step` and `roofline` "
+                         "are those of leg `%s`, the first that completed" % line["leg"]
+                         + ("" if not any(not r.get("ok") and "skipped" not in r for r in records[:len(records)]) else
+                            "; legs before it failed or timed out and are recorded with their error"))
+    if extras:
+        line["variants"] = dict(extras, note="the other forms of the same step, each its own bounded child after the measured leg")
+    if replicas is not None:
+        line["replicas"] = replicas
+    line.pop("stage", None)
+    line["wall_s"]["process"] = round(time.perf_counter() - _T0, 2)
+    line["wall_s"]["note"] = ("process = the orchestrating parent: device probe, every leg of the ladder (each a fresh child: imports, "
+                              "set-up, warm-up, its timed region, its checks), variants, replicas; timed_region = the K steps "
+                              "`value` comes from, inside the chosen leg")
+    return line
+
+
+def orchestrate_native(args):
+    """`python3 bench.py --gpus P` typed as is (no launcher — the reference is one command on its GPUs too, hw5.cu:618).  THIS
+    process never initialises HIP: it walks the ladder of native_legs(), each leg a fresh bounded child that drives the P GPUs
+    through the C-ABI host, and prints the line of the first leg that completes with the failures before it recorded —
+    a refused or wedged ncclReduceScatter costs its leg, not the line.  Then, untimed and bounded: the other legs as
+    `variants`, the overlap toggle, and the reference's own multi-GPU mode (`replicas`)."""
+    t0 = time.perf_counter()
+    log = lambda msg: print(f"[bench] {msg}", file=sys.stderr, flush=True)  # noqa: E731
+    if args.resume or args.checkpoint or args.conservation or args.dump_rows:
+        raise SystemExit("--resume/--checkpoint/--conservation/--dump-rows: single rank or the torch host")
+    ndev = args.gpus if args.leg_program else probe_device_count()  # (a test's stand-in legs bring their own "devices")
+    if ndev <= 0:  # no usable GPU at all: fail loudly, with the library's own words, no ladder (there is no CPU path)
+        rc, out, err = run_process([sys.executable, os.path.abspath(__file__)] + passthrough_args(args) +
+                                   ["--host", "native", "--exchange", args.exchange or "rccl"], 300)
+        sys.stderr.write(err)
+        raise SystemExit(rc if rc else 1)
+    legs = native_legs(args, ndev)
+    program = args.leg_program.split() if args.leg_program else [sys.executable, os.path.abspath(__file__)]
+
+    def runner(leg, timeout, steps=None, diagnostics=True):
+        return run_process(program + passthrough_args(args, steps, diagnostics) + leg["argv"], timeout)
+
+    records, chosen, line = run_ladder(legs, runner, args.legs_budget, args.leg_timeout, log)
+    if line is None:
+        emit(json.dumps(failed_line(args, records, "native")))
+        raise SystemExit(1)
+    extras, replicas = {}, None
+    if not args.no_diagnostics:
+        k_ab = min(5, max(2, args.steps))
+        win = legs[chosen]
+        todo = [lg for lg in legs[chosen + 1:] if not lg.get("skip")]
+        if not args.overlap and args.bodies // args.gpus % 256 == 0:  # the two-phase step that hides the all-gather (ordered pairs)
+            todo.append({"name": "ordered_pairs_" + win["exchange"].replace("-", "_") + "_overlap",
+                         "argv": ["--host", "native", "--exchange", win["exchange"], "--ordered-pairs", "--overlap"]})
+        for lg in todo:
+            if time.perf_counter() - t0 > args.legs_budget - 60:
+                extras[lg["name"]] = {"skipped": "out of time budget"}
+                continue
+            t1 = time.perf_counter()
+            rc, out, err = runner(lg, min(args.leg_timeout, 180), steps=k_ab, diagnostics=False)
+            rec, ln = leg_record(lg["name"], rc, out, err, min(args.leg_timeout, 180), time.perf_counter() - t1)
+            extras[lg["name"]] = summarise_leg_line(ln) if rec["ok"] else {k: rec[k] for k in ("error", "timeout", "stderr_tail") if k in rec}
+        replicas = replicas_check([0, 0] if legs[chosen]["exchange"] == "copy-one-gpu" else list(range(args.gpus)))
+    emit(json.dumps(finish_ladder_line(args, line, records, chosen, legs, extras, replicas)))
+
+
+def torch_legs(args, world, ndev):
+    """The ladder under torch.distributed.run (one parent per rank, each leg = one fresh child per rank forming its own process
+    group on a fresh port): the ranks share the unordered pairs (reduce_scatter_tensor + all_gather_into_tensor), then
+    north_star's literal scheme (ordered pairs, all-gather only), then — no RCCL at all — the native C-ABI host with the
+    copy-engine exchange, run by rank 0 alone while the other parents wait on the host."""
+    req_ordered = bool(args.ordered_pairs or args.overlap or args.exchange == "ring")
+    common = ["--backend", args.backend] + (["--single-device"] if args.single_device else []) + \
+             (["--exchange", args.exchange] if args.exchange else []) + (["--overlap"] if args.overlap else [])
+    coll = {"nccl": "RCCL", "gloo": "gloo (rehearsal)"}.get(args.backend, args.backend)
+    legs = []
+    for ordered in ([False, True] if not req_ordered else [True]):
+        name = ("ordered_pairs" if ordered else "shared_pairs") + "_" + args.backend + \
+               ("_ring" if args.exchange == "ring" else "") + ("_overlap" if args.overlap else "")
+        legs.append({"name": name, "host": "torch", "argv": common + (["--ordered-pairs"] if ordered else []), "ordered": ordered,
+                     "what": f"one process per GPU, torch.distributed: " + (f"ordered pairs (K1), {coll} all-gather of positions only "
+                             "(north_star's scheme)" if ordered else f"the ranks share the unordered pairs (K1s), {coll} reduce-scatter of "
+                             "partial forces + all-gather of positions")})
+    if args.exchange != "ring":
+        ex = "copy-one-gpu" if (args.single_device or ndev < world) else "copy"
+        for ordered in ([False, True] if not req_ordered else [True]):
+            legs.append({"name": "native_" + ("ordered_pairs" if ordered else "shared_pairs") + "_" + ex.replace("-", "_") +
+                                 ("_overlap" if args.overlap else ""), "host": "native", "exchange": ex, "ordered": ordered,
+                         "argv": ["--host", "native", "--exchange", ex] + (["--ordered-pairs"] if ordered else []) +
+                                 (["--overlap"] if args.overlap else []),
+                         "what": "the C-ABI host (ONE process for all GPUs, run by rank 0), copy-engine exchange: no RCCL involved"})
+    return legs
+
+
+def orchestrate_torch(args, world):
+    """`python -m torch.distributed.run --nproc-per-node P bench.py --gpus P` (the driver's form).  Every launched process is a
+    PARENT that never initialises HIP; the parents keep in step over a host-side gloo group (the launcher's store) and walk
+    the ladder of torch_legs() together: for every leg each parent starts ONE fresh child — its rank of the leg, on a fresh
+    rendezvous port — bounded by the leg's time limit, and stops it early when another rank's child has failed.  Rank 0 prints
+    the line of the first leg that completed, with the legs before it recorded."""
+    import datetime
+    import socket
+
+    import torch.distributed as dist
+    t0 = time.perf_counter()
+    rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the torch host runs one rank per GPU under "
+                         f"torch.distributed.run (or type the command without a launcher for the native host)")
+    if args.exchange in ("rccl", "copy", "copy-one-gpu"):
+        raise SystemExit(f"--exchange {args.exchange} belongs to the native host (run without a launcher)")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=max(1800.0, 4 * args.legs_budget)))
+    log = (lambda msg: print(f"[bench] {msg}", file=sys.stderr, flush=True)) if rank == 0 else None
+
+    def bcast(x):
+        box = [x]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    def free_port():
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            return sk.getsockname()[1]
+
+    try:
+        store = dist.distributed_c10d._get_default_store()
+        store.check(["nb_probe"])
+    except Exception:  # noqa: BLE001  (no early stop then: every rank waits for its own time limit)
+        store = None
+    ndev = bcast((args.gpus if args.leg_program else probe_device_count()) if rank == 0 else None)
+    legs = torch_legs(args, world, ndev)
+    program = args.leg_program.split() if args.leg_program else [sys.executable, os.path.abspath(__file__)]
+    serial = [0]
+
+    def runner(leg, timeout, steps=None, diagnostics=True, parity=None):
+        serial[0] += 1
+        tag = f"nb_leg_failed_{serial[0]}"
+        timeout = bcast(timeout)
+        argv = program + passthrough_args(args, steps, diagnostics, parity) + leg["argv"]
+        if leg["host"] == "native":  # rank 0 alone drives all GPUs; the other parents wait here, their GPUs idle
+            return bcast(run_process(argv, timeout) if rank == 0 else None)
+        port = bcast(free_port() if rank == 0 else None)
+        env = child_env(RANK=str(rank), LOCAL_RANK=os.environ.get("LOCAL_RANK", str(rank)), WORLD_SIZE=str(world),
+                        LOCAL_WORLD_SIZE=os.environ.get("LOCAL_WORLD_SIZE", str(world)),
+                        MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=str(port))
+
+        def others_failed():
+            try:
+                return bool(store is not None and store.check([tag]))
+            except Exception:  # noqa: BLE001
+                return False
+
+        rc, out, err = run_process(argv, timeout, env, others_failed)
+        if rc != 0 and store is not None:
+            try:
+                store.set(tag, str(rank))
+            except Exception:  # noqa: BLE001
+                pass
+        every = [None] * world
+        dist.all_gather_object(every, (rc, " | ".join(ln for ln in err.strip().splitlines()[-4:] if ln.strip())[-400:]))
+        if rank == 0:
+            bad = [f"rank {r}: " + ("killed at the time limit / stopped" if c is None else f"rc={c}") + (f" ({tail})" if tail else "")
+                   for r, (c, tail) in enumerate(every) if r > 0 and c != 0]
+            if bad:
+                err = err + "\n" + "\n".join(bad)
+                if rc == 0 and last_json_line(out) is None:
+                    rc = -1
+        return bcast((rc, out, err) if rank == 0 else None)
+
+    records, chosen, line = run_ladder(legs, runner, args.legs_budget, args.leg_timeout, log, sync=bcast)
+    if line is None:
+        if rank == 0:
+            emit(json.dumps(failed_line(args, records, "torch")))
+        dist.barrier()
+        dist.destroy_process_group()
+        raise SystemExit(1)
+    extras, replicas = {}, None
+    if not args.no_diagnostics:
+        k_ab = min(5, max(2, args.steps))
+        todo = list(legs[chosen + 1:])
+        if legs[chosen]["host"] == "torch" and args.exchange != "ring":
+            # the same workload through the C-ABI host over RCCL (what `python3 bench.py --gpus P` measures), with its oracle check
+            ex = "copy-one-gpu" if (args.single_device or ndev < world) else "rccl"
+            todo.insert(0, {"name": "native_host", "host": "native", "parity": True, "steps": min(10, max(2, args.steps)),
+                            "argv": ["--host", "native", "--exchange", ex]})
+        for lg in todo:
+            if bcast(time.perf_counter() - t0 > args.legs_budget - 60):
+                extras[lg["name"]] = {"skipped": "out of time budget"}
+                continue
+            t1 = time.perf_counter()
+            limit = min(args.leg_timeout, 180)
+            rc, out, err = runner(lg, limit, steps=lg.get("steps", k_ab), diagnostics=False, parity=lg.get("parity", False))
+            rec, ln = leg_record(lg["name"], rc, out, err, limit, time.perf_counter() - t1)
+            if rec["ok"] and lg["name"] == "native_host":
+                keep = ("value", "ms_per_step", "n_gpus", "steps", "host", "exchange", "ranks", "kernel_ms_per_rank",
+                        "non_kernel_ms_per_step", "parity_spot")
+                extras[lg["name"]] = dict({k: ln[k] for k in keep if k in ln}, roofline_frac=ln.get("roofline", {}).get("frac"),
+                                          what="the same workload through the C-ABI host (nb_sharded_*: ONE process, ncclCommInitAll), "
+                                               "run by rank 0 as a bounded child after the measured leg while the other ranks wait")
+            else:
+                extras[lg["name"]] = summarise_leg_line(ln) if rec["ok"] else {k: rec[k] for k in ("error", "timeout", "stderr_tail") if k in rec}
+        if rank == 0:
+            replicas = replicas_check([0, 0] if (args.single_device or ndev < 2) else list(range(world)))
+    if rank == 0:
+        native = extras.pop("native_host", None)
+        line = finish_ladder_line(args, line, records, chosen, legs, extras, replicas)
+        if native is not None:
+            line["native_host"] = native
+        emit(json.dumps(line))
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def conservation(torch, sysm, n, sample=1024):
@@ -662,10 +1099,27 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; gloo + --single-device rehearses "
                     "the multi-rank path on a one-GPU box (RCCL refuses two ranks on one device)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--deadline", type=float, default=120.0, help="multi-GPU: seconds one step (kernels + exchange) may take once "
+                    "the host waits for it before the leg gives up with an error (native host: nb_sharded_set_deadline; torch "
+                    "host: the collective timeout of the process group).  Raise it for systems whose step is longer")
+    ap.add_argument("--leg-timeout", type=float, default=240.0, help="multi-GPU: wall-clock limit of one leg of the ladder (a "
+                    "fresh child: imports, communicator, upload, warm-up, the timed steps, its checks)")
+    ap.add_argument("--legs-budget", type=float, default=480.0, help="multi-GPU: wall-clock budget of the whole ladder plus the "
+                    "untimed variants after it")
+    ap.add_argument("--leg-child", action="store_true", help=argparse.SUPPRESS)    # this process IS a leg (started by the parent)
+    ap.add_argument("--leg-program", default="", help=argparse.SUPPRESS)           # tests: run this instead of bench.py as a leg
     args = ap.parse_args()
     only_the_json_line_on_stdout()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and not args.leg_child:
+        # the measured step of a multi-GPU line runs in bounded fresh children; this process orchestrates and never touches HIP
+        if args.time_box or args.steps > 200:  # sustained runs: a leg may take as long as the run is asked to
+            args.leg_timeout = max(args.leg_timeout, 2 * args.time_box + 600)
+            args.legs_budget = max(args.legs_budget, 2 * args.leg_timeout)
+        return orchestrate_torch(args, world) if world > 1 else orchestrate_native(args)
+    if world > 1 and args.host == "native":
+        raise SystemExit("--host native is ONE process for all GPUs: run it without a launcher")
     if args.host == "native" or (args.host == "auto" and args.gpus > 1 and world == 1):
         return main_native(args)
     if args.exchange in ("rccl", "copy", "copy-one-gpu"):
@@ -694,7 +1148,7 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
-        patience = datetime.timedelta(seconds=300)  # a wedged collective ends the run instead of hanging it
+        patience = datetime.timedelta(seconds=max(60.0, args.deadline))  # a wedged collective ends the leg instead of hanging it
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=device, timeout=patience)
         else:
@@ -781,10 +1235,90 @@ def main():
         vd = (sysm.vel64 if acc64 else sysm.vel)[idx].cpu().numpy()
         np.savez(args.dump_rows, idx=idx.cpu().numpy(), q=qd, v=vd, step=first_step + args.warmup + steps_done)
 
-    # --- untimed diagnostics (after the timed region; not part of `value`)
-    exchange_ms = check = overlap_ab = spot = lds = sgpr = native = replicas = None
+    # --- who ran: every rank's GPU, read by the rank itself, and every rank's own kernel time (host-side gloo group)
     kern_per_rank = rank_ids = None
     diag_errors = []
+    if world > 1:
+        try:
+            pr = torch.cuda.get_device_properties(dev_index)
+            me = {"rank": rank, "device": dev_index, "name": pr.name, "uuid": str(getattr(pr, "uuid", "")),
+                  "pci_bus_id": f"{getattr(pr, 'pci_domain_id', 0):04x}:{getattr(pr, 'pci_bus_id', 0):02x}:"
+                                f"{getattr(pr, 'pci_device_id', 0):02x}.0",
+                  "compute_units": pr.multi_processor_count, "first_target": lo, "targets": hi - lo, "kernel_ms": k_ms}
+            ids = [None] * world
+            dist.all_gather_object(ids, me, group=ctl)
+            rank_ids, kern_per_rank = ids, [r["kernel_ms"] for r in ids]
+        except Exception as e:  # noqa: BLE001
+            diag_errors.append(f"ranks: {type(e).__name__}: {e}")
+
+    # --- the line of the timed region (rank 0); a leg child prints it NOW, before any diagnostic can hang or fail
+    out = None
+    shared = bool(getattr(sysm, "shared_pairs", False))
+    if rank == 0:
+        pairs_step = n * (n - 1)
+        # dominant kernel: a rank's force+kick-drift launch sequence = n_tgt x N pair evaluations, 20 flop each; with
+        # several ranks the slowest one's time
+        if kern_per_rank:
+            k_ms = max(kern_per_rank)
+        achieved = FLOP_PER_PAIR * sysm.n_tgt * (n - 1) / (k_ms * 1e-3) / 1e12
+        n_cover = sysm.n_tgt if sysm.ring else n  # sources one launch sequence covers (ring pass: one travelling block)
+        ws_bytes = workspace_bytes(n_cover, sysm.n_tgt, acc64, args.targets_per_lane, args.j_split, args.source_path,
+                                   args.wg_size)  # what hip_compute allocates
+        kname = capi.kernel_name_f32(n_cover, sysm.n_tgt, acc64, args.targets_per_lane, args.j_split, ws_bytes,
+                                     source_path=args.source_path, wg_size=args.wg_size)
+        tpl, jsp, wgs = capi.plan_f32(n_cover, sysm.n_tgt, acc64, args.targets_per_lane, args.j_split, ws_bytes,
+                                      args.source_path, args.wg_size)
+        if shared:  # the ranks share the unordered pairs: K1s; its launch shape from the library (nb_plan_shared_pairs_f32)
+            _, jsp, _ = capi.plan_shared_pairs_f32(n, world, acc64)
+            kname, tpl, wgs = f"nbody_force_sym_f32<{'true' if acc64 else 'false'}>", 8, 512
+        coll = {"nccl": "RCCL (torch.distributed nccl)", "gloo": "gloo (host-staged: rehearsal, not RCCL)"}.get(args.backend, args.backend)
+        out = {
+            "metric": "body-pair interactions/sec",
+            "value": pairs_step * args.steps / wall,
+            "unit": "pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": wall / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32" if not acc64 else "f32 pair math / f64 accumulate",
+            "data": "synthetic",
+            "config": workload_config(n, world, f"index-sharded x{world}, ring pass of float4 position blocks ({coll} send/recv)" if sysm.ring
+                                      else f"index-sharded x{world}, "
+                                      + (f"unordered pairs shared by the ranks, 1 {coll} reduce-scatter of partial forces + " if shared else "")
+                                      + f"1 {coll} all-gather of float4 positions/step"),
+            "host": "torch" if world > 1 else "single",
+            "exchange": sysm.exchange_mode,
+            "roofline": roofline_block(achieved, kname, k_ms, tpl, jsp, wgs, acc64, shared_pairs=shared),
+        }
+        if getattr(sysm, "shared_pairs_note", None):
+            out["shared_pairs_note"] = sysm.shared_pairs_note
+        if world > 1:
+            out["host_detail"] = ("nbody_amd.distributed: one process per GPU, torch.distributed (backend "
+                                  f"{args.backend}) for the collective only; kernels through the C ABI (nb_launch_step_f32)")
+            out["pairs"] = ("every unordered pair once, shared by the ranks (K1s); every rank's partial force on all bodies is "
+                            "reduce-scattered to the shard owners") if shared else "every ordered pair of a rank's own targets (K1)"
+            out["overlap"] = bool(args.overlap)
+        if args.single_device and world > 1:
+            out["rehearsal"] = f"all {world} ranks on GPU 0 (they share the chip): the P > 1 host logic, not a {world}-GPU measurement"
+        if rank_ids:
+            out["ranks"] = {"count": world, "distinct_devices": len({(r["uuid"], r["pci_bus_id"]) for r in rank_ids}),
+                            "backend": args.backend, "per_rank": rank_ids}
+            out["kernel_ms_per_rank"] = kern_per_rank
+            out["non_kernel_ms_per_step"] = wall / args.steps * 1e3 - k_ms
+        if first_step:
+            out["resumed_from_step"] = first_step
+        if ckpt_s:
+            out["checkpoints"] = {"count": len(ckpt_s), "seconds_each": [round(x, 2) for x in ckpt_s],
+                                  "bytes": os.path.getsize(args.checkpoint), "inside_timed_region": True}
+        if args.leg_child and world > 1:
+            out["stage"] = "timed_region"
+            emit(json.dumps(with_wall(out)))
+
+    # --- untimed diagnostics (after the timed region; not part of `value`)
+    exchange_ms = check = overlap_ab = spot = lds = sgpr = acc64_path = f64_path = None
     if world == 1 and not args.no_diagnostics and not sysm.ring and not args.lib:
         # the other kernels of the family on the same system, five untimed steps each, so that the adopted kernel's margin
         # comes from this run and not from a builder profile: the north star's named kernel — sources staged through an LDS
@@ -814,20 +1348,14 @@ def main():
                                      "sliced launch + reducer; HIP events on the launch stream")
         except Exception as e:  # noqa: BLE001
             diag_errors.append(f"other kernels: {type(e).__name__}: {e}")
-    if world > 1:
-        # who ran: every rank's GPU, read by the rank itself; and every rank's own kernel time (rank 0's prices `roofline`
-        # unless another rank was slower)
+        # the other arithmetic modes of the same system (BASELINE configs[4] computes in fp32 with fp64 sums and fp64 q,v
+        # masters; the testcases' mode is all-fp64), each with its own oracle check, so that their rates are the driver's too
         try:
-            pr = torch.cuda.get_device_properties(dev_index)
-            me = {"rank": rank, "device": dev_index, "name": pr.name, "uuid": str(getattr(pr, "uuid", "")),
-                  "pci_bus_id": f"{getattr(pr, 'pci_domain_id', 0):04x}:{getattr(pr, 'pci_bus_id', 0):02x}:"
-                                f"{getattr(pr, 'pci_device_id', 0):02x}.0",
-                  "compute_units": pr.multi_processor_count, "first_target": lo, "targets": hi - lo, "kernel_ms": k_ms}
-            ids = [None] * world
-            dist.all_gather_object(ids, me, group=ctl)
-            rank_ids, kern_per_rank = ids, [r["kernel_ms"] for r in ids]
+            if not acc64 and args.source_path in (0, 3):
+                acc64_path = other_precision_path(torch, n, device, "f32acc64")
+            f64_path = other_precision_path(torch, min(n, 262144), device, "f64")
         except Exception as e:  # noqa: BLE001
-            diag_errors.append(f"ranks: {type(e).__name__}: {e}")
+            diag_errors.append(f"other precisions: {type(e).__name__}: {e}")
     if world > 1 and not args.no_diagnostics:
         # every rank takes the same path through these: an exception that all ranks raise alike (a refused argument) is
         # recorded in the JSON instead of losing the measurement above
@@ -877,11 +1405,11 @@ def main():
             ab = {}
             k_ab = min(5, max(2, args.steps))
             was_shared = sysm.shared_pairs
-            for name, shared, mode in (("shared", True, False), ("off", False, False), ("on", False, True)):
-                if (mode and sysm.n_tgt % 256) or sysm.ring or (shared and not was_shared):
+            for name, shared_, mode in (("shared", True, False), ("off", False, False), ("on", False, True)):
+                if (mode and sysm.n_tgt % 256) or sysm.ring or (shared_ and not was_shared):
                     continue
                 sysm._wait_gather()
-                sysm.shared_pairs, sysm.overlap = shared, mode
+                sysm.shared_pairs, sysm.overlap = shared_, mode
                 sysm.step()
                 barrier()
                 t1 = time.perf_counter()
@@ -902,38 +1430,9 @@ def main():
         except Exception:  # noqa: BLE001
             pass
         sysm.overlap = args.overlap and world > 1
-        # rank 0 alone now drives all the GPUs from child processes — the C-ABI host (nb_sharded_*: one process,
-        # ncclCommInitAll) on the same workload, and the reference's own multi-GPU mode (bin/hw5 with NB_DEVICES) — while the
-        # other ranks wait on the host-side group, GPUs idle
-        torch.cuda.synchronize()
-        dist.barrier(group=ctl)
-        if rank == 0:
-            nat = ["--gpus", str(world), "--host", "native", "--bodies", str(n), "--precision", args.precision,
-                   "--steps", str(min(10, max(2, args.steps))), "--warmup", "2", "--no-diagnostics",
-                   "--exchange", "copy-one-gpu" if args.single_device else "rccl"]
-            native = run_bench_child(nat, timeout=300)
-            replicas = replicas_check([0, 0] if args.single_device else list(range(world)))
-        dist.barrier(group=ctl)
 
     if rank == 0:
-        pairs_step = n * (n - 1)
-        value = pairs_step * args.steps / wall
-        # dominant kernel: a rank's force+kick-drift launch sequence = n_tgt x N pair evaluations, 20 flop each; with
-        # several ranks the slowest one's time
-        if kern_per_rank:
-            k_ms = max(kern_per_rank)
-        flops_launch = FLOP_PER_PAIR * sysm.n_tgt * (n - 1)
-        achieved = flops_launch / (k_ms * 1e-3) / 1e12
-        n_cover = sysm.n_tgt if sysm.ring else n  # sources one launch sequence covers (ring pass: one travelling block)
-        ws_bytes = workspace_bytes(n_cover, sysm.n_tgt, acc64, args.targets_per_lane, args.j_split, args.source_path,
-                                   args.wg_size)  # what hip_compute allocates
-        kname = capi.kernel_name_f32(n_cover, sysm.n_tgt, acc64, args.targets_per_lane, args.j_split, ws_bytes,
-                                     source_path=args.source_path, wg_size=args.wg_size)
-        tpl, jsp, wgs = capi.plan_f32(n_cover, sysm.n_tgt, acc64, args.targets_per_lane, args.j_split, ws_bytes,
-                                      args.source_path, args.wg_size)
-        if getattr(sysm, "shared_pairs", False):  # the ranks share the unordered pairs: K1s, 8 targets per lane, 512 threads
-            kname, tpl, wgs = f"nbody_force_sym_f32<{'true' if acc64 else 'false'}>", 8, 512
-            jsp = max(1, -(-256 // max(1, sysm.n_tgt // 4096)))  # workgroups per superblock (csrc: sym_shape)
+        kname, jsp = out["roofline"]["kernel"], out["roofline"]["j_split"]
         traffic, reduce_share, valu_busy, pmc_tag = load_traffic(n, world, kname, jsp)
         traffic_source = (f"profiles/pmc_traffic.json ({pmc_tag}: builder's rocprofv3 PMC passes on this kernel, N and source "
                           f"split; not measured by this run)") if traffic else None
@@ -948,44 +1447,19 @@ def main():
                 traffic_source = ("measured by this run: three 2-step child runs under rocprofv3 --pmc (FETCH_SIZE x2 gfx950 "
                                   "correction + WRITE_SIZE; SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE); bytes = force kernel + "
                                   "reducer of one step (the launches kernel_ms spans), VALU-busy of the force kernel")
-        out = {
-            "metric": "body-pair interactions/sec",
-            "value": value,
-            "unit": "pairs/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": wall / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "strong",
-            "vs_baseline": None,
-            "dtype": "f32" if not acc64 else "f32 pair math / f64 accumulate",
-            "data": "synthetic",
-            "config": workload_config(n, world, f"index-sharded x{world}, ring pass of float4 position blocks" if sysm.ring
-                                      else f"index-sharded x{world}, "
-                                      + ("unordered pairs shared by the ranks, 1 RCCL reduce-scatter of partial forces + "
-                                         if getattr(sysm, "shared_pairs", False) else "")
-                                      + "1 RCCL all-gather of float4 positions/step"),
-            "host": "torch" if world > 1 else "single",
-            "exchange": sysm.exchange_mode,
-            "roofline": roofline_block(achieved, kname, k_ms, tpl, jsp, wgs, acc64, traffic, traffic_source, live,
-                                       valu_busy, reduce_share, shared_pairs=bool(getattr(sysm, "shared_pairs", False))),
-        }
+        r = out["roofline"]
+        out["roofline"] = roofline_block(r["achieved"], kname, r["kernel_ms"], r["targets_per_lane"], jsp, r["wg_size"], acc64,
+                                         traffic, traffic_source, live, valu_busy, reduce_share, shared_pairs=shared)
         if out["roofline"]["traffic_detail"]:
             out["roofline"]["traffic_detail"]["algorithmic"] = 56 * n  # 16N + 12N read, 12N + 16N written
-        if getattr(sysm, "shared_pairs_note", None):
-            out["shared_pairs_note"] = sysm.shared_pairs_note
-        if world > 1:
-            out["host_detail"] = ("nbody_amd.distributed: one process per GPU, torch.distributed (backend "
-                                  f"{args.backend}) for the collective only; kernels through the C ABI (nb_launch_step_f32)")
-        if rank_ids:
-            out["ranks"] = {"count": world, "distinct_devices": len({(r["uuid"], r["pci_bus_id"]) for r in rank_ids}),
-                            "backend": args.backend, "per_rank": rank_ids}
-            out["kernel_ms_per_rank"] = kern_per_rank
         if lds is not None:
             out["lds_path"] = lds
         if sgpr is not None:
             out["ordered_pair_path"] = sgpr
+        if acc64_path is not None:
+            out["acc64_path"] = acc64_path
+        if f64_path is not None:
+            out["f64_path"] = f64_path
         if exchange_ms is not None:
             out["exchange_ms"] = exchange_ms  # one all-gather of float4[N] by itself, mean of 20
         if check is not None:
@@ -995,26 +1469,9 @@ def main():
         if diag_errors:
             out["diagnostics_errors"] = diag_errors
         if overlap_ab:
-            out["overlap"] = bool(args.overlap)
             out["overlap_ab"] = {"ms_per_step": overlap_ab, "note": "same system, untimed diagnostic after the timed region: every "
                                  "rank its own ordered pairs (K1) without / with the two-phase step that hides the all-gather "
                                  "(off / on); shared = the ranks share the unordered pairs (K1s + reduce-scatter of forces)"}
-        if native is not None:
-            keep = ("value", "ms_per_step", "n_gpus", "steps", "host", "exchange", "ranks", "kernel_ms_per_rank",
-                    "non_kernel_ms_per_step", "parity_spot", "error", "stderr_tail")
-            out["native_host"] = {k: native[k] for k in keep if k in native}
-            if "roofline" in native:
-                out["native_host"]["roofline_frac"] = native["roofline"]["frac"]
-            out["native_host"]["what"] = ("the same workload through the C-ABI host (nb_sharded_*: ONE process, ncclCommInitAll, "
-                                          "one in-place ncclAllGather per GPU per step), run by rank 0 as a child process after "
-                                          "the timed region while the other ranks wait on the host")
-        if replicas is not None:
-            out["replicas"] = replicas
-        if first_step:
-            out["resumed_from_step"] = first_step
-        if ckpt_s:
-            out["checkpoints"] = {"count": len(ckpt_s), "seconds_each": [round(x, 2) for x in ckpt_s],
-                                  "bytes": os.path.getsize(args.checkpoint), "inside_timed_region": True}
         if cons0 is not None:
             e0, e1 = cons0["kinetic"] + cons0["potential_sampled"], cons1["kinetic"] + cons1["potential_sampled"]
             out["conservation"] = {
@@ -1031,6 +1488,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(n)
+        if world > 1:
+            out["stage"] = "complete"
         emit(json.dumps(with_wall(out)))
     if world > 1:
         dist.destroy_process_group()

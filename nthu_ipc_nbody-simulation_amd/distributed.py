@@ -146,9 +146,12 @@ class ShardedSystem:
                 (torch.device(device).type == "cuda"
                  and (compute is None or (getattr(compute, "is_hip_compute", False) and not compute.forced))
                  and capi.workspace_bytes_shared_pairs_f32(n, self.world, acc64) > 0)))
+        # `can` holds device-local facts (this rank's compute-unit count sizes the workspace): the ranks must AGREE, or some
+        # would enqueue reduce-scatter + all-gather per step and others only the all-gather — mismatched collectives, a hang
+        can = self._all_ranks(can, device)
         if shared_pairs and not can:
             raise ValueError("shared_pairs needs >= 2 ranks, HIP tensors, the all-gather exchange without overlap, "
-                             "n % (4096 * world) == 0 and n >= 49152")
+                             "n % (4096 * world) == 0 and n >= 49152 — on EVERY rank")
         self.shared_pairs = can if shared_pairs is None else bool(shared_pairs)
         self.shared_pairs_note = None
         if self.shared_pairs and shared_pairs is None and dist.get_backend(group) == "nccl":
@@ -165,6 +168,11 @@ class ShardedSystem:
             except Exception as e:  # noqa: BLE001
                 self.shared_pairs = False
                 self.shared_pairs_note = f"shared pairs off, every rank runs K1 on its own targets: {type(e).__name__}: {e}"
+            # the probe's verdict is per rank (an exception caught here was raised on this rank): one refusal switches every
+            # rank to the ordered form
+            if not self._all_ranks(self.shared_pairs, device) and self.shared_pairs:
+                self.shared_pairs = False
+                self.shared_pairs_note = "shared pairs off on every rank: another rank's reduce_scatter_tensor probe failed"
         self._fpart = self._facc = self._pair_ws = None
         if self.ring:
             if overlap:
@@ -195,6 +203,15 @@ class ShardedSystem:
         self.pos[1].copy_(self.pos[0])  # G*m column of the other buffer for slots this rank never writes
         if self.shared_pairs and self._pair_steps is None:
             self._alloc_shared_pairs(self.pos[0].device)  # not inside somebody's timed first step
+
+    def _all_ranks(self, flag, device):
+        """True iff `flag` holds on every rank of the group (all_reduce MIN of 0/1); the flag itself without a group."""
+        if not self.dist_on or self.world == 1:
+            return bool(flag)
+        on_gpu = dist.get_backend(self.group) == "nccl"
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device if on_gpu else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(int(t.item()))
 
     @property
     def exchange_mode(self):

@@ -175,7 +175,7 @@ def test_two_ranks_equal_one_rank(oracle, tmp_path):
     assert not np.array_equal(p0[:, :3], b["pos"][:, :3]) and np.array_equal(p0[:, 3], b["pos"][:, 3])
 
 
-@pytest.mark.parametrize("world,acc64", [(2, False), (2, True), (4, False)])
+@pytest.mark.parametrize("world,acc64", [(2, False), (2, True), (4, False), (8, False)])  # (8: the driver's full node)
 def test_ranks_sharing_the_unordered_pairs_equal_one_rank(oracle, tmp_path, world, acc64):
     """What bench.py --gpus P runs by default from two ranks up: every unordered pair evaluated once, by one rank; the
     partial forces summed across the ranks.  Same trajectory as the one-rank run to the rounding of the partial forces

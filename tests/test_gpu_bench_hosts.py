@@ -2,9 +2,12 @@
 
 `python3 bench.py --gpus P` typed without a launcher must run — the reference is one command on its GPUs (hw5.cu:618,
 564-567) — through the C-ABI host (nb_sharded_*: one process, one in-place all-gather per GPU per step); under
-torch.distributed.run the torch host runs and rank 0 adds the native host as a child.  A one-GPU box rehearses both with
-every rank on device 0 (`--exchange copy-one-gpu`, `--backend gloo --single-device`): exactly the code paths of the driver's
-multi-GPU node except the collective library itself.  The tests at the end need two GPUs and skip on the one-GPU box."""
+torch.distributed.run the torch host runs and rank 0 adds the native host as a child.  Since round 5 the measured step of
+both spellings runs as a LADDER of bounded fresh children (shared pairs over RCCL -> ordered pairs, all-gather only -> the
+copy-engine exchange; tests/test_bench_ladder.py exercises the parent on the CPU): here the real legs run.  A one-GPU box
+rehearses both with every rank on device 0 (`--exchange copy-one-gpu`, `--backend gloo --single-device`): exactly the code
+paths of the driver's multi-GPU node except the collective library itself — and `--gpus 2 --exchange rccl` on one GPU is the
+natural failure the ladder exists for.  The tests at the end need two GPUs and skip on the one-GPU box."""
 import json
 import os
 import socket
@@ -62,12 +65,36 @@ def test_native_host_line_without_a_launcher(nb):
     ps = r["parity_spot"]
     assert ps["ok"] and ps["ranks_covered"] == 2 and ps["rows"] == 64 and ps["max_err_over_sum_abs"] < ps["tol"] == 1e-5
     assert r["sharded_check"]["ok"]
-    # variants ran as children: the overlapped step (copy exchange on one GPU: rccl is skipped there)
+    # the measured step ran as a leg of the ladder: the request first, and it completed
+    assert r["leg"] == "shared_pairs_copy_one_gpu" and [x["name"] for x in r["legs"]] == ["shared_pairs_copy_one_gpu"]
+    assert r["legs"][0]["ok"] and "diagnostics_incomplete" not in r["legs"][0] and "stage" not in r
+    assert "rehearsal" in r and "same-device copy" in r["config"]["parallelism"] and "ncclAllGather" not in r["config"]["parallelism"]
+    # the other forms ran afterwards as bounded children: ordered pairs, and its overlapped step
     v = r["variants"]
-    assert v["overlap_on"]["ms_per_step"] > 0 and "exchange_rccl" not in v and "exchange_copy" not in v
-    assert v["pairs_ordered"]["kernel"].startswith("nbody_force_f32<") and v["overlap_on"]["kernel"].startswith("nbody_force_f32<")
+    assert v["ordered_pairs_copy_one_gpu"]["kernel"].startswith("nbody_force_f32<") and v["ordered_pairs_copy_one_gpu"]["ms_per_step"] > 0
+    assert v["ordered_pairs_copy_one_gpu_overlap"]["kernel"].startswith("nbody_force_f32<") and v["ordered_pairs_copy_one_gpu_overlap"]["overlap"]
     # the reference's own multi-GPU mode (two device slots, both this GPU): golden outputs
     assert r["replicas"]["b200"]["byte_identical"] and r["replicas"]["b1024"]["byte_identical"]
+
+
+def test_a_refused_rccl_leg_costs_the_leg_not_the_line(nb):
+    """`--gpus 2 --exchange rccl` on a box with ONE GPU.  RCCL cannot serve two ranks here (device 1 does
+    not exist; one rank per GPU) — both RCCL legs fail by themselves — and the ladder ends on the copy-engine exchange with
+    every rank on GPU 0: rc 0, ONE line, `legs[0].error` present, the value from the copy leg, its oracle spot check green."""
+    if nb.capi.device_count() != 1:
+        pytest.skip("a one-GPU box: the natural failure of an RCCL leg")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--exchange", "rccl", "--bodies", "131072",
+                        "--steps", "3", "--warmup", "1"], capture_output=True, text=True, timeout=900, env=_env(), cwd=ROOT)
+    r = _line(p)
+    legs = r["legs"]
+    assert legs[0]["name"] == "shared_pairs_rccl" and not legs[0]["ok"] and legs[0]["error"].startswith("rc=") and legs[0]["stderr_tail"]
+    assert "no usable HIP device" in legs[0]["stderr_tail"] or "nccl" in legs[0]["stderr_tail"].lower()
+    skipped = [x for x in legs if "skipped" in x]
+    assert {x["name"] for x in skipped} == {"ordered_pairs_rccl", "shared_pairs_copy", "ordered_pairs_copy"}  # need 2 GPUs
+    assert r["leg"] == "shared_pairs_copy_one_gpu" and legs[-1]["name"] == r["leg"] and legs[-1]["ok"]
+    assert r["exchange"] == "copy-one-gpu" and r["value"] == pytest.approx(131072 * 131071 * 3 / (r["ms_per_step"] * 3e-3), rel=1e-9)
+    assert r["parity_spot"]["ok"] and r["parity_spot"]["ranks_covered"] == 2 and r["sharded_check"]["ok"]
+    assert r["roofline"]["kernel"] == "nbody_force_sym_f32<false>" and "failed or timed out" in r["legs_note"]
 
 
 def test_native_host_acc64_overlapped_line(nb):
@@ -78,6 +105,7 @@ def test_native_host_acc64_overlapped_line(nb):
     assert r["n_gpus"] == 4 and r["overlap"] is True and r["ranks"]["count"] == 4
     ps = r["parity_spot"]
     assert ps["ok"] and ps["ranks_covered"] == 4 and ps["tol"] == 1e-6 and "variants" not in r and "replicas" not in r
+    assert r["leg"] == "ordered_pairs_copy_one_gpu_overlap" and r["roofline"]["kernel"].startswith("nbody_force_f32<")
 
 
 def test_torch_host_two_ranks_line(nb):
@@ -89,6 +117,9 @@ def test_torch_host_two_ranks_line(nb):
                         "--warmup", "1"], capture_output=True, text=True, timeout=1200, env=_env(), cwd=ROOT)
     r = _line(p)
     assert r["n_gpus"] == 2 and r["host"] == "torch" and r["steps"] == 3 and "diagnostics_errors" not in r, r.get("diagnostics_errors")
+    # 32768 bodies: too few for the shared pairs, so the first leg's ranks run K1 — and the line says gloo, not RCCL
+    assert r["leg"] == "shared_pairs_gloo" and r["legs"][0]["ok"] and "diagnostics_incomplete" not in r["legs"][0]
+    assert "gloo" in r["config"]["parallelism"] and "RCCL" not in r["config"]["parallelism"].replace("not RCCL", "") and "rehearsal" in r
     assert r["sharded_check"]["ok"] and r["exchange_ms"] > 0
     assert r["overlap_ab"]["ms_per_step"]["on"] > 0 and r["overlap_ab"]["ms_per_step"]["off"] > 0
     assert r["parity_spot"]["ok"] and r["parity_spot"]["ranks_covered"] == 2
@@ -113,6 +144,13 @@ def test_single_gpu_line_reports_the_lds_kernel_and_step_traffic(nb):
     assert k1["kernel"].startswith("nbody_force_f32<") and ", true, 512>" in k1["kernel"] and 0 < k1["frac"] < r["roofline"]["frac"]
     lds = r["lds_path"]
     assert lds["kernel"].startswith("nbody_force_f32<") and ", false, 256>" in lds["kernel"] and 0 < lds["frac"] < 1
+    # the other arithmetic modes through the plain C-ABI context, each with its own oracle check (configs[4]'s fp32 pair math /
+    # fp64 sums; the testcases' fp64 at large n against the fp64 vector peak)
+    a64, f64 = r["acc64_path"], r["f64_path"]
+    assert a64["kernel"] == "nbody_force_sym_f32<true>" and a64["parity"]["ok"] and a64["parity"]["tol"] == 1e-6 and 0 < a64["frac"] < 1
+    assert f64["dtype"] == "f64" and f64["peak"] == 78.6 and f64["parity"]["ok"] and f64["parity"]["tol"] == 1e-12 and 0 < f64["frac"] < 1
+    assert r["roofline"]["flop_per_pair"] == 20 and r["roofline"]["flop_per_pair_executed"] == 13
+    assert r["roofline"]["frac_executed"] == pytest.approx(r["roofline"]["frac"] * 13 / 20)
     live = r["roofline"]["live_pmc"]
     if live and "error" not in live:  # rocprofv3 present: bytes of force kernel + reducer = the launches kernel_ms spans
         assert live["force"]["hbm_bytes"] > 0 and live["reducer"]["hbm_bytes"] > 0
