@@ -532,8 +532,9 @@ static int nb_accel_impl(nb_context* c, int step, double* ax, double* ay, double
         NB_HIP(c, hipStreamSynchronize(c->stream));
     } else {
         const bool acc64 = c->cfg.precision == NB_F32_ACC64;
+        const F32Plan plan = context_plan_f32(c);  // first: it may replace the workspace (ensure_sym_workspace) the arguments point at
         F32Args a = f32_args(c);
-        NB_HIP(c, (hipError_t)launch_f32(a, context_plan_f32(c), acc64, true, c->stream));
+        NB_HIP(c, (hipError_t)launch_f32(a, plan, acc64, true, c->stream));
         if (acc64) {
             std::vector<double4> h(n);
             NB_HIP(c, hipMemcpyAsync(h.data(), c->acc32, n * sizeof(double4), hipMemcpyDeviceToHost, c->stream));

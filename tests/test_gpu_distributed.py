@@ -54,8 +54,20 @@ def _run(rank, world, port, path, acc64=False, backend="gloo", overlap=False, ex
             dist.reduce_scatter_tensor(o, f, op=dist.ReduceOp.SUM)
             torch.cuda.synchronize()
             assert torch.equal(o, f)
-    for _ in range(STEPS):
+    def all_velocities():
+        mine = (sysm.vel64 if acc64 else sysm.vel).clone()
+        if world == 1:
+            return mine
+        vels = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(vels, mine)
+        return torch.cat(vels)
+
+    vel_first = None
+    for k in range(STEPS):
         sysm.step()
+        if k == 0 and shared_pairs:  # the velocities after the FIRST step too (checked against oracle rows)
+            torch.cuda.synchronize()
+            vel_first = all_velocities()
     torch.cuda.synchronize()
     if acc64:  # the fp64 masters are the state of this mode: gather them instead of the fp32 copies
         p64 = [torch.zeros_like(sysm.pos64) for _ in range(world)] if world > 1 else [sysm.pos64]
@@ -72,6 +84,8 @@ def _run(rank, world, port, path, acc64=False, backend="gloo", overlap=False, ex
     full = sysm.positions  # every rank: with exchange="ring" this is a collective (no rank holds all positions)
     if rank == 0:
         extra = dict(pos64=pos64) if acc64 else {}
+        if vel_first is not None:
+            extra["vel_first"] = vel_first.cpu().numpy()
         np.savez(path, pos=full.cpu().numpy(), vel=allv.cpu().numpy(), **extra)
     if dist.is_initialized():
         dist.barrier()
@@ -142,10 +156,8 @@ def test_ranks_sharing_the_unordered_pairs_match_single(nb, oracle, tmp_path, wo
         assert np.abs(a["pos64"] - b["pos64"])[:, :3].max() < 1e-9 and np.abs(a["vel"] - b["vel"]).max() < 1e-7
     else:
         assert np.abs(a["pos"] - b["pos"]).max() < 5e-7 and np.abs(a["vel"] - b["vel"]).max() < 1e-5
-    # one step from the initial state against the oracle, rows from every shard
-    three = str(tmp_path / "three.npz")
-    mp.spawn(_run, args=(world, _free_port(), three, acc64, "gloo", False, "in_place", n, 1, True), nprocs=world, join=True)
-    c = np.load(three)
+    # the first of the two steps against the oracle, rows from every shard
+    c = {"vel": b["vel_first"]}
     syn = nb.synthetic
     q, v, m = syn.bodies(n)
     per = n // world
