@@ -462,7 +462,10 @@ def run_ladder(legs, runner, budget_s, leg_timeout_s, log=None, sync=None):
         if left < min(20.0, leg_timeout_s):
             records.append({"name": leg["name"], "skipped": "out of time budget", "ok": False})
             continue
-        timeout = min(leg_timeout_s, left)
+        # a leg may use what is left minus a reserve of 90 s for every leg still behind it (two RCCL legs that hang until
+        # their limit must not starve the copy-engine legs), but always at least a minute
+        behind = sum(1 for lg in legs[i + 1:] if not lg.get("skip"))
+        timeout = min(leg_timeout_s, max(min(60.0, left), left - 90.0 * behind))
         t1 = time.perf_counter()
         if log:
             log(f"leg {i} {leg['name']}: starting (limit {timeout:.0f} s)")

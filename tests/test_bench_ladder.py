@@ -49,6 +49,11 @@ def test_ladder_takes_the_first_leg_that_yields_a_line():
         raise OSError("no such program")
     records, chosen, line = bench.run_ladder(legs[:1], broken, 100, 7)
     assert chosen is None and line is None and "OSError" in records[0]["stderr_tail"]
+    # the limit of a leg leaves 90 s for every leg behind it (two hanging RCCL legs must not starve the copy legs) but is never
+    # under a minute: four legs, 300 s, a runner that fails at once
+    seen.clear()
+    bench.run_ladder([{"name": "a"}, {"name": "a"}, {"name": "a"}, {"name": "a"}], runner, budget_s=300, leg_timeout_s=240)
+    assert [round(t / 10) * 10 for _, t in seen] == [60, 120, 210, 240], seen
     # out of budget: legs are skipped, not started
     records, chosen, _ = bench.run_ladder([{"name": "a"}], runner, budget_s=0.0, leg_timeout_s=7)
     assert chosen is None and records[0]["skipped"] == "out of time budget"
