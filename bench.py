@@ -597,9 +597,14 @@ def workload_config(n, world, how):
             "parallelism": how if world > 1 else "single GPU"}
 
 
+NATIVE_EXCHANGES = ("rccl", "copy", "copy-one-gpu", "host", "host-one-gpu")
+
+
 def native_parallelism(P, sym, exchange):
     """config.parallelism of a native-host line, from what actually ran."""
-    coll = {"rccl": ("ncclReduceScatter", "in-place ncclAllGather"),
+    coll = {"host": ("-", "host-staged all-gather (D2H of the own slot into one pinned array, H2D of the others: no peer-to-peer)"),
+            "host-one-gpu": ("-", "host-staged all-gather (all ranks on GPU 0: rehearsal)"),
+            "rccl": ("ncclReduceScatter", "in-place ncclAllGather"),
             "copy": ("copy-engine reduce-scatter (hipMemcpyPeerAsync pulls + ordered sum)", "copy-engine all-gather (hipMemcpyPeerAsync)"),
             "copy-one-gpu": ("same-device copy reduce-scatter (all ranks on GPU 0: rehearsal)",
                              "same-device copy all-gather (all ranks on GPU 0: rehearsal)")}[exchange]
@@ -625,16 +630,17 @@ def main_native(args):
     P, n = args.gpus, args.bodies
     acc64 = args.precision == "f32acc64"
     exchange = args.exchange or "rccl"
-    if exchange not in ("rccl", "copy", "copy-one-gpu"):
-        raise SystemExit(f"--exchange {exchange}: the native host takes rccl, copy or copy-one-gpu "
+    if exchange not in NATIVE_EXCHANGES:
+        raise SystemExit(f"--exchange {exchange}: the native host takes {', '.join(NATIVE_EXCHANGES)} "
                          f"(in_place/staged/ring belong to the torch host: launch with torch.distributed.run)")
     if args.resume or args.checkpoint or args.conservation or args.dump_rows:
         raise SystemExit("--resume/--checkpoint/--conservation/--dump-rows: single rank or the torch host")
-    devices = [0] * P if exchange == "copy-one-gpu" else list(range(P))
+    devices = [0] * P if exchange.endswith("one-gpu") else list(range(P))
+    lib_exchange = exchange.split("-")[0]  # rccl | copy | host
     prec = capi.NB_F32_ACC64 if acc64 else capi.NB_F32
     kw = dict(G=synthetic.G, eps=synthetic.EPS, dt=synthetic.DT)
     try:
-        sh = capi.Sharded(n, devices, prec, overlap=args.overlap, exchange="rccl" if exchange == "rccl" else "copy",
+        sh = capi.Sharded(n, devices, prec, overlap=args.overlap, exchange=lib_exchange,
                           ordered_pairs=args.ordered_pairs, deadline=args.deadline, **kw)
     except capi.NBodyError as e:  # no GPU (NB_ERR_NO_DEVICE), fewer than P GPUs, RCCL missing: fail loudly, no fallback
         raise SystemExit(f"bench.py --gpus {P} (native host, devices {devices}): {e}")
@@ -687,6 +693,7 @@ def main_native(args):
         "host_detail": "nb_sharded_* (csrc/nbody_sharded.cpp): ONE process, one stream per GPU, "
                        + ("ncclCommInitAll; per GPU and step " + ("one ncclReduceScatter of partial forces + " if sym else "")
                           + "one in-place ncclAllGather (RCCL over xGMI)" if exchange == "rccl"
+                          else "the all-gather through a pinned host array, per-device copies only (NB_SHARDED_HOST_EXCHANGE)" if lib_exchange == "host"
                           else "P-1 peer copies per GPU per step and collective on the copy engines (NB_SHARDED_COPY_EXCHANGE)")
                        + f"; every wait bounded at {args.deadline:g} s per step (nb_sharded_set_deadline)",
         "exchange": exchange,
@@ -705,7 +712,7 @@ def main_native(args):
     }
     if sh.note:
         out["shared_pairs_note"] = sh.note
-    if exchange == "copy-one-gpu":
+    if exchange.endswith("one-gpu"):
         out["rehearsal"] = f"all {P} ranks on GPU 0 (they share the chip): the P > 1 host logic, not a {P}-GPU measurement"
     out["roofline"]["kernel_ms_detail"] = ("slowest rank's mean per step, HIP events on each rank's own compute stream "
                                            "around its launch sequence (nb_sharded_step_profiled); all ranks in kernel_ms_per_rank")
@@ -735,7 +742,7 @@ def main_native(args):
             nn, steps, dt = 32768, 3, 1e-2
             q, v, mm = synthetic.bodies(nn)
             with capi.Sharded(nn, devices, capi.NB_F32, G=synthetic.G, eps=synthetic.EPS, dt=dt, overlap=args.overlap,
-                              exchange="rccl" if exchange == "rccl" else "copy", deadline=args.deadline) as s2:
+                              exchange=lib_exchange, deadline=args.deadline) as s2:
                 s2.set_state(q, v, mm)
                 s2.step(steps)
                 q2, _ = s2.get_state()
@@ -780,25 +787,31 @@ def native_legs(args, ndev):
     (no RCCL at all: shared, then ordered).  A box with fewer than P GPUs can only rehearse: the copy exchange with every rank
     on GPU 0 (said in the line: `rehearsal`)."""
     P = args.gpus
-    req = (args.exchange or "rccl", bool(args.ordered_pairs or args.overlap))
-    if req[0] not in ("rccl", "copy", "copy-one-gpu"):
-        raise SystemExit(f"--exchange {req[0]}: the native host takes rccl, copy or copy-one-gpu "
+    req_ex = args.exchange or "rccl"
+    if req_ex not in NATIVE_EXCHANGES:
+        raise SystemExit(f"--exchange {req_ex}: the native host takes {', '.join(NATIVE_EXCHANGES)} "
                          f"(in_place/staged/ring belong to the torch host: launch with torch.distributed.run)")
+    if req_ex.startswith("host") and args.overlap:
+        raise SystemExit("--exchange host: the host-staged exchange is not overlapped")
+    req = (req_ex, bool(args.ordered_pairs or args.overlap or req_ex.startswith("host")))
     order = [req]
-    if req[0] != "copy-one-gpu":
-        order += [x for x in (("rccl", False), ("rccl", True), ("copy", False), ("copy", True)) if x != req and not (args.overlap and not x[1])]
-    if ndev < P or req[0] == "copy-one-gpu":
-        order += [x for x in (("copy-one-gpu", False), ("copy-one-gpu", True)) if x not in order and not (args.overlap and not x[1])]
+    usable = lambda x: not (args.overlap and (not x[1] or x[0].startswith("host")))  # noqa: E731  (overlap = ordered pairs, not host-staged)
+    if not req_ex.endswith("one-gpu"):
+        order += [x for x in (("rccl", False), ("rccl", True), ("copy", False), ("copy", True), ("host", True)) if x != req and usable(x)]
+    if ndev < P or req_ex.endswith("one-gpu"):
+        order += [x for x in (("copy-one-gpu", False), ("copy-one-gpu", True), ("host-one-gpu", True)) if x not in order and usable(x)]
     legs = []
     for k, (ex, ordered) in enumerate(order):
         name = ("ordered_pairs" if ordered else "shared_pairs") + "_" + ex.replace("-", "_") + ("_overlap" if args.overlap else "")
         argv = ["--host", "native", "--exchange", ex] + (["--ordered-pairs"] if ordered else []) + (["--overlap"] if args.overlap else [])
         what = {"rccl": "RCCL: " + ("in-place all-gather of positions only (north_star's scheme)" if ordered else
                                     "reduce-scatter of partial forces + in-place all-gather of positions"),
-                "copy": "copy engines (hipMemcpyPeerAsync), no RCCL", "copy-one-gpu": f"all {P} ranks on GPU 0 (rehearsal)"}[ex]
+                "copy": "copy engines (hipMemcpyPeerAsync), no RCCL", "copy-one-gpu": f"all {P} ranks on GPU 0 (rehearsal)",
+                "host": "all-gather through a pinned host array: per-device copies only, no peer-to-peer, no RCCL (last resort)",
+                "host-one-gpu": f"host-staged all-gather, all {P} ranks on GPU 0 (rehearsal)"}[ex]
         leg = {"name": name, "argv": argv, "what": ("every ordered pair of a GPU's own targets (K1); " if ordered else
                                                    "the GPUs share the unordered pairs (K1s); ") + what, "exchange": ex, "ordered": ordered}
-        if k > 0 and ex != "copy-one-gpu" and ndev < P:
+        if k > 0 and not ex.endswith("one-gpu") and ndev < P:
             leg["skip"] = f"needs {P} GPUs, this box shows {ndev}"
         legs.append(leg)
     return legs
@@ -874,7 +887,7 @@ def orchestrate_native(args):
             rc, out, err = runner(lg, min(args.leg_timeout, 180), steps=k_ab, diagnostics=False)
             rec, ln = leg_record(lg["name"], rc, out, err, min(args.leg_timeout, 180), time.perf_counter() - t1)
             extras[lg["name"]] = summarise_leg_line(ln) if rec["ok"] else {k: rec[k] for k in ("error", "timeout", "stderr_tail") if k in rec}
-        replicas = replicas_check([0, 0] if legs[chosen]["exchange"] == "copy-one-gpu" else list(range(args.gpus)))
+        replicas = replicas_check([0, 0] if legs[chosen]["exchange"].endswith("one-gpu") else list(range(args.gpus)))
     emit(json.dumps(finish_ladder_line(args, line, records, chosen, legs, extras, replicas)))
 
 
@@ -903,6 +916,12 @@ def torch_legs(args, world, ndev):
                          "argv": ["--host", "native", "--exchange", ex] + (["--ordered-pairs"] if ordered else []) +
                                  (["--overlap"] if args.overlap else []),
                          "what": "the C-ABI host (ONE process for all GPUs, run by rank 0), copy-engine exchange: no RCCL involved"})
+        if not args.overlap:
+            hx = "host-one-gpu" if ex == "copy-one-gpu" else "host"
+            legs.append({"name": "native_ordered_pairs_" + hx.replace("-", "_"), "host": "native", "exchange": hx, "ordered": True,
+                         "argv": ["--host", "native", "--exchange", hx, "--ordered-pairs"],
+                         "what": "the C-ABI host, all-gather through a pinned host array: per-device copies only, no peer-to-peer, no "
+                                 "RCCL (last resort)"})
     return legs
 
 
@@ -921,7 +940,7 @@ def orchestrate_torch(args, world):
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the torch host runs one rank per GPU under "
                          f"torch.distributed.run (or type the command without a launcher for the native host)")
-    if args.exchange in ("rccl", "copy", "copy-one-gpu"):
+    if args.exchange in NATIVE_EXCHANGES:
         raise SystemExit(f"--exchange {args.exchange} belongs to the native host (run without a launcher)")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=max(1800.0, 4 * args.legs_budget)))
@@ -1070,7 +1089,7 @@ def main():
     ap.add_argument("--wg-size", type=int, default=0, help="0 auto, 256, 512 (with --targets-per-lane 8), 1024 (4)")
     ap.add_argument("--overlap", action="store_true", help="multi-GPU: two-phase step, own-shard sources while the "
                     "all-gather of the other shards is in flight (SURVEY 8(f)-3); default off, see overlap_ab in the JSON")
-    ap.add_argument("--exchange", choices=["in_place", "staged", "ring", "rccl", "copy", "copy-one-gpu"], default=None,
+    ap.add_argument("--exchange", choices=["in_place", "staged", "ring", "rccl", "copy", "copy-one-gpu", "host", "host-one-gpu"], default=None,
                     help="multi-GPU, torch host: in_place all-gather (default), all-gather from a cloned shard (staged), or "
                     "the ring pass (no rank holds all positions).  Native host: rccl (default, in-place ncclAllGather), copy "
                     "(peer copies on the copy engines) or copy-one-gpu (all ranks on device 0: rehearsal on a one-GPU box)")
@@ -1125,7 +1144,7 @@ def main():
         raise SystemExit("--host native is ONE process for all GPUs: run it without a launcher")
     if args.host == "native" or (args.host == "auto" and args.gpus > 1 and world == 1):
         return main_native(args)
-    if args.exchange in ("rccl", "copy", "copy-one-gpu"):
+    if args.exchange in NATIVE_EXCHANGES:
         raise SystemExit(f"--exchange {args.exchange} belongs to the native host (run without a launcher, or --host native)")
     args.exchange = args.exchange or "in_place"
 

@@ -166,6 +166,11 @@ typedef struct nb_sharded nb_sharded;
                                 the superblocks of its shard against the half of the system behind each), which leaves every GPU
                                 with a partial force on all n bodies — one reduce-scatter per step (ncclReduceScatter, or peer
                                 copies + an ordered sum with NB_SHARDED_COPY_EXCHANGE) in front of the kick-drift and the all-gather */
+#define NB_SHARDED_HOST_EXCHANGE 8 /* last resort for a node whose peer-to-peer path does not work: the all-gather through ONE pinned
+                                host array — every GPU downloads its slot, the host waits for all of them, every GPU uploads the
+                                others' — only per-device copies, no peer mapping, no cross-device event, RCCL not loaded.  Ordered
+                                pairs only (kernel K1), not overlapped; accepts an ordinal more than once like the copy exchange.
+                                Costs a host round trip per step and 16 n bytes over PCIe per GPU and step (2.4 ms of a 30 ms step at n = 2^20, P = 8) */
 int nb_sharded_create(nb_sharded** out, const int* devices, int n_devices, int64_t n, int precision, double G,
                       double eps, double dt, int flags);
 int nb_sharded_destroy(nb_sharded* s);
@@ -199,16 +204,16 @@ const char* nb_sharded_kernel_name(const nb_sharded* s);
 /* who rank `rank` is: which GPU it drives (ordinal, PCI bus id, UUID, name), which targets it owns, and what its exchange
  * is — for RCCL straight from the rank's communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice), so that
  * "the collective ran over N ranks on N distinct GPUs" is a fact read back from RCCL, not an echo of the arguments */
-typedef enum nb_sharded_exchange { NB_EXCHANGE_RCCL = 1, NB_EXCHANGE_COPY = 2 } nb_sharded_exchange;
+typedef enum nb_sharded_exchange { NB_EXCHANGE_RCCL = 1, NB_EXCHANGE_COPY = 2, NB_EXCHANGE_HOST = 3 } nb_sharded_exchange;
 typedef struct nb_sharded_rank {
     int32_t device;        /* HIP ordinal */
     int32_t compute_units;
     int64_t first_target;  /* owns targets [first_target, first_target + targets) */
     int64_t targets;
     int32_t exchange;      /* nb_sharded_exchange */
-    int32_t comm_ranks;    /* RCCL: ncclCommCount of this rank's communicator; copy exchange: n_devices */
-    int32_t comm_rank;     /* RCCL: ncclCommUserRank; copy exchange: rank */
-    int32_t comm_device;   /* RCCL: ncclCommCuDevice; copy exchange: device */
+    int32_t comm_ranks;    /* RCCL: ncclCommCount of this rank's communicator; copy / host exchange: n_devices */
+    int32_t comm_rank;     /* RCCL: ncclCommUserRank; copy / host exchange: rank */
+    int32_t comm_device;   /* RCCL: ncclCommCuDevice; copy / host exchange: device */
     char pci_bus_id[16];   /* "0000:05:00.0" */
     char uuid[36];         /* hipDeviceGetUuid, 32 hex digits */
     char name[64];

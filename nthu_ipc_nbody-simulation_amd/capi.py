@@ -127,12 +127,13 @@ DEBUG_SYMBOLS = {
     "nb_read_step_stamps": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]),
     "nb_create_cu_masked": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(NbConfig), C.c_int]),
 }
-NB_EXCHANGE_RCCL, NB_EXCHANGE_COPY = 1, 2
+NB_EXCHANGE_RCCL, NB_EXCHANGE_COPY, NB_EXCHANGE_HOST = 1, 2, 3
 NB_SHARDED_OVERLAP = 1
 NB_CU_ALL, NB_CU_LOW, NB_CU_HIGH, NB_CU_EVEN, NB_CU_ODD = 0, 1, 2, 3, 4
 NB_HANDOFF_AUTO, NB_HANDOFF_HOST_STAGED = 0, 1
 NB_SHARDED_COPY_EXCHANGE = 2
 NB_SHARDED_ORDERED_PAIRS = 4
+NB_SHARDED_HOST_EXCHANGE = 8
 NB_CFG_ORDERED_PAIRS = 1
 
 
@@ -467,13 +468,14 @@ class Sharded:
 
     def __init__(self, n, devices=(0,), precision=NB_F32, G=6.674e-11, eps=1e-3, dt=60.0, overlap=False,
                  exchange="rccl", ordered_pairs=False, deadline=0.0):
-        if exchange not in ("rccl", "copy"):
-            raise ValueError("exchange must be 'rccl' or 'copy'")
+        if exchange not in ("rccl", "copy", "host"):
+            raise ValueError("exchange must be 'rccl', 'copy' or 'host'")
         self.n = n
         self.devices = list(devices)
         self._h = C.c_void_p()
         devs = (C.c_int * len(devices))(*devices)
         flags = (NB_SHARDED_OVERLAP if overlap else 0) | (NB_SHARDED_COPY_EXCHANGE if exchange == "copy" else 0) | \
+            (NB_SHARDED_HOST_EXCHANGE if exchange == "host" else 0) | \
             (NB_SHARDED_ORDERED_PAIRS if ordered_pairs else 0)
         rc = lib().nb_sharded_create(C.byref(self._h), devs, len(devices), n, precision, G, eps, dt, flags)
         if rc != NB_OK:
@@ -541,7 +543,7 @@ class Sharded:
         r = NbShardedRank()
         self._check(lib().nb_sharded_rank_info(self._h, rank, C.byref(r)), "nb_sharded_rank_info")
         return dict(rank=rank, device=r.device, compute_units=r.compute_units, first_target=r.first_target,
-                    targets=r.targets, exchange={NB_EXCHANGE_RCCL: "rccl", NB_EXCHANGE_COPY: "copy"}[r.exchange],
+                    targets=r.targets, exchange={NB_EXCHANGE_RCCL: "rccl", NB_EXCHANGE_COPY: "copy", NB_EXCHANGE_HOST: "host"}[r.exchange],
                     comm_ranks=r.comm_ranks, comm_rank=r.comm_rank, comm_device=r.comm_device,
                     pci_bus_id=r.pci_bus_id.decode(), uuid=r.uuid.decode(), name=r.name.decode())
 

@@ -5,7 +5,8 @@
 // pairs=ordered: every GPU evaluates every ordered pair of its own targets (K1), all-gather only; overlap=1 = two-phase
 // ordered-pair step hiding the gather); gpus = 0 the plain context.
 // exchange: rccl | copy (peer copies on the copy engines, NB_SHARDED_COPY_EXCHANGE) | copy-one-gpu (the same with all
-// `gpus` ranks on device 0 — every P > 1 line of the host runs on a one-GPU box; the ranks then share the chip).
+// `gpus` ranks on device 0 — every P > 1 line of the host runs on a one-GPU box; the ranks then share the chip) | host (the
+// all-gather through a pinned host array, NB_SHARDED_HOST_EXCHANGE: no peer-to-peer involved) | host-one-gpu.
 // Generates the synthetic bodies of SURVEY §8(d) (same splitmix64 stream as nbody_amd/synthetic.py), uploads them with
 // nb_set_state, advances `steps` steps with nb_step_timed (HIP events on the context's stream) and prints pairs/s.
 // Shows what a C/C++ caller of libnbody_amd looks like and gives rocprofv3 a target without an interpreter in front.
@@ -35,10 +36,11 @@ int main(int argc, char** argv) {
     const int overlap = argc > 6 ? atoi(argv[6]) : 0;
     const char* exchange = argc > 7 ? argv[7] : "rccl";
     const bool ordered = argc > 8 && !strcmp(argv[8], "ordered");
-    const bool one_gpu = !strcmp(exchange, "copy-one-gpu");
-    const bool copy = one_gpu || !strcmp(exchange, "copy");
-    if (!copy && strcmp(exchange, "rccl")) {
-        fprintf(stderr, "exchange must be rccl, copy or copy-one-gpu\n");
+    const bool one_gpu = !strcmp(exchange, "copy-one-gpu") || !strcmp(exchange, "host-one-gpu");
+    const bool host = !strncmp(exchange, "host", 4);
+    const bool copy = !strncmp(exchange, "copy", 4);
+    if (!copy && !host && strcmp(exchange, "rccl")) {
+        fprintf(stderr, "exchange must be rccl, copy, copy-one-gpu, host or host-one-gpu\n");
         return 2;
     }
     nb_config cfg;
@@ -62,7 +64,7 @@ int main(int argc, char** argv) {
         for (int g = 0; g < gpus; ++g) devs[g] = one_gpu ? 0 : g;
         nb_sharded* sh = nullptr;
         int rc = nb_sharded_create(&sh, devs.data(), gpus, n, cfg.precision, cfg.G, cfg.eps, cfg.dt,
-                                   (overlap ? NB_SHARDED_OVERLAP : 0) | (copy ? NB_SHARDED_COPY_EXCHANGE : 0) |
+                                   (overlap ? NB_SHARDED_OVERLAP : 0) | (copy ? NB_SHARDED_COPY_EXCHANGE : 0) | (host ? NB_SHARDED_HOST_EXCHANGE : 0) |
                                        (ordered ? NB_SHARDED_ORDERED_PAIRS : 0));
         if (!rc) rc = nb_sharded_set_state(sh, &q[0], &q[n], &q[2 * n], &v[0], &v[n], &v[2 * n], m.data());
         if (!rc && warmup > 0) rc = nb_sharded_step(sh, warmup);

@@ -22,6 +22,10 @@
 //                             ranks' slots on its own exchange stream once the owner's `stepped` event has fired.  It is
 //                             also the only exchange that accepts the same ordinal more than once in `devices` (ranks
 //                             that share a GPU), which is how a one-GPU box runs every P > 1 line of step_once.
+//   NB_SHARDED_HOST_EXCHANGE  the last resort (round 5): every GPU downloads its slot into one pinned host array, the host
+//                             waits for all of them, every GPU uploads the other slots.  Only per-device operations — no
+//                             peer mapping, no cross-device event, no library — for a node whose P2P path is broken; ordered
+//                             pairs only (a host-side sum of P partial forces would cost more than the step).
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -130,6 +134,7 @@ struct nb_sharded {
     long enqueued = 0;       // steps enqueued since the streams were last drained (the `done` ring is indexed by it)
     long awaited = 0;        // ... of which the first `awaited` are known to have finished
     bool dead = false;       // a wait timed out: the GPUs may still be busy with what was enqueued; nothing may be enqueued
+    float4* host_stage[2] = {nullptr, nullptr};  // NB_SHARDED_HOST_EXCHANGE: pinned float4[n] per ping-pong array
     char err[512] = {0};
 };
 
@@ -187,6 +192,8 @@ int wait_event(nb_sharded* s, hipEvent_t ev, const char* what) {
 bool acc64(const nb_sharded* s) { return s->precision == NB_F32_ACC64; }
 bool overlapped(const nb_sharded* s) { return (s->flags & NB_SHARDED_OVERLAP) && s->P > 1; }
 bool copy_exchange(const nb_sharded* s) { return (s->flags & NB_SHARDED_COPY_EXCHANGE) != 0; }
+bool host_exchange(const nb_sharded* s) { return (s->flags & NB_SHARDED_HOST_EXCHANGE) != 0; }
+bool uses_rccl(const nb_sharded* s) { return !copy_exchange(s) && !host_exchange(s); }
 size_t force_rec(const nb_sharded* s) { return acc64(s) ? sizeof(double4) : sizeof(float4); }
 
 // slots of the source-slice workspace: the documented minimum of 16, or as many as the whole-step plan has slices (up to
@@ -283,6 +290,29 @@ int exchange_copy(nb_sharded* s, int nxt, bool ov) {
                 SH_HIP(s, hipMemcpyPeerAsync(q.pos[nxt] + r.lo, q.device, r.pos[nxt] + r.lo, r.device, bytes, xs));
         }
         if (ov) SH_HIP(s, hipEventRecord(q.gathered, xs));
+    }
+    return NB_OK;
+}
+
+// Host-staged all-gather: D2H of every GPU's own slot into the pinned array of this ping-pong side, a (bounded) host wait
+// for all of them, H2D of the other slots on every GPU.  The host array is reused two steps later, behind another such wait,
+// which every upload of this step has passed by then.
+int exchange_host(nb_sharded* s, int nxt) {
+    float4* H = s->host_stage[nxt];
+    const size_t N = (size_t)s->n, per = (size_t)s->per;
+    for (Rank& k : s->rank) {
+        SH_HIP(s, hipSetDevice(k.device));
+        SH_HIP(s, hipMemcpyAsync(H + k.lo, k.pos[nxt] + k.lo, per * sizeof(float4), hipMemcpyDeviceToHost, k.stream));
+    }
+    for (Rank& k : s->rank) {
+        SH_HIP(s, hipSetDevice(k.device));
+        if (int rc = wait_stream(s, k.stream, "a GPU's step and the download of its shard (host-staged exchange)")) return rc;
+    }
+    for (Rank& q : s->rank) {
+        SH_HIP(s, hipSetDevice(q.device));
+        const size_t lo = (size_t)q.lo, hi = lo + per;
+        if (lo > 0) SH_HIP(s, hipMemcpyAsync(q.pos[nxt], H, lo * sizeof(float4), hipMemcpyHostToDevice, q.stream));
+        if (hi < N) SH_HIP(s, hipMemcpyAsync(q.pos[nxt] + hi, H + hi, (N - hi) * sizeof(float4), hipMemcpyHostToDevice, q.stream));
     }
     return NB_OK;
 }
@@ -410,7 +440,7 @@ int step_once(nb_sharded* s, StepEvents* ev = nullptr, size_t step = 0) {
         if (int rc = exchange_forces(s)) return rc;
     // exchange: every GPU contributes its own slot of the array its kernels have just written
     const int nxt = s->cur ^ 1;
-    if (int rc = copy_exchange(s) ? exchange_copy(s, nxt, ov) : exchange_rccl(s, nxt, ov)) return rc;
+    if (int rc = host_exchange(s) ? exchange_host(s, nxt) : copy_exchange(s) ? exchange_copy(s, nxt, ov) : exchange_rccl(s, nxt, ov)) return rc;
     s->gather_pending = ov;
     s->cur = nxt;
     if (s->deadline_s > 0) {  // (an overlapped step's gather sits on the comm stream: the NEXT step's kernels wait for it, and
@@ -468,6 +498,8 @@ void release(nb_sharded* s) {
         if (k.stream) (void)hipStreamDestroy(k.stream);
         if (k.comm_stream) (void)hipStreamDestroy(k.comm_stream);
     }
+    for (float4*& h : s->host_stage)  // (every stream that copied from / into them is gone)
+        if (h) { (void)hipHostFree(h); h = nullptr; }
 }
 
 int create_impl(nb_sharded** out, const int* devices, int n_devices, int64_t n, int precision, double G, double eps,
@@ -479,6 +511,8 @@ int create_impl(nb_sharded** out, const int* devices, int n_devices, int64_t n, 
     if (!((float)(eps * eps) >= F32_EPS2_MIN)) return fail(nullptr, NB_ERR_INVALID, "nb_sharded_create", "fp32 kernels need eps >= 1e-12 (eps^2 a normal fp32 number with a finite inverse cube)");
     if (n % n_devices) return fail(nullptr, NB_ERR_INVALID, "nb_sharded_create", "n must be divisible by the number of devices");
     // overlap cuts the sources at shard boundaries: they must fall on whole 256-body tiles
+    if ((flags & NB_SHARDED_HOST_EXCHANGE) && (flags & (NB_SHARDED_OVERLAP | NB_SHARDED_COPY_EXCHANGE)))
+        return fail(nullptr, NB_ERR_INVALID, "nb_sharded_create", "the host-staged exchange is neither overlapped nor combined with the copy exchange");
     if ((flags & NB_SHARDED_OVERLAP) && n_devices > 1 && (n / n_devices) % TILE)
         return fail(nullptr, NB_ERR_INVALID, "nb_sharded_create", "overlap needs n / devices to be a multiple of 256");
     int ndev = 0;
@@ -486,7 +520,7 @@ int create_impl(nb_sharded** out, const int* devices, int n_devices, int64_t n, 
     for (int i = 0; i < n_devices; ++i) {
         if (devices[i] < 0 || devices[i] >= ndev) return NB_ERR_NO_DEVICE;
         for (int j = 0; j < i; ++j)
-            if (devices[j] == devices[i] && !(flags & NB_SHARDED_COPY_EXCHANGE))
+            if (devices[j] == devices[i] && !(flags & (NB_SHARDED_COPY_EXCHANGE | NB_SHARDED_HOST_EXCHANGE)))
                 return fail(nullptr, NB_ERR_INVALID, "nb_sharded_create", "a device is listed twice (RCCL: one rank per GPU; NB_SHARDED_COPY_EXCHANGE lets ranks share a GPU)");
     }
     nb_sharded* s = new (std::nothrow) nb_sharded();
@@ -500,7 +534,7 @@ int create_impl(nb_sharded** out, const int* devices, int n_devices, int64_t n, 
     s->G = G;
     s->eps = eps;
     s->dt = dt;
-    if (!copy_exchange(s)) {
+    if (uses_rccl(s)) {
         s->api = rccl(s->err, sizeof s->err);
         if (!s->api) return NB_ERR_HIP;
     }
@@ -510,7 +544,8 @@ int create_impl(nb_sharded** out, const int* devices, int n_devices, int64_t n, 
         // or the two-phase step, which cuts the sources of K1 into ranges)
         int cus0 = 256;
         if (hipDeviceGetAttribute(&cus0, hipDeviceAttributeMultiprocessorCount, devices[0]) != hipSuccess) cus0 = 256;
-        s->sym = !(flags & NB_SHARDED_ORDERED_PAIRS) && !overlapped(s) && sym_sharded_ok(n, n_devices, cus0, acc64(s), &s->shape);
+        s->sym = !(flags & NB_SHARDED_ORDERED_PAIRS) && !overlapped(s) && !host_exchange(s) &&
+                 sym_sharded_ok(n, n_devices, cus0, acc64(s), &s->shape);
     }
     for (int r = 0; r < n_devices; ++r) {
         Rank& k = s->rank[(size_t)r];
@@ -585,7 +620,10 @@ int create_impl(nb_sharded** out, const int* devices, int n_devices, int64_t n, 
         SH_HIP(s, hipSetDevice(k.device));
         if (k.ws_bytes && !k.ws) SH_HIP(s, hipMalloc(&k.ws, k.ws_bytes));
     }
-    if (copy_exchange(s)) {
+    if (host_exchange(s)) {
+        // one pinned array per ping-pong side, visible to every device's copy engine
+        for (float4*& h : s->host_stage) SH_HIP(s, hipHostMalloc((void**)&h, N * sizeof(float4), hipHostMallocPortable));
+    } else if (copy_exchange(s)) {
         // direct xGMI copies between distinct GPUs; without peer access the runtime stages through the host, which is
         // slower but still correct, so a refusal here is not an error
         for (Rank& q : s->rank)
@@ -825,8 +863,8 @@ int nb_sharded_rank_info(const nb_sharded* cs, int rank, nb_sharded_rank* out) {
     out->compute_units = k.n_cus;
     out->first_target = k.lo;
     out->targets = s->per;
-    if (copy_exchange(s)) {
-        out->exchange = NB_EXCHANGE_COPY;
+    if (copy_exchange(s) || host_exchange(s)) {
+        out->exchange = host_exchange(s) ? NB_EXCHANGE_HOST : NB_EXCHANGE_COPY;
         out->comm_ranks = s->P;
         out->comm_rank = rank;
         out->comm_device = k.device;

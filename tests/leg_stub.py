@@ -7,6 +7,7 @@ code — it only plays the ways a real leg can end, chosen by the leg's own argu
     ordered pairs over nccl / gloo          completes
     copy exchange, shared pairs             prints the line of its timed region, then hangs in its diagnostics
     copy exchange, ordered pairs            completes
+    host-staged exchange                    completes
 """
 import json
 import os

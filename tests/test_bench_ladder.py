@@ -99,6 +99,7 @@ def test_native_spelling_walks_the_ladder_to_the_copy_exchange():
     assert b["timeout"].startswith("killed after 4") and c["ok"] and c["diagnostics_incomplete"]  # (the stub hangs after its line)
     # the forms that were not needed for the measurement ran afterwards, bounded, as variants
     assert r["variants"]["ordered_pairs_copy"]["value"] == 1.0e12 + 5 and "ordered_pairs_copy_overlap" in r["variants"]
+    assert r["variants"]["ordered_pairs_host"]["value"] == 1.0e12 + 5
     assert "replicas" in r and r["wall_s"]["process"] >= r["wall_s"]["timed_region"]
     # asking for a form starts the ladder there; with every leg failing the line still comes, value null, rc 1
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--exchange", "copy", "--ordered-pairs",
@@ -110,7 +111,9 @@ def test_native_spelling_walks_the_ladder_to_the_copy_exchange():
                         "--leg-program", f"{sys.executable} -c raise(SystemExit(9))"], capture_output=True, text=True, timeout=300,
                        env=_env(), cwd=ROOT)
     r = _line(p)
-    assert p.returncode == 1 and r["value"] is None and len(r["legs"]) == 4 and all(x["error"] == "rc=9" for x in r["legs"])
+    assert p.returncode == 1 and r["value"] is None and all(x["error"] == "rc=9" for x in r["legs"])
+    assert [x["name"] for x in r["legs"]] == ["shared_pairs_rccl", "ordered_pairs_rccl", "shared_pairs_copy", "ordered_pairs_copy",
+                                              "ordered_pairs_host"]  # the last resort: no peer-to-peer, no RCCL
 
 
 def _free_port():
@@ -140,3 +143,4 @@ def test_launcher_spelling_parents_walk_the_ladder_together():
     assert r["native_host"]["value"] == 1.0e12 + 6 and r["native_host"]["host"] == "native"
     v = r["variants"]
     assert v["native_ordered_pairs_copy_one_gpu"]["value"] == 1.0e12 + 5 and v["native_shared_pairs_copy_one_gpu"]["value"] == 1.0e12 + 5
+    assert v["native_ordered_pairs_host_one_gpu"]["value"] == 1.0e12 + 5

@@ -290,3 +290,42 @@ def test_the_unordered_pair_step_is_a_preference_not_a_requirement(nb):
         torch.cuda.empty_cache()
     with c.Sharded(n, [0, 0], c.NB_F32, G=syn.G, eps=syn.EPS, dt=1e-2, exchange="copy") as sh:
         assert sh.kernel_name() == "nbody_force_sym_f32<false>" and sh.note == ""
+
+
+# ---------------------------------------------------------------- the host-staged exchange (last resort of the ladder)
+
+@pytest.mark.parametrize("precision", ["NB_F32", "NB_F32_ACC64"])
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_host_staged_exchange_follows_nb_step_and_the_oracle(nb, oracle, ranks, precision):
+    """NB_SHARDED_HOST_EXCHANGE: the all-gather through one pinned host array — D2H of every rank's own slot, a bounded host
+    wait, H2D of the others' — only per-device copies, for a node whose peer-to-peer path is broken.  Ordered pairs (K1).  Same
+    checks as the copy exchange: 3 steps against nb_step, the first against oracle rows of every shard; a system large enough
+    for shared pairs still runs K1 here; the overlapped step is refused."""
+    c, syn = nb.capi, nb.synthetic
+    prec = getattr(c, precision)
+    n, dt = 16384, 1e-2
+    q, v, m = syn.bodies(n)
+    with c.Context(n, prec, 0, G=syn.G, eps=syn.EPS, dt=dt) as ctx:
+        ctx.set_state(q, v, m)
+        ctx.step(1, 3)
+        q_ref, v_ref = ctx.get_state()
+    with c.Sharded(n, [0] * ranks, prec, G=syn.G, eps=syn.EPS, dt=dt, exchange="host", deadline=60.0) as sh:
+        assert sh.rank_info(ranks - 1)["exchange"] == "host" and sh.kernel_name().startswith("nbody_force_f32<")
+        sh.set_state(q, v, m)
+        sh.step(1)
+        q1, v1 = sh.get_state()
+        _, kms = sh.step_profiled(2)
+        q3, v3 = sh.get_state()
+    assert all(k > 0 for k in kms)
+    per = n // ranks
+    rows = [(r * per + off, 8) for r in range(ranks) for off in (0, per // 2 + 3, per - 8)]
+    idx, qo, vo = _oracle_one_step(oracle, syn, q, v, m, dt, rows, f32_start=(precision == "NB_F32"))
+    tol_v, tol_q = (2e-6, 2e-7) if precision == "NB_F32" else (2e-6, 3e-8)
+    assert np.abs(v1[:, idx] - vo).max() < tol_v and np.abs(q1[:, idx] - qo).max() < tol_q
+    assert np.abs(q3 - q_ref).max() < (5e-7 if precision == "NB_F32" else 1e-7) and np.abs(v3 - v_ref).max() < 1e-5
+    assert np.abs(q3 - q).max() > 1e-6
+    with c.Sharded(1 << 17, [0, 0], c.NB_F32, G=syn.G, eps=syn.EPS, dt=dt, exchange="host") as big:
+        assert big.kernel_name().startswith("nbody_force_f32<")  # no shared pairs: a host-side sum of partial forces is not worth it
+    with pytest.raises(c.NBodyError) as e:
+        c.Sharded(n, [0, 0], prec, G=syn.G, eps=syn.EPS, dt=dt, exchange="host", overlap=True)
+    assert e.value.code == c.NB_ERR_INVALID
