@@ -90,7 +90,7 @@ def test_a_refused_rccl_leg_costs_the_leg_not_the_line(nb):
     assert legs[0]["name"] == "shared_pairs_rccl" and not legs[0]["ok"] and legs[0]["error"].startswith("rc=") and legs[0]["stderr_tail"]
     assert "no usable HIP device" in legs[0]["stderr_tail"] or "nccl" in legs[0]["stderr_tail"].lower()
     skipped = [x for x in legs if "skipped" in x]
-    assert {x["name"] for x in skipped} == {"ordered_pairs_rccl", "shared_pairs_copy", "ordered_pairs_copy"}  # need 2 GPUs
+    assert {x["name"] for x in skipped} == {"ordered_pairs_rccl", "shared_pairs_copy", "ordered_pairs_copy", "ordered_pairs_host"}  # need 2 GPUs
     assert r["leg"] == "shared_pairs_copy_one_gpu" and legs[-1]["name"] == r["leg"] and legs[-1]["ok"]
     assert r["exchange"] == "copy-one-gpu" and r["value"] == pytest.approx(131072 * 131071 * 3 / (r["ms_per_step"] * 3e-3), rel=1e-9)
     assert r["parity_spot"]["ok"] and r["parity_spot"]["ranks_covered"] == 2 and r["sharded_check"]["ok"]
