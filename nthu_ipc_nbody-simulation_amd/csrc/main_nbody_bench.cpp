@@ -1,5 +1,5 @@
 // main_nbody_bench.cpp — a compiled host of the C ABI for large N (no Python, no torch):
-//     bin/nbody_bench [N=1048576] [steps=10] [warmup=2] [precision: f32|f32acc64|f64] [gpus=0] [overlap=0] [exchange=rccl] [pairs=shared]
+//     bin/nbody_bench [N=1048576] [steps=10] [warmup=2] [precision: f32|f32acc64|f64] [gpus=0] [overlap=0] [exchange=rccl] [pairs=shared] [deadline_s=0]
 // gpus >= 1 runs the index-sharded stepper (nb_sharded_*: this one process drives GPUs 0..gpus-1; per step the GPUs share
 // the unordered pairs of the system — K1s, one reduce-scatter of partial forces — and all-gather the positions in place;
 // pairs=ordered: every GPU evaluates every ordered pair of its own targets (K1), all-gather only; overlap=1 = two-phase
@@ -36,6 +36,7 @@ int main(int argc, char** argv) {
     const int overlap = argc > 6 ? atoi(argv[6]) : 0;
     const char* exchange = argc > 7 ? argv[7] : "rccl";
     const bool ordered = argc > 8 && !strcmp(argv[8], "ordered");
+    const double deadline = argc > 9 ? atof(argv[9]) : 0.0;  // > 0: every wait of the sharded host bounded (nb_sharded_set_deadline)
     const bool one_gpu = !strcmp(exchange, "copy-one-gpu") || !strcmp(exchange, "host-one-gpu");
     const bool host = !strncmp(exchange, "host", 4);
     const bool copy = !strncmp(exchange, "copy", 4);
@@ -66,6 +67,7 @@ int main(int argc, char** argv) {
         int rc = nb_sharded_create(&sh, devs.data(), gpus, n, cfg.precision, cfg.G, cfg.eps, cfg.dt,
                                    (overlap ? NB_SHARDED_OVERLAP : 0) | (copy ? NB_SHARDED_COPY_EXCHANGE : 0) | (host ? NB_SHARDED_HOST_EXCHANGE : 0) |
                                        (ordered ? NB_SHARDED_ORDERED_PAIRS : 0));
+        if (!rc && deadline > 0) rc = nb_sharded_set_deadline(sh, deadline);
         if (!rc) rc = nb_sharded_set_state(sh, &q[0], &q[n], &q[2 * n], &v[0], &v[n], &v[2 * n], m.data());
         if (!rc && warmup > 0) rc = nb_sharded_step(sh, warmup);
         double ms = 0;

@@ -204,7 +204,9 @@ def test_compiled_host_runs_the_sharded_path(nb):
 @pytest.mark.parametrize("args", [["16384", "3", "1", "f32", "4", "1", "copy-one-gpu"], ["16384", "2", "1", "f32acc64", "2", "0", "copy-one-gpu"],
                                   ["16384", "2", "0", "f32", "1", "0", "rccl"],
                                   ["131072", "2", "1", "f32acc64", "4", "0", "copy-one-gpu"],   # the ranks share the unordered pairs
-                                  ["131072", "2", "0", "f32", "1", "0", "rccl"]])              # K1s on one GPU through RCCL's rank-1 path
+                                  ["131072", "2", "0", "f32", "1", "0", "rccl"],               # K1s on one GPU through RCCL's rank-1 path
+                                  ["16384", "40", "1", "f32", "2", "0", "copy-one-gpu", "shared", "60"],   # bounded waits: the ring of 16 steps lapped
+                                  ["16384", "3", "1", "f32acc64", "4", "0", "host-one-gpu", "ordered", "60"]])  # host-staged exchange
 def test_sharded_host_under_host_asan(nb, args):
     """bin/asan/nbody_bench (`make asan`): the multi-GPU host — per-rank streams and events, phased launches, the copy
     exchange, the RCCL path with one rank — compiled with AddressSanitizer + UBSan (device code: the plain gfx950 build), on the GPU."""
