@@ -82,15 +82,26 @@ def test_ragged_and_tiny_sizes(nb, oracle):
         assert _close(q, ref.q, 1e-12) and _close(v, ref.v, 1e-12), n
 
 
-def test_eps_zero_self_pair_is_skipped(nb, oracle):
+@pytest.mark.parametrize("eps", [0.0, 1e-100, 1e-85, 1e-70])
+def test_eps_zero_self_pair_is_skipped(nb, oracle, eps):
+    """The fp64 kernels drop the `j == i` compare when the self pair adds +0 by itself: 0 * G*m*(eps^2)^-1.5, finite only for
+    eps^2 >= 1e-160 (masses up to 1e37 kg here).  Below that — eps = 0 as the reference allows (nbody.cc:59), and tiny non-zero
+    values, which round 4 sent down the fast path to 0 * inf = NaN — the instantiation that skips the self pair explicitly runs
+    (round 5).  Per-step kernel (K2) and the persistent one (K3)."""
     s = oracle.read_input(case_path("b20", "in"))
-    p = oracle.make_params(eps=0.0)
+    p = oracle.make_params(eps=eps)
     ref = s.copy()
     oracle.run_steps(ref, 1, 2, params=p)
-    with _ctx(nb, s, eps=0.0) as ctx:
+    with _ctx(nb, s, eps=eps) as ctx:
         ctx.step(1, 2)
         q, v = ctx.get_state()
     assert np.isfinite(q).all() and _close(q, ref.q, 1e-12) and _close(v, ref.v, 1e-12)
+    with _ctx(nb, s, eps=eps) as ctx:  # K3: 50 steps of the min-distance scenario inside one launch
+        r = ctx.run_scenario(nb.capi.NB_SCN_MIN_DIST, s.planet, s.asteroid, first_step=0, last_step=50, engine=2)
+        q3, _ = ctx.get_state()
+    ref3 = s.copy()
+    oracle.run_steps(ref3, 1, 50, params=p)
+    assert r["steps_done"] == 50 and np.isfinite(q3).all() and _close(q3, ref3.q, 1e-11)
 
 
 def test_bitwise_reproducible(nb, oracle):
