@@ -169,12 +169,14 @@ def _two_gpus(nb):
 
 @pytest.mark.parametrize("n", [32768, 262144])  # ordered pairs (K1) / the GPUs share the unordered pairs (K1s + reduce-scatter)
 @pytest.mark.parametrize("overlap", [False, True])
-@pytest.mark.parametrize("exchange", ["copy", "rccl"])
+@pytest.mark.parametrize("exchange", ["copy", "rccl", "host"])
 def test_two_distinct_gpus_follow_nb_step(nb, oracle, exchange, overlap, n):
     """Devices [0, 1]: peer copies over xGMI / a two-rank RCCL all-gather (and, at 262144 bodies, reduce-scatter of the
     partial forces), plain and overlapped, against nb_step and oracle rows from both shards.  NOT EXECUTED on the builder's
     one-GPU boxes."""
     _two_gpus(nb)
+    if exchange == "host" and overlap:
+        pytest.skip("the host-staged exchange is not overlapped")
     from test_gpu_sharded_native import _oracle_one_step
     c, syn = nb.capi, nb.synthetic
     dt = 1e-2
@@ -206,3 +208,19 @@ def test_reference_mode_on_two_distinct_gpus(nb):
     import bench
     r = bench.replicas_check([0, 1])
     assert r["b1024"]["byte_identical"] and r["b200"]["byte_identical"], r
+
+
+def test_ladder_on_two_distinct_gpus(nb):
+    """`python3 bench.py --gpus 2` on two real GPUs: the first leg — shared pairs, ncclReduceScatter + ncclAllGather over two
+    ranks — should simply work; whatever it does, the line must come, prove itself against the oracle, and say which leg it
+    is.  NOT EXECUTED on the builder's one-GPU boxes."""
+    _two_gpus(nb)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--bodies", "262144", "--steps", "3",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=1200, env=_env(), cwd=ROOT)
+    r = _line(p)
+    assert r["value"] > 0 and r["parity_spot"]["ok"] and r["ranks"]["distinct_devices"] == 2 and "rehearsal" not in r
+    assert r["leg"] in [x["name"] for x in r["legs"] if x.get("ok")]
+    if r["leg"] == "shared_pairs_rccl":
+        assert r["ranks"]["comm_ranks_seen_by_every_rank"] == [2] and r["roofline"]["kernel"] == "nbody_force_sym_f32<false>"
+    for name in ("ordered_pairs_rccl", "shared_pairs_copy", "ordered_pairs_copy", "ordered_pairs_host"):
+        assert name in r["variants"] or name == r["leg"] or name in [x["name"] for x in r["legs"]]
