@@ -144,3 +144,47 @@ def test_launcher_spelling_parents_walk_the_ladder_together():
     v = r["variants"]
     assert v["native_ordered_pairs_copy_one_gpu"]["value"] == 1.0e12 + 5 and v["native_shared_pairs_copy_one_gpu"]["value"] == 1.0e12 + 5
     assert v["native_ordered_pairs_host_one_gpu"]["value"] == 1.0e12 + 5
+
+
+def test_leg_lists_for_the_requests_a_user_can_make():
+    """Which legs, in which order, for which command line — no process is started."""
+    import argparse
+    bench = _bench()
+
+    def names(legs):
+        return [(lg["name"], "skip" in lg) for lg in legs]
+
+    def A(**kw):
+        d = dict(gpus=8, exchange=None, ordered_pairs=False, overlap=False, backend="nccl", single_device=False)
+        d.update(kw)
+        return argparse.Namespace(**d)
+
+    # the default on a full node: shared pairs over RCCL first, north_star's scheme second, then no RCCL, then no peer-to-peer
+    assert names(bench.native_legs(A(), 8)) == [("shared_pairs_rccl", False), ("ordered_pairs_rccl", False), ("shared_pairs_copy", False),
+                                                ("ordered_pairs_copy", False), ("ordered_pairs_host", False)]
+    # a request moves to the front; nothing is tried twice
+    assert [n for n, _ in names(bench.native_legs(A(exchange="copy", ordered_pairs=True), 8))] == \
+        ["ordered_pairs_copy", "shared_pairs_rccl", "ordered_pairs_rccl", "shared_pairs_copy", "ordered_pairs_host"]
+    # the two-phase step runs the ordered-pair kernel and is not host-staged
+    assert [n for n, _ in names(bench.native_legs(A(overlap=True), 8))] == ["ordered_pairs_rccl_overlap", "ordered_pairs_copy_overlap"]
+    # fewer GPUs than ranks: the request runs (and fails by itself), the other distinct-device legs are skipped, the rehearsal forms follow
+    assert names(bench.native_legs(A(), 1)) == [("shared_pairs_rccl", False), ("ordered_pairs_rccl", True), ("shared_pairs_copy", True),
+                                                ("ordered_pairs_copy", True), ("ordered_pairs_host", True),
+                                                ("shared_pairs_copy_one_gpu", False), ("ordered_pairs_copy_one_gpu", False),
+                                                ("ordered_pairs_host_one_gpu", False)]
+    assert [n for n, _ in names(bench.native_legs(A(exchange="host-one-gpu"), 1))] == ["ordered_pairs_host_one_gpu", "shared_pairs_copy_one_gpu",
+                                                                                     "ordered_pairs_copy_one_gpu"]
+    # under the launcher: the torch host's two forms, then the native host without RCCL run by rank 0
+    t = bench.torch_legs(A(), 8, 8)
+    assert [(lg["name"], lg["host"]) for lg in t] == [("shared_pairs_nccl", "torch"), ("ordered_pairs_nccl", "torch"),
+                                                      ("native_shared_pairs_copy", "native"), ("native_ordered_pairs_copy", "native"),
+                                                      ("native_ordered_pairs_host", "native")]
+    assert [lg["name"] for lg in bench.torch_legs(A(exchange="ring"), 8, 8)] == ["ordered_pairs_nccl_ring"]
+    assert [lg["name"] for lg in bench.torch_legs(A(backend="gloo", single_device=True, gpus=2), 2, 1)] == \
+        ["shared_pairs_gloo", "ordered_pairs_gloo", "native_shared_pairs_copy_one_gpu", "native_ordered_pairs_copy_one_gpu",
+         "native_ordered_pairs_host_one_gpu"]
+    import pytest
+    with pytest.raises(SystemExit):
+        bench.native_legs(A(exchange="ring"), 8)
+    with pytest.raises(SystemExit):
+        bench.native_legs(A(exchange="host", overlap=True), 8)
