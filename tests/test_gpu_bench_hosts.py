@@ -224,3 +224,23 @@ def test_ladder_on_two_distinct_gpus(nb):
         assert r["ranks"]["comm_ranks_seen_by_every_rank"] == [2] and r["roofline"]["kernel"] == "nbody_force_sym_f32<false>"
     for name in ("ordered_pairs_rccl", "shared_pairs_copy", "ordered_pairs_copy", "ordered_pairs_host"):
         assert name in r["variants"] or name == r["leg"] or name in [x["name"] for x in r["legs"]]
+
+
+def test_a_wedged_exchange_ends_its_leg_with_a_message(nb):
+    """What a collective that never completes looks like from the outside, produced here by an allowance no step can meet
+    (--deadline 1e-4 s for steps of milliseconds): every leg's child gives up by ITSELF — "exchange timed out" from the native
+    host's bounded waits, rc != 0, within seconds, not at the leg's time limit — the ladder walks on, and with every leg
+    failing the line still comes: value null, the legs recorded, rc 1."""
+    import time
+    t0 = time.perf_counter()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--exchange", "copy-one-gpu", "--bodies", "262144",
+                        "--steps", "3", "--warmup", "1", "--deadline", "1e-4", "--leg-timeout", "120"], capture_output=True, text=True,
+                       timeout=600, env=_env(), cwd=ROOT)
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert p.returncode == 1 and len(lines) == 1, (p.returncode, p.stdout[-500:], p.stderr[-2000:])
+    r = json.loads(lines[0])
+    assert r["value"] is None and r["error"] == "every leg of the ladder failed"
+    assert [x["name"] for x in r["legs"]] == ["shared_pairs_copy_one_gpu", "ordered_pairs_copy_one_gpu", "ordered_pairs_host_one_gpu"]
+    for leg in r["legs"]:
+        assert leg["error"].startswith("rc=") and "timed out after 0.0001 s" in leg["stderr_tail"] and leg["seconds"] < 60, leg
+    assert time.perf_counter() - t0 < 150
