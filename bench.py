@@ -943,7 +943,17 @@ def orchestrate_torch(args, world):
     if args.exchange in NATIVE_EXCHANGES:
         raise SystemExit(f"--exchange {args.exchange} belongs to the native host (run without a launcher)")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=max(1800.0, 4 * args.legs_budget)))
+    try:
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=max(1800.0, 4 * args.legs_budget)))
+    except Exception as e:  # noqa: BLE001
+        # the parents cannot even form their host-side group (the launcher's store is unreachable): the torch legs need it,
+        # the native host does not — rank 0 walks the native ladder alone (one process for all GPUs), the others step aside
+        print(f"[bench] rank {rank}: no host-side group among the parents ({type(e).__name__}: {e}); "
+              + ("rank 0 runs the native host's ladder alone" if rank == 0 else "leaving the GPUs to rank 0"), file=sys.stderr, flush=True)
+        if rank != 0:
+            return
+        args.exchange = None
+        return orchestrate_native(args)
     log = (lambda msg: print(f"[bench] {msg}", file=sys.stderr, flush=True)) if rank == 0 else None
 
     def bcast(x):
