@@ -244,3 +244,26 @@ def test_a_wedged_exchange_ends_its_leg_with_a_message(nb):
     for leg in r["legs"]:
         assert leg["error"].startswith("rc=") and "timed out after 0.0001 s" in leg["stderr_tail"] and leg["seconds"] < 60, leg
     assert time.perf_counter() - t0 < 150
+
+
+def test_launcher_spelling_survives_refused_nccl_legs(nb):
+    """The driver's form on a box with ONE GPU and the real backend: `torch.distributed.run --nproc-per-node 2 bench.py --gpus 2`
+    (nccl).  Rank 1's child has no device 1 and dies; rank 0's child would wait in the rendezvous for ever and is stopped early
+    by its parent; both torch legs end that way.  The ladder goes on to the native host without RCCL — rank 0's parent alone,
+    copy exchange, all ranks on GPU 0 — and rank 0 prints that line: rc 0."""
+    import time
+    if nb.capi.device_count() != 1:
+        pytest.skip("a one-GPU box: the natural failure of the nccl legs")
+    t0 = time.perf_counter()
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--bodies", "131072", "--steps", "3", "--warmup", "1", "--no-diagnostics"],
+                       capture_output=True, text=True, timeout=900, env=_env(), cwd=ROOT)
+    r = _line(p)
+    names = [x["name"] for x in r["legs"]]
+    assert names == ["shared_pairs_nccl", "ordered_pairs_nccl", "native_shared_pairs_copy_one_gpu"], names
+    for leg in r["legs"][:2]:
+        assert not leg["ok"] and ("rank 1" in leg["stderr_tail"] or leg.get("error", "").startswith("rc=")), leg
+        assert leg["seconds"] < 120, leg  # stopped early, not at the 240 s limit
+    assert r["leg"] == "native_shared_pairs_copy_one_gpu" and r["host"] == "native" and r["parity_spot"]["ok"] and "rehearsal" in r
+    assert time.perf_counter() - t0 < 400
