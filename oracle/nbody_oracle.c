@@ -61,28 +61,43 @@ void orc_effective_mass(int step, int n, const double* m, const uint8_t* is_devi
  * to scale fp32 tolerances (the net force on a uniform cloud cancels heavily).
  * Rows are independent, so the OpenMP split over i does not change any bit of the result.
  */
+static inline void accel_row(int n, const double* qx, const double* qy, const double* qz, const double* m_eff, double G,
+                             double eps, int i, double* ax, double* ay, double* az, double* abs_sum) {
+    double sx = 0, sy = 0, sz = 0, sa = 0;
+    for (int j = 0; j < n; j++) {
+        if (j == i) continue;
+        double mj = m_eff[j];
+        double dx = qx[j] - qx[i];
+        double dy = qy[j] - qy[i];
+        double dz = qz[j] - qz[i];
+        double dist3 = pow(dx * dx + dy * dy + dz * dz + eps * eps, 1.5);
+        sx += G * mj * dx / dist3;
+        sy += G * mj * dy / dist3;
+        sz += G * mj * dz / dist3;
+        if (abs_sum) sa += G * mj * sqrt(dx * dx + dy * dy + dz * dz) / dist3;
+    }
+    *ax = sx;
+    *ay = sy;
+    *az = sz;
+    if (abs_sum) *abs_sum = sa;
+}
+
 void orc_accel_rows(int n, const double* qx, const double* qy, const double* qz, const double* m_eff, double G,
                     double eps, int i0, int i1, double* ax, double* ay, double* az, double* abs_sum) {
 #pragma omp parallel for schedule(static) if ((long)(i1 - i0) * n >= 65536) /* tiny systems: fork/join costs more than the rows */
-    for (int i = i0; i < i1; i++) {
-        double sx = 0, sy = 0, sz = 0, sa = 0;
-        for (int j = 0; j < n; j++) {
-            if (j == i) continue;
-            double mj = m_eff[j];
-            double dx = qx[j] - qx[i];
-            double dy = qy[j] - qy[i];
-            double dz = qz[j] - qz[i];
-            double dist3 = pow(dx * dx + dy * dy + dz * dz + eps * eps, 1.5);
-            sx += G * mj * dx / dist3;
-            sy += G * mj * dy / dist3;
-            sz += G * mj * dz / dist3;
-            if (abs_sum) sa += G * mj * sqrt(dx * dx + dy * dy + dz * dz) / dist3;
-        }
-        ax[i - i0] = sx;
-        ay[i - i0] = sy;
-        az[i - i0] = sz;
-        if (abs_sum) abs_sum[i - i0] = sa;
-    }
+    for (int i = i0; i < i1; i++)
+        accel_row(n, qx, qy, qz, m_eff, G, eps, i, ax + (i - i0), ay + (i - i0), az + (i - i0), abs_sum ? abs_sum + (i - i0) : NULL);
+}
+
+/*
+ * The same for an arbitrary LIST of target rows (the spot checks of large systems take a few rows from every shard): row r of
+ * the outputs belongs to target rows[r].  The same per-row loop, so every bit equals orc_accel_rows'; OpenMP over the list.
+ */
+void orc_accel_rows_at(int n, const double* qx, const double* qy, const double* qz, const double* m_eff, double G, double eps,
+                       const int* rows, int k, double* ax, double* ay, double* az, double* abs_sum) {
+#pragma omp parallel for schedule(dynamic, 1) if ((long)k * n >= 65536)
+    for (int r = 0; r < k; r++)
+        accel_row(n, qx, qy, qz, m_eff, G, eps, rows[r], ax + r, ay + r, az + r, abs_sum ? abs_sum + r : NULL);
 }
 
 /*

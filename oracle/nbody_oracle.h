@@ -43,6 +43,9 @@ double orc_missile_cost(double t);
 void orc_effective_mass(int step, int n, const double* m, const uint8_t* is_device, double dt, double* m_eff);
 void orc_accel_rows(int n, const double* qx, const double* qy, const double* qz, const double* m_eff, double G,
                     double eps, int i0, int i1, double* ax, double* ay, double* az, double* abs_sum);
+/* the same for a list of target rows: outputs[r] belongs to rows[r]; bit-identical per row, OpenMP over the list */
+void orc_accel_rows_at(int n, const double* qx, const double* qy, const double* qz, const double* m_eff, double G, double eps,
+                       const int* rows, int k, double* ax, double* ay, double* az, double* abs_sum);
 void orc_run_step(int step, int n, double* qx, double* qy, double* qz, double* vx, double* vy, double* vz,
                   const double* m, const uint8_t* is_device, const orc_params* p, double* scratch);
 int orc_read_input(const char* filename, orc_system* s);

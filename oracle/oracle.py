@@ -70,6 +70,8 @@ def lib(omp=False):
         L.orc_effective_mass.argtypes = [C.c_int, C.c_int, _dp, _u8p, C.c_double, _dp]
         L.orc_accel_rows.argtypes = [C.c_int, _dp, _dp, _dp, _dp, C.c_double, C.c_double, C.c_int, C.c_int,
                                      _dp, _dp, _dp, _dp]
+        L.orc_accel_rows_at.argtypes = [C.c_int, _dp, _dp, _dp, _dp, C.c_double, C.c_double, C.POINTER(C.c_int), C.c_int,
+                                        _dp, _dp, _dp, _dp]
         L.orc_run_step.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _u8p,
                                    C.POINTER(OrcParams), _dp]
         L.orc_read_input.argtypes = [C.c_char_p, C.POINTER(OrcSystem)]
@@ -145,6 +147,20 @@ def accel_rows(q, m_eff, G, eps, i0=0, i1=None, want_abs=False, omp=True):
     ab = np.empty(i1 - i0) if want_abs else None
     lib(omp).orc_accel_rows(n, _dptr(q[0]), _dptr(q[1]), _dptr(q[2]), _dptr(m_eff), G, eps, i0, i1,
                             _dptr(a[0]), _dptr(a[1]), _dptr(a[2]), _dptr(ab) if want_abs else None)
+    return (a, ab) if want_abs else a
+
+
+def accel_rows_at(q, m_eff, G, eps, rows, want_abs=False, omp=True):
+    """Accelerations of the target rows listed in `rows` (any order), fp64, reference arithmetic — row r of the result belongs
+    to rows[r]; every bit as accel_rows gives for that row, all rows in one call (OpenMP over the list)."""
+    n = q.shape[1]
+    idx = np.ascontiguousarray(rows, dtype=np.int32)
+    assert idx.ndim == 1 and (idx >= 0).all() and (idx < n).all()
+    a = np.empty((3, len(idx)))
+    ab = np.empty(len(idx)) if want_abs else None
+    lib(omp).orc_accel_rows_at(n, _dptr(q[0]), _dptr(q[1]), _dptr(q[2]), _dptr(m_eff), G, eps,
+                               idx.ctypes.data_as(C.POINTER(C.c_int)), len(idx), _dptr(a[0]), _dptr(a[1]), _dptr(a[2]),
+                               _dptr(ab) if want_abs else None)
     return (a, ab) if want_abs else a
 
 

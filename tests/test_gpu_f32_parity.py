@@ -26,12 +26,11 @@ def _accel_err(nb, oracle, n, precision, rows=None):
             assert not a.any()
             return 0.0, a, m
         return (np.abs(a - ref).max(axis=0) / s).max(), a, m
-    worst = 0.0
-    for i in rows:  # an int = one target row, a (first, count) pair = a block of consecutive rows (OpenMP over its rows)
-        i0, cnt = (int(i), 1) if np.ndim(i) == 0 else (int(i[0]), int(i[1]))
-        ref, s = oracle.accel_rows(q32, gm, syn.G, syn.EPS, i0, i0 + cnt, want_abs=True)
-        worst = max(worst, (np.abs(a[:, i0:i0 + cnt] - ref).max(axis=0) / s).max())
-    return worst, a, m
+    # an int = one target row, a (first, count) pair = a block of consecutive rows; all of them in ONE oracle call (its per-row
+    # loop, OpenMP over the list)
+    idx = np.concatenate([np.arange(int(i), int(i) + 1) if np.ndim(i) == 0 else np.arange(int(i[0]), int(i[0]) + int(i[1])) for i in rows])
+    ref, s = oracle.accel_rows_at(q32, gm, syn.G, syn.EPS, idx, want_abs=True)
+    return (np.abs(a[:, idx] - ref).max(axis=0) / s).max(), a, m
 
 
 @pytest.mark.parametrize("n", [1, 2, 255, 256, 257, 1000, 4096, 16384 + 77])
@@ -186,15 +185,11 @@ def test_fp32_rejects_eps_zero_and_devices(nb):
 # A rank of P = 8 holds all n_src sources and owns n_tgt = n_src / 8 targets starting at tgt_off = rank * n_tgt.
 
 def _oracle_rows(oracle, syn, pos, rows):
-    """fp64 reference accelerations + sum of magnitudes for single target rows, from the fp32 records the GPU sees."""
+    """fp64 reference accelerations + sum of magnitudes for single target rows, from the fp32 records the GPU sees (all rows
+    in one call: the oracle's per-row loop, OpenMP over the list)."""
     q32 = np.ascontiguousarray(pos[:, :3].T.astype(np.float64))
     gm = pos[:, 3].astype(np.float64) / syn.G
-    ref = np.empty((3, len(rows)))
-    s = np.empty(len(rows))
-    for c, i in enumerate(rows):
-        r, ab = oracle.accel_rows(q32, gm, syn.G, syn.EPS, int(i), int(i) + 1, want_abs=True)
-        ref[:, c], s[c] = r[:, 0], ab[0]
-    return ref, s
+    return oracle.accel_rows_at(q32, gm, syn.G, syn.EPS, [int(i) for i in rows], want_abs=True)
 
 
 def _check_step_rows(pos, vel0, out, vel1, rows, off, ref, s, dt, tol):

@@ -46,9 +46,8 @@ def _oracle_one_step(oracle, syn, q, v, m, dt, rows, f32_start):
     q0 = q.astype(np.float32).astype(np.float64) if f32_start else q
     v0 = v.astype(np.float32).astype(np.float64) if f32_start else v
     # sources are always the fp32-rounded positions (also in NB_F32_ACC64: the pair loop reads the float4 copies)
-    a = np.concatenate([oracle.accel_rows(q.astype(np.float32).astype(np.float64), gm, syn.G, syn.EPS, lo, lo + cnt)
-                        for lo, cnt in rows], axis=1)
     idx = np.concatenate([np.arange(lo, lo + cnt) for lo, cnt in rows])
+    a = oracle.accel_rows_at(np.ascontiguousarray(q.astype(np.float32).astype(np.float64)), gm, syn.G, syn.EPS, idx)
     v1 = v0[:, idx] + a * dt
     return idx, q0[:, idx] + v1 * dt, v1
 

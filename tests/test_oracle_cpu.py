@@ -124,3 +124,20 @@ def test_host_code_under_sanitizers(tmp_path):
                        capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
     assert p.returncode == 0, p.stderr
     assert so.read_text().split("\n")[1:3] == ["2506", "2 4.0000000000000000e+05"]
+
+
+def test_row_list_entry_equals_the_row_range_entry_bitwise(oracle):
+    """orc_accel_rows_at (a list of target rows in one call, OpenMP over the list: what the spot checks of large systems use)
+    runs the very per-row loop of orc_accel_rows: every bit equal, with and without OpenMP, in any order of the list."""
+    import numpy as np
+    rng = np.random.default_rng(3)
+    n = 3000
+    q = np.ascontiguousarray(rng.uniform(-1, 1, (3, n)))
+    m = rng.uniform(0.5, 1.5, n)
+    rows = [n - 1, 0, 17, 17, 1234, n // 2]
+    for omp in (False, True):
+        a, ab = oracle.accel_rows_at(q, m, 6.674e-11, 1e-3, rows, want_abs=True, omp=omp)
+        for k, i in enumerate(rows):
+            r, s = oracle.accel_rows(q, m, 6.674e-11, 1e-3, i, i + 1, want_abs=True, omp=False)
+            assert np.array_equal(r[:, 0], a[:, k]) and s[0] == ab[k]
+    assert np.array_equal(oracle.accel_rows_at(q, m, 6.674e-11, 1e-3, rows), a)
