@@ -51,6 +51,8 @@ bool trace_enabled() {
 
 namespace {
 
+constexpr size_t STAGE_MAX_N = 65536;  // fp64 contexts up to this size move their state through one host staging block
+
 void release(nb_context* c) {
     free_dev(c->arena);  // q, v, m, coef, acc, mon, done_dev, ctl
     free_dev(c->snap_q); free_dev(c->snap_v); free_dev(c->fst_dev); free_dev(c->fst_chunk); free_dev(c->stamps);
@@ -369,6 +371,22 @@ static int nb_set_state_impl(nb_context* c, const double* qx, const double* qy, 
         double* q = c->q[0];
         c->cur = 0;
         const size_t B = n * sizeof(double);
+        if (n <= STAGE_MAX_N) {
+            // small systems (the testcases; a caller that round-trips the state every step): a transfer
+            // costs ~6 us whatever its size, so the eight arrays travel as the three contiguous ranges of the arena they fill
+            // — [q0: x y z], [v: x y z], [m, coef] — from one host staging block: 3 copies instead of 8
+            std::vector<double>& st = c->stage_host;
+            st.resize(8 * n);
+            memcpy(&st[0], qx, B); memcpy(&st[n], qy, B); memcpy(&st[2 * n], qz, B);
+            memcpy(&st[3 * n], vx, B); memcpy(&st[4 * n], vy, B); memcpy(&st[5 * n], vz, B);
+            memcpy(&st[6 * n], m, B); memcpy(&st[7 * n], coef.data(), B);
+            NB_HIP(c, hipMemcpyAsync(q, &st[0], 3 * B, hipMemcpyHostToDevice, c->stream));
+            NB_HIP(c, hipMemcpyAsync(c->v, &st[3 * n], 3 * B, hipMemcpyHostToDevice, c->stream));
+            NB_HIP(c, hipMemcpyAsync(c->m, &st[6 * n], 2 * B, hipMemcpyHostToDevice, c->stream));  // coef sits right behind m
+            NB_HIP(c, hipStreamSynchronize(c->stream));
+            c->have_state = true;
+            return NB_OK;
+        }
         NB_HIP(c, hipMemcpyAsync(q, qx, B, hipMemcpyHostToDevice, c->stream));
         NB_HIP(c, hipMemcpyAsync(q + n, qy, B, hipMemcpyHostToDevice, c->stream));
         NB_HIP(c, hipMemcpyAsync(q + 2 * n, qz, B, hipMemcpyHostToDevice, c->stream));
@@ -414,6 +432,16 @@ static int nb_get_state_impl(nb_context* c, double* qx, double* qy, double* qz, 
     if (c->cfg.precision == NB_F64) {
         const double* q = c->q[c->cur];
         const size_t B = n * sizeof(double);
+        if (n <= STAGE_MAX_N) {  // as nb_set_state: the two contiguous ranges q[cur], v in 2 copies instead of 6
+            std::vector<double>& st = c->stage_host;
+            st.resize(8 * n);
+            NB_HIP(c, hipMemcpyAsync(&st[0], q, 3 * B, hipMemcpyDeviceToHost, c->stream));
+            NB_HIP(c, hipMemcpyAsync(&st[3 * n], c->v, 3 * B, hipMemcpyDeviceToHost, c->stream));
+            NB_HIP(c, hipStreamSynchronize(c->stream));
+            memcpy(qx, &st[0], B); memcpy(qy, &st[n], B); memcpy(qz, &st[2 * n], B);
+            memcpy(vx, &st[3 * n], B); memcpy(vy, &st[4 * n], B); memcpy(vz, &st[5 * n], B);
+            return NB_OK;
+        }
         NB_HIP(c, hipMemcpyAsync(qx, q, B, hipMemcpyDeviceToHost, c->stream));
         NB_HIP(c, hipMemcpyAsync(qy, q + n, B, hipMemcpyDeviceToHost, c->stream));
         NB_HIP(c, hipMemcpyAsync(qz, q + 2 * n, B, hipMemcpyDeviceToHost, c->stream));

@@ -66,6 +66,7 @@ struct nb_context {
                                  // allocations instead of ten: nb_solve creates 2 + D of them per program run)
     std::vector<double> m_host;
     std::vector<uint8_t> dev_host;
+    std::vector<double> stage_host;  // NB_F64, n <= 65536: nb_set_state / nb_get_state staging (3 / 2 copies instead of 8 / 6)
 
     // F32 / F32_ACC64: float4 {x,y,z,G*m} ping-pong, float4 velocities, optional double4 masters
     float4* pos[2] = {nullptr, nullptr};
