@@ -137,6 +137,14 @@ int nb_set_mass(nb_context* ctx, int index, double m); /* e.g. Problem 1's m[dev
 /* run_step(step, ...) for step = first_step .. first_step+count-1 (nbody.cc:51-89): accelerations from the old
  * positions, v += a*dt, q += v*dt.  The step index feeds the device-mass law m0 + 0.5*m0*|sin(step*dt/6000)|. */
 int nb_step(nb_context* ctx, int first_step, int count);
+/* run_step(step, n, qx, qy, qz, vx, vy, vz, m, type) itself — samples/nbody.cc:51-54, the call main() makes at nbody.cc:116,129 —
+ * as ONE entry: the state in the caller's seven arrays goes to the GPU, step `step` runs, the new q, v come back in place
+ * (m and is_device are only read; is_device may be NULL).  Equal, bit for bit, to nb_set_state + nb_step(ctx, step, 1) +
+ * nb_get_state, with one synchronisation instead of three — and without the upload when the arrays still hold what the
+ * previous nb_run_step returned (the library compares them with its copy of that download; any other call on the context
+ * in between makes it upload again), which is the reference's own loop: ~30 us per step for the testcases instead of ~70 */
+int nb_run_step(nb_context* ctx, int step, double* qx, double* qy, double* qz, double* vx, double* vy, double* vz,
+                const double* m, const uint8_t* is_device /* may be NULL */);
 /* accelerations only (nbody.cc:56-74), no update; outputs double[n] each */
 int nb_accel(nb_context* ctx, int step, double* ax, double* ay, double* az);
 /* as nb_step, and reports the mean GPU time of one step's launches in milliseconds, measured with HIP events

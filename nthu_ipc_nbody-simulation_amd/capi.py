@@ -78,6 +78,7 @@ SYMBOLS = {
     "nb_get_state": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _dp, _dp]),
     "nb_set_mass": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
     "nb_step": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "nb_run_step": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _u8p]),
     "nb_accel": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp]),
     "nb_step_timed": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "nb_run_scenario": (C.c_int, [C.c_void_p, C.POINTER(NbScenario), C.POINTER(NbScenarioResult)]),
@@ -322,6 +323,20 @@ class Context:
 
     def step(self, first_step, count=1):
         _check(lib().nb_step(self._h, first_step, count), "nb_step", self._h)
+
+    def run_step(self, step, qx, qy, qz, vx, vy, vz, m, is_device=None):
+        """nb_run_step: the reference's run_step(step, n, qx, ..., m, type) as one call — the six state vectors (contiguous
+        float64 arrays) are updated IN PLACE."""
+        for a in (qx, qy, qz, vx, vy, vz):
+            if not (isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags.c_contiguous and a.shape == (self.n,)):
+                raise ValueError("run_step updates its arrays in place: contiguous float64 arrays of n elements")
+        keep_m = _d(m)
+        dev = None
+        if is_device is not None:
+            dev_arr = np.ascontiguousarray(is_device, dtype=np.uint8)
+            dev = dev_arr.ctypes.data_as(_u8p)
+        ptrs = [a.ctypes.data_as(_dp) for a in (qx, qy, qz, vx, vy, vz)]
+        _check(lib().nb_run_step(self._h, step, *ptrs, keep_m[1], dev), "nb_run_step", self._h)
 
     def step_timed(self, first_step, count):
         ms = C.c_float()

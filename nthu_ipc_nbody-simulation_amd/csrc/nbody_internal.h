@@ -67,6 +67,8 @@ struct nb_context {
     std::vector<double> m_host;
     std::vector<uint8_t> dev_host;
     std::vector<double> stage_host;  // NB_F64, n <= 65536: nb_set_state / nb_get_state staging (3 / 2 copies instead of 8 / 6)
+    bool stage_fresh = false;        // stage_host[0 .. 6n) is what nb_run_step last downloaded AND no other call has touched
+                                     // the context since (every entry point passes through bind(), which clears this)
 
     // F32 / F32_ACC64: float4 {x,y,z,G*m} ping-pong, float4 velocities, optional double4 masters
     float4* pos[2] = {nullptr, nullptr};

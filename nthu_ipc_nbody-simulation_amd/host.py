@@ -65,6 +65,10 @@ def run_step(step, n, qx, qy, qz, vx, vy, vz, m, type, device=0):  # noqa: A002
     ctx = _contexts.get((n, device))
     if ctx is None:
         ctx = _contexts[(n, device)] = capi.Context(n, capi.NB_F64, device)
+    ok = all(isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags.c_contiguous for a in (qx, qy, qz, vx, vy, vz))
+    if ok:  # nb_run_step: one call, in place, no upload when the vectors still hold what the last call returned
+        ctx.run_step(step, qx, qy, qz, vx, vy, vz, m, _is_device(type))
+        return
     ctx.set_state(np.stack([qx, qy, qz]), np.stack([vx, vy, vz]), m, _is_device(type))
     ctx.step(step, 1)
     q, v = ctx.get_state()

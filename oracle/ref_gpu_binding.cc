@@ -40,9 +40,9 @@ void run_step(int step, int n, std::vector<double>& qx, std::vector<double>& qy,
         g_n = n;
         atexit(release);
     }
-    if (nb_set_state(g_ctx, qx.data(), qy.data(), qz.data(), vx.data(), vy.data(), vz.data(), m.data(), dev.data()) ||
-        nb_step(g_ctx, step, 1) ||
-        nb_get_state(g_ctx, qx.data(), qy.data(), qz.data(), vx.data(), vy.data(), vz.data())) {
+    // nb_run_step = nb_set_state + nb_step(step, 1) + nb_get_state in one call (one synchronisation; no upload while the vectors
+    // still hold what the previous call returned, which is what main()'s loops do, nbody.cc:114-122,127-138)
+    if (nb_run_step(g_ctx, step, qx.data(), qy.data(), qz.data(), vx.data(), vy.data(), vz.data(), m.data(), dev.data())) {
         fprintf(stderr, "GPU run_step failed: %s\n", nb_last_error(g_ctx));
         abort();
     }

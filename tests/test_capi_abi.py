@@ -17,7 +17,7 @@ def _declared_symbols(header="nbody_amd.h"):
 # what a caller of run_step needs and nothing else ("thin C-ABI"): lifecycle, state, nb_step / nb_accel,
 # scenarios, nb_solve, state files
 CORE = {"nb_abi_version", "nb_device_count", "nb_config_default", "nb_create", "nb_destroy", "nb_strerror", "nb_last_error",
-        "nb_set_state", "nb_get_state", "nb_set_mass", "nb_step", "nb_accel", "nb_step_timed", "nb_run_scenario",
+        "nb_set_state", "nb_get_state", "nb_set_mass", "nb_step", "nb_run_step", "nb_accel", "nb_step_timed", "nb_run_scenario",
         "nb_run_scenarios_batched", "nb_restore_snapshot", "nb_save_state", "nb_load_state", "nb_state_file_info",
         "nb_read_state_file", "nb_write_state_file", "nb_solve"}
 

@@ -359,3 +359,50 @@ def test_reference_main_drives_the_gpu_step(nb, tmp_path):
     got, gold = out.read_text().split("\n"), open(case_path("b20", "out")).read().split("\n")
     assert got[0] == gold[0] and got[1] == gold[1], (got, gold)
     assert got[2].split()[0] == "-999"
+
+
+@pytest.mark.parametrize("case", ["b20", "b200", "b1024"])
+def test_run_step_entry_equals_set_step_get_bitwise(nb, oracle, case):
+    """nb_run_step — the reference's run_step signature as ONE entry (nbody.cc:51-54) — against nb_set_state + nb_step + nb_get_state
+    on a second context, bit for bit, through a sequence that makes it take every branch: consecutive calls (no upload: the
+    arrays still hold the last download), the caller changing q, then v, then m, then the `device` predicate between calls
+    (uploads again), another call on the context in between (nb_get_state, nb_step: its mirror is stale), and a jump in the
+    step index (the device-mass law, nbody.cc:14-16, follows `step`)."""
+    c = nb.capi
+    s = oracle.read_input(case_path(case, "in"))
+    n = s.n
+    a = [np.ascontiguousarray(x).copy() for x in (s.q[0], s.q[1], s.q[2], s.v[0], s.v[1], s.v[2])]
+    b = [x.copy() for x in a]
+    m, dev = s.m.copy(), s.is_device.copy()
+    with c.Context(n, c.NB_F64, 0) as one, c.Context(n, c.NB_F64, 0) as three:
+        def both(step):
+            one.run_step(step, *a, m, dev)
+            three.set_state(np.stack(b[:3]), np.stack(b[3:]), m, dev)
+            three.step(step, 1)
+            q, v = three.get_state()
+            for k in range(3):
+                b[k][:], b[3 + k][:] = q[k], v[k]
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y), step
+
+        for step in range(1, 6):
+            both(step)
+        a[0][n // 2] *= 1.0 + 1e-9                      # the caller moves a body
+        b[0][n // 2] = a[0][n // 2]
+        both(6)
+        a[4][0] += 1.0                                  # ... kicks one
+        b[4][0] = a[4][0]
+        both(7)
+        m[n - 1] *= 2.0                                 # ... changes a mass (Problem 1 zeroes the devices', nbody.cc:109-113)
+        both(8)
+        if dev.any():
+            dev[np.argmax(dev)] = 0                     # ... and what counts as a device
+            both(9)
+        q_mid, _ = one.get_state()                      # another call on the context: the next run_step must not trust its mirror
+        assert np.array_equal(q_mid[0], a[0])
+        both(10)
+        one.step(11, 1)                                 # the device state moves on without the arrays: they are re-uploaded
+        both(12)
+        both(4321)                                      # |sin(step * dt / 6000)| of a far step
+    ref = oracle.System(n)
+    assert np.isfinite(np.stack(a)).all() and ref.n == n
