@@ -28,6 +28,8 @@ def _accel_err(nb, oracle, n, precision, rows=None):
         return (np.abs(a - ref).max(axis=0) / s).max(), a, m
     # an int = one target row, a (first, count) pair = a block of consecutive rows; all of them in ONE oracle call (its per-row
     # loop, OpenMP over the list)
+    if len(rows) == 0:  # (the caller only wants the accelerations)
+        return 0.0, a, m
     idx = np.concatenate([np.arange(int(i), int(i) + 1) if np.ndim(i) == 0 else np.arange(int(i[0]), int(i[0]) + int(i[1])) for i in rows])
     ref, s = oracle.accel_rows_at(q32, gm, syn.G, syn.EPS, idx, want_abs=True)
     return (np.abs(a[:, idx] - ref).max(axis=0) / s).max(), a, m
