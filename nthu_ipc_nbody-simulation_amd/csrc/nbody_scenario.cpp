@@ -722,6 +722,10 @@ int nb_run_scenario(nb_context* c, const nb_scenario* s, nb_scenario_result* res
 
 int nb_run_scenarios_batched(nb_context** ctxs, const nb_scenario* scns, nb_scenario_result* results, int count) {
     try {
+        // only the leader of the launch stream passes through bind(): every context's state is about to change, so none may
+        // keep treating nb_run_step's last download as a mirror of it
+        for (int k = 0; ctxs && k < count && k < MAX_BATCH; ++k)
+            if (ctxs[k]) ctxs[k]->stage_fresh = false;
         return run_batched_impl(ctxs, scns, results, count);
     } catch (...) {
         return NB_ERR_NOMEM;
