@@ -68,9 +68,16 @@ typedef enum nb_config_flags {
                                 (kernel K1s, 1.35x faster), which needs a pair-slot workspace that grows with n^2 — 12 B x
                                 (n/8192 + 8) per body: 1.7 GB at n = 2^20, 26 GB at 2^22, 52 GB from 2^23 on.  That workspace
                                 is allocated by the FIRST nb_step / nb_accel, not by nb_create; if the device cannot give it
-                                (hipMalloc fails, or it would take more than 3/4 of the free memory) the context falls back to
-                                K1 for its lifetime and nb_last_error(ctx) says so once — it is not an error */
+                                (it would take more than 3/4 of the free memory) the step goes in batches that fit (below), and
+                                if even those do not, or hipMalloc fails, the context falls back to K1 for its lifetime;
+                                nb_last_error(ctx) says so once either way — it is not an error */
 } nb_config_flags;
+/* fp32 modes, OR-ed into nb_config.flags: the caller's own limit for that workspace, in GiB (1..65535; 0 = none).  Within a
+ * limit K1s steps in BATCHES of superblocks — several launches whose reducers add up a running force — instead of one launch:
+ * memory for speed (n = 2^22: 26 GB in one launch, or 8 batches in 6.7 GB about 2 % slower).  Without a limit the library
+ * does the same by itself when the fastest shape would take more than 3/4 of the free device memory; only when not even
+ * batches of 16 superblocks fit does the context fall back to K1 */
+#define NB_CFG_WORKSPACE_GIB(g) (((g) & 0xffff) << 8)
 
 /* scenario drivers — the loops main() runs around run_step */
 typedef enum nb_scenario_kind {

@@ -107,7 +107,9 @@ const char* nb_kernel_name_f32(const nb_launch_f32* a, int accel_only);
 int nb_plan_f32(const nb_launch_f32* a, int* targets_per_lane, int* j_split, int* wg_size);
 /* workspace size that allows source slicing for n_tgt targets: 18 records per target (2 + 16 slots) */
 int64_t nb_workspace_bytes_f32(int64_t n_tgt, int acc64);
-/* workspace size that lets a whole-system launch of n bodies use K1s (source_path 3): three floats per body and
+/* workspace size with which a whole-system launch of n bodies runs K1s (source_path 3) in its FASTEST shape — a smaller one, down
+ * to roughly 50 slots of 12 n bytes, still runs K1s, in batches of superblocks that fit it (about a percent slower per doubling
+ * of the batch count); below that the launch falls to K1.  Three floats per body and
  * superblock round plus three (six with acc64) per workgroup of a superblock — 12 B x (n/8192 + 8) per body: 1.7 GB at
  * n = 2^20, 26 GB at 2^22; larger systems are stepped in batches of superblocks with a running force behind the slots: 52 GB
  * at 2^23 and 2^24, 107 GB at 2^26; 0 = K1s does not apply to this n (fewer than 49152 bodies, or no batch fits 128 GiB) */
@@ -140,6 +142,10 @@ int nb_plan_shared_pairs_f32(int64_t n_src, int ranks, int acc64, int* superbloc
  * Needs no GPU — it is how the 8-GPU shapes are checked on machines that have one or none.  NB_OK, or NB_ERR_STATE with the
  * first inconsistency in msg */
 int nb_selftest_pair_schedule(int64_t n, int n_cus, int ranks, int acc64, char* msg, int msg_len);
+/* the same for ONE GPU whose K1s workspace is limited to workspace_bytes (a raw launch handed a smaller workspace than
+ * nb_workspace_bytes_sym_f32, nb_config's NB_CFG_WORKSPACE_GIB, or a device short of memory): the batches of superblocks chosen
+ * for that budget must cover every pair once and fit it */
+int nb_selftest_pair_schedule_within(int64_t n, int n_cus, int acc64, int64_t workspace_bytes, char* msg, int msg_len);
 
 /* ---- index-sharded multi-GPU stepping: ONE process, P GPUs of a node, RCCL over xGMI (csrc/nbody_sharded.cpp) ----
  * The reference's only multi-GPU use is task parallelism (hw5.cu:564-567,587-588); this is the data-parallel scheme of

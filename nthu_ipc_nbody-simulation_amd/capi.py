@@ -107,6 +107,7 @@ SYMBOLS = {
     "nb_plan_shared_pairs_f32": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "nb_context_kernel_name": (C.c_char_p, [C.c_void_p]),
     "nb_selftest_pair_schedule": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]),
+    "nb_selftest_pair_schedule_within": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_char_p, C.c_int]),
     "nb_sharded_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int64, C.c_int, C.c_double,
                                    C.c_double, C.c_double, C.c_int]),
     "nb_sharded_destroy": (C.c_int, [C.c_void_p]),
@@ -260,12 +261,12 @@ class Context:
     """One nb_context: a system of n bodies resident on one GPU."""
 
     def __init__(self, n, precision=NB_F64, device=0, G=None, eps=None, dt=None, f64_large_min=0, f64_split=0,
-                 cu_mask=NB_CU_ALL, ordered_pairs=False):
+                 cu_mask=NB_CU_ALL, ordered_pairs=False, workspace_gib=0):
         cfg = NbConfig()
         _check(lib().nb_config_default(C.byref(cfg)), "nb_config_default")
         cfg.n, cfg.precision, cfg.device = n, precision, device
         cfg.f64_large_min, cfg.f64_split = f64_large_min, f64_split
-        cfg.flags = NB_CFG_ORDERED_PAIRS if ordered_pairs else 0
+        cfg.flags = (NB_CFG_ORDERED_PAIRS if ordered_pairs else 0) | ((int(workspace_gib) & 0xffff) << 8)  # NB_CFG_WORKSPACE_GIB
         if G is not None:
             cfg.G = G
         if eps is not None:
@@ -626,6 +627,14 @@ def selftest_pair_schedule(n, n_cus=256, ranks=1, acc64=False):
     rc = lib().nb_selftest_pair_schedule(n, n_cus, ranks, int(acc64), buf, len(buf))
     if rc != NB_OK:
         raise NBodyError(rc, "nb_selftest_pair_schedule", buf.value.decode())
+
+
+def selftest_pair_schedule_within(n, workspace_bytes, n_cus=256, acc64=False):
+    """The same for one GPU whose K1s workspace is limited to `workspace_bytes` (batches of superblocks)."""
+    buf = C.create_string_buffer(256)
+    rc = lib().nb_selftest_pair_schedule_within(n, n_cus, int(acc64), int(workspace_bytes), buf, len(buf))
+    if rc != NB_OK:
+        raise NBodyError(rc, "nb_selftest_pair_schedule_within", buf.value.decode())
 
 
 def plan_f32(n_src, n_tgt, acc64=False, targets_per_lane=0, j_split=0, workspace_bytes=0, source_path=0, wg_size=0):

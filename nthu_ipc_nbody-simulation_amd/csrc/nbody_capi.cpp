@@ -155,14 +155,26 @@ F32Args f32_args(nb_context* c) {
 void ensure_sym_workspace(nb_context* c) {
     if (!c->sym_bytes || c->sym_tried) return;
     c->sym_tried = true;
-    const size_t need = std::max(c->partial_bytes, c->sym_bytes);
+    const bool acc64 = c->cfg.precision == NB_F32_ACC64;
+    size_t need = std::max(c->partial_bytes, c->sym_bytes);
     size_t free_b = 0, total_b = 0;
     const bool known = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
     if (!known) (void)hipGetLastError();
     void* ws = nullptr;
     const char* why = nullptr;
-    if (known && (double)need > 0.75 * (double)(free_b + c->partial_bytes)) why = "more than 3/4 of the free device memory";
-    else if (hipMalloc(&ws, need) != hipSuccess) {
+    int batches = 1;
+    const size_t room = known ? (size_t)(0.75 * (double)(free_b + c->partial_bytes)) : need;
+    if (need > room) {
+        // the fastest shape does not fit: the largest batches of superblocks that do (memory for speed, a percent or two)
+        const F32SymBatches kb = sym_batches(c->n, c->n_cus, acc64, room);
+        if (kb.count >= 1 && std::max(c->partial_bytes, kb.bytes) <= room) {
+            need = std::max(c->partial_bytes, kb.bytes);
+            batches = kb.count;
+        } else {
+            why = "more than 3/4 of the free device memory even in batches of 16 superblocks";
+        }
+    }
+    if (!why && hipMalloc(&ws, need) != hipSuccess) {
         (void)hipGetLastError();  // not an error of this context: the fallback below is the answer
         ws = nullptr;
         why = "hipMalloc failed";
@@ -173,10 +185,14 @@ void ensure_sym_workspace(nb_context* c) {
         c->sym_bytes = 0;
         return;
     }
+    if (need < std::max(c->partial_bytes, c->sym_bytes))
+        snprintf(c->err, sizeof c->err, "note: %.1f GB free: the unordered-pair kernel (K1s) steps in %d batches of superblocks with a %.1f GB "
+                 "workspace instead of one launch with %.1f GB", free_b / 1e9, batches, need / 1e9, c->sym_bytes / 1e9);
     (void)hipStreamSynchronize(c->stream);  // nothing in flight may still be reading the slice workspace
     free_dev(c->partial);
     c->partial = ws;
     c->partial_bytes = need;
+    c->sym_bytes = need;
 }
 
 // the context's launch plan: K1s (every unordered pair once) when the system is large enough for it and its workspace
@@ -259,7 +275,7 @@ int nbi::create_context(nb_context** out, const nb_config* cfg, hipStream_t borr
     // fp32 kernels evaluate the self pair as 0 * G*m*eps2^-1.5: eps^2 must be a normal fp32 number with a finite inverse cube
     if (cfg->precision != NB_F64 && !((float)(cfg->eps * cfg->eps) >= F32_EPS2_MIN))
         return set_error(NB_ERR_INVALID, "nb_create: the fp32 modes need eps >= 1e-12");
-    if (cfg->flags & ~NB_CFG_ORDERED_PAIRS) return NB_ERR_INVALID;
+    if (cfg->flags & ~(NB_CFG_ORDERED_PAIRS | NB_CFG_WORKSPACE_GIB(0xffff))) return NB_ERR_INVALID;
     if (cfg->f64_split < 0 || cfg->f64_split > 64 || (cfg->f64_split & (cfg->f64_split - 1))) return NB_ERR_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return NB_ERR_NO_DEVICE;
@@ -335,7 +351,9 @@ int nbi::create_context(nb_context** out, const nb_config* cfg, hipStream_t borr
         if (c->n >= SYM_MIN_N && !(cfg->flags & NB_CFG_ORDERED_PAIRS)) {
             // K1s: a slot per superblock round (1.6 GB at 2^20), in batches beyond 32 GiB of them — wanted, not yet allocated
             // (ensure_sym_workspace, on the first step)
-            const F32SymBatches kb = sym_batches(c->n, c->n_cus, cfg->precision == NB_F32_ACC64);
+            const size_t cap = (size_t)((cfg->flags >> 8) & 0xffff) << 30;  // NB_CFG_WORKSPACE_GIB: the caller's own limit
+            F32SymBatches kb = sym_batches(c->n, c->n_cus, cfg->precision == NB_F32_ACC64);
+            if (cap && kb.count >= 1 && kb.bytes > cap) kb = sym_batches(c->n, c->n_cus, cfg->precision == NB_F32_ACC64, cap);
             if (kb.count >= 1 && kb.bytes <= SYM_MAX_WORKSPACE) c->sym_bytes = kb.bytes;
         }
         if (c->partial_bytes) NB_HIP(c, hipMalloc(&c->partial, c->partial_bytes));

@@ -142,7 +142,12 @@ struct F32SymBatches {
     int count = 0;    // 0: K1s does not apply (too small, or no batch fits SYM_MAX_WORKSPACE)
     size_t bytes = 0;
 };
-F32SymBatches sym_batches(long n, int n_cus, bool acc64);
+// budget = 0: the defaults above (the fastest shape: as few, as large launches as 32 / 64 GiB allow).  budget > 0 (round 5): the
+// workspace the caller actually has — one launch if a slot per round fits it, else the largest batch of whole rounds of
+// workgroups (failing that a half, a quarter ... of the CU count, down to 16 superblocks) whose slots and running force do:
+// memory for speed, about a percent per doubling of the batch count (profiles/r05_workspace_cap_ab.txt); count == 0 if not
+// even 16 superblocks per batch fit
+F32SymBatches sym_batches(long n, int n_cus, bool acc64, size_t budget = 0);
 // a launch that leaves a partial force (mode 2: one rank of a multi-GPU step): its I-superblocks go in sub-launches of
 // sym_sub_batch(s) superblocks when a slot for each of them would not fit SYM_BATCH_WORKSPACE (configs[4] over 8 GPUs: 512
 // superblocks per rank = 103 GB -> 2 x 256 = 52 GB); sym_partial_workspace_bytes = the workspace such a launch needs

@@ -329,6 +329,8 @@ bool plan_symmetric(F32Plan& p, long n_tgt, long n_src, bool whole, size_t works
     if (source_path != 0 && source_path != 3) return false;
     if (!whole || n_tgt != n_src || n_src < SYM_MIN_N) return false;
     F32SymBatches kb = sym_batches(n_src, n_cus, acc64);
+    // a workspace smaller than the fastest shape wants: the batches that fit what the caller has (memory for speed)
+    if (kb.count >= 1 && kb.bytes > workspace_bytes && !force_chunks) kb = sym_batches(n_src, n_cus, acc64, workspace_bytes);
     F32SymShape s = sym_shape(n_src, n_cus, 0, kb.count > 1 ? kb.nb : 0, kb.count > 1 ? 0 : force_chunks);
     if (kb.count == 1) kb.bytes = sym_workspace_bytes(s, acc64);  // (a forced chunk count changes the own and tail slots)
     if (kb.count < 1 || kb.bytes > SYM_MAX_WORKSPACE || workspace_bytes < kb.bytes) return false;
@@ -440,11 +442,12 @@ int launch_f32_sym(const F32Args& a0, const F32SymShape& sh, bool acc64, int mod
 // ---- one GPU, system too large for a slot per round (B/2 slots of n bodies): the I-superblocks go in BATCHES of `nb`, each a
 // launch like one rank of a multi-GPU step (a slot per I-superblock of the batch) whose reducer adds the batch's slots to a
 // running force F[n] kept behind the slots in the workspace; the last batch's reducer runs the epilogue from the total.
-F32SymBatches sym_batches(long n, int n_cus, bool acc64) {
+F32SymBatches sym_batches(long n, int n_cus, bool acc64, size_t budget) {
     F32SymBatches k{};
     if (n < SYM_MIN_N) return k;
     const F32SymShape whole = sym_shape(n, n_cus);
-    if (sym_workspace_bytes(whole, acc64) <= SYM_WHOLE_WORKSPACE) {
+    const size_t whole_budget = budget ? budget : SYM_WHOLE_WORKSPACE;
+    if (sym_workspace_bytes(whole, acc64) <= whole_budget) {
         k.nb = whole.B;
         k.count = 1;
         k.bytes = sym_workspace_bytes(whole, acc64);
@@ -459,17 +462,17 @@ F32SymBatches sym_batches(long n, int n_cus, bool acc64) {
         const size_t b = sym_workspace_bytes(sym_shape(n, n_cus, 0, last, 0), acc64);
         return (a > b ? a : b) + (size_t)whole.npad * frec;
     };
-    auto take = [&](int nb, size_t budget) {
-        if (nb < 1 || nb >= whole.B || bytes_of(nb) > budget) return false;
+    auto take = [&](int nb, size_t limit) {
+        if (nb < 1 || nb >= whole.B || bytes_of(nb) > limit) return false;
         k.nb = nb;
         k.count = (whole.B + nb - 1) / nb;
         k.bytes = bytes_of(nb);
         return true;
     };
     for (int nb = (whole.B / n_cus) * n_cus; nb >= n_cus; nb -= n_cus)
-        if (take(nb, SYM_BATCH_WORKSPACE)) return k;
+        if (take(nb, budget ? budget : SYM_BATCH_WORKSPACE)) return k;
     for (int nb = n_cus / 2; nb >= 16; nb /= 2)
-        if (take(nb, SYM_MAX_WORKSPACE)) return k;
+        if (take(nb, budget ? budget : SYM_MAX_WORKSPACE)) return k;
     return k;  // count == 0: not even 16 superblocks per batch fit
 }
 

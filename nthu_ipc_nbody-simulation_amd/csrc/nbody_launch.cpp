@@ -188,7 +188,7 @@ int nb_plan_shared_pairs_f32(int64_t n_src, int ranks, int acc64, int* superbloc
 // two workgroups of a launch write the same (slot, J-superblock) region; the slots the reducer adds for a superblock are
 // exactly the ones that were written for it; the workspace is large enough.  0 = consistent; else NB_ERR_STATE with the first
 // inconsistency in msg.
-int nb_selftest_pair_schedule(int64_t n, int n_cus, int ranks, int acc64, char* msg, int msg_len) {
+static int selftest_pair_schedule(int64_t n, int n_cus, int ranks, int acc64, size_t budget, char* msg, int msg_len) {
     auto say = [&](const char* fmt, long a = 0, long b = 0, long c = 0, long d = 0) {
         if (msg && msg_len > 0) snprintf(msg, (size_t)msg_len, fmt, a, b, c, d);
         return NB_ERR_STATE;
@@ -200,8 +200,9 @@ int nb_selftest_pair_schedule(int64_t n, int n_cus, int ranks, int acc64, char* 
     std::vector<F32SymShape> launches;
     try {
         if (ranks == 1) {
-            const F32SymBatches kb = sym_batches(n, n_cus, a64);
+            const F32SymBatches kb = sym_batches(n, n_cus, a64, budget);
             if (kb.count < 1) return say("K1s does not apply to %ld bodies", n);
+            if (budget && kb.bytes > budget) return say("the batches need %ld bytes, more than the budget of %ld", (long)kb.bytes, (long)budget);
             const int B = (int)((n + SYM_SB - 1) / SYM_SB);
             if (kb.count == 1) launches.push_back(sym_shape(n, n_cus));
             else
@@ -284,6 +285,15 @@ int nb_selftest_pair_schedule(int64_t n, int n_cus, int ranks, int acc64, char* 
         return NB_ERR_NOMEM;
     }
     return NB_OK;
+}
+
+int nb_selftest_pair_schedule(int64_t n, int n_cus, int ranks, int acc64, char* msg, int msg_len) {
+    return selftest_pair_schedule(n, n_cus, ranks, acc64, 0, msg, msg_len);
+}
+
+int nb_selftest_pair_schedule_within(int64_t n, int n_cus, int acc64, int64_t workspace_bytes, char* msg, int msg_len) {
+    if (workspace_bytes <= 0) return NB_ERR_INVALID;
+    return selftest_pair_schedule(n, n_cus, 1, acc64, (size_t)workspace_bytes, msg, msg_len);
 }
 
 int64_t nb_workspace_bytes_sym_f32(int64_t n, int acc64) {

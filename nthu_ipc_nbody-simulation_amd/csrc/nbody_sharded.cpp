@@ -594,7 +594,15 @@ int create_impl(nb_sharded** out, const int* devices, int n_devices, int64_t n, 
             const size_t fp = s->sym ? N * force_rec(s) : 0, fa = s->sym ? (copy_exchange(s) ? (size_t)n_devices : 1) * per * force_rec(s) : 0;
             need = ws + fp + fa;
             if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
-            else if ((double)need > 0.75 * (double)free_b) { why = "more than 3/4 of a GPU's free memory"; break; }
+            else if ((double)need > 0.75 * (double)free_b) {
+                // one GPU holding the whole system: batches of superblocks that fit what is free (memory for speed)
+                const F32SymBatches kb = want_one ? sym_batches(n, k.n_cus, acc64(s), (size_t)(0.75 * (double)free_b)) : F32SymBatches{};
+                if (kb.count < 1) { why = "more than 3/4 of a GPU's free memory"; break; }
+                snprintf(s->err, sizeof s->err, "note: %.1f GB free: the unordered-pair kernel (K1s) steps in %d batches of superblocks with a "
+                         "%.1f GB workspace instead of one launch with %.1f GB", free_b / 1e9, kb.count, kb.bytes / 1e9, need / 1e9);
+                ws = std::max(kb.bytes, k.ws_bytes);
+                need = ws;
+            }
             if (hipMalloc(&k.ws, ws) != hipSuccess || (fp && hipMalloc(&k.fpart, fp) != hipSuccess) || (fa && hipMalloc(&k.facc, fa) != hipSuccess)) {
                 (void)hipGetLastError();
                 why = "hipMalloc failed";

@@ -350,8 +350,27 @@ def test_pair_schedule_of_the_symmetric_kernel_on_shapes_no_box_here_can_run(nb)
         if ranks * per_rank * SB >= 49152:
             c.selftest_pair_schedule(ranks * per_rank * SB, cus, ranks, acc64)
 
+    @settings(max_examples=60, deadline=None)
+    @given(st.integers(12, 1100), st.integers(0, SB - 1), st.sampled_from([104, 256, 304]), st.booleans(), st.floats(0.02, 1.0))
+    def one_gpu_within_a_budget(blocks, ragged, cus, acc64, share):
+        """A workspace smaller than the fastest shape wants (NB_CFG_WORKSPACE_GIB, a raw launch's workspace, a device short of
+        memory): batches of superblocks — every pair once, within the budget, or an honest "does not apply"."""
+        n = blocks * SB - ragged
+        if n < 49152:
+            return
+        full = c.workspace_bytes_sym_f32(n, acc64)
+        if full <= 0:
+            return
+        try:
+            c.selftest_pair_schedule_within(n, max(1 << 20, int(full * share)), cus, acc64)
+        except c.NBodyError as e:
+            assert "does not apply" in str(e), e   # too small even for batches of 16 superblocks — never an inconsistent schedule
+
     one_gpu()
     several_gpus()
+    one_gpu_within_a_budget()
+    for n, gib in ((1 << 20, 1.0), (1 << 22, 8.0), (1 << 22, 3.0), (1 << 24, 20.0)):
+        c.selftest_pair_schedule_within(n, int(gib * 2 ** 30))
 
 
 def test_fp32_modes_refuse_an_eps_whose_inverse_cube_overflows(nb):

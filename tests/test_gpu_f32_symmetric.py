@@ -308,11 +308,32 @@ def test_context_workspace_is_lazy_optional_and_never_fatal(nb, oracle):
     for a in (a_sym, a_k1):
         assert (np.abs(a[:, rows] - ref).max(axis=0) / s).max() < TOL_F32
     assert not np.array_equal(a_sym, a_k1)  # two kernels, two summation orders
-    # a GPU with 1 GB to spare: the context is created, steps with K1 and says so
-    free, _ = torch.cuda.mem_get_info(0)
+    # a limit of the caller's own (NB_CFG_WORKSPACE_GIB): K1s still, in batches of superblocks within 1 GiB
+    with c.Context(n, c.NB_F32, 0, G=syn.G, eps=syn.EPS, dt=1e-2, workspace_gib=1) as lim:
+        lim.set_state(q, v, m)
+        assert lim.kernel_name() == "nbody_force_sym_f32<false>"
+        assert used() - u0 < 0.4e9 + (1 << 30)
+        a_lim = lim.accel(1)
+    assert (np.abs(a_lim[:, rows] - ref).max(axis=0) / s).max() < TOL_F32
+    assert np.abs(a_lim - a_sym).max() < 2e-6 * np.abs(a_sym).max() and not np.array_equal(a_lim, a_sym)  # same pairs, other cuts of the sums
+    c.selftest_pair_schedule_within(n, 1 << 30)
+    # a GPU with 1.2 GB to spare: the library does the same by itself (3/4 of what is free) and says so
     ctx = c.Context(n, c.NB_F32, 0, G=syn.G, eps=syn.EPS, dt=1e-2)
     ctx.set_state(q, v, m)
-    hog = torch.empty(max(0, torch.cuda.mem_get_info(0)[0] - (1 << 30)), dtype=torch.uint8, device="cuda:0")
+    hog = torch.empty(max(0, torch.cuda.mem_get_info(0)[0] - int(1.2 * (1 << 30))), dtype=torch.uint8, device="cuda:0")
+    try:
+        assert ctx.kernel_name() == "nbody_force_sym_f32<false>"
+        assert "note:" in ctx.last_error() and "batches of superblocks" in ctx.last_error()
+        a_b = ctx.accel(1)
+    finally:
+        del hog
+        torch.cuda.empty_cache()
+        ctx.close()
+    assert (np.abs(a_b[:, rows] - ref).max(axis=0) / s).max() < TOL_F32
+    # ... and with 0.25 GB to spare not even batches of 16 superblocks fit: the context steps with K1 and says so
+    ctx = c.Context(n, c.NB_F32, 0, G=syn.G, eps=syn.EPS, dt=1e-2)
+    ctx.set_state(q, v, m)
+    hog = torch.empty(max(0, torch.cuda.mem_get_info(0)[0] - (1 << 28)), dtype=torch.uint8, device="cuda:0")
     try:
         assert ctx.kernel_name().startswith("nbody_force_f32<")
         assert "note:" in ctx.last_error() and "every ordered pair (K1) instead" in ctx.last_error()
@@ -322,4 +343,3 @@ def test_context_workspace_is_lazy_optional_and_never_fatal(nb, oracle):
         torch.cuda.empty_cache()
         ctx.close()
     assert np.array_equal(a_fb, a_k1)  # the fallback IS the ordered-pair context
-    assert free > 0
