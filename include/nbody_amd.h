@@ -65,8 +65,8 @@ typedef struct nb_config {
 typedef enum nb_config_flags {
     NB_CFG_ORDERED_PAIRS = 1 /* fp32 modes: nb_step / nb_accel evaluate every ORDERED pair (kernel K1, 288 B of workspace per
                                 body) even where the default applies.  Default from 49152 bodies on: every UNORDERED pair once
-                                (kernel K1s, 1.35x faster), which needs a pair-slot workspace that grows with n^2 — 12 B x
-                                (n/8192 + 8) per body: 1.7 GB at n = 2^20, 26 GB at 2^22, 52 GB from 2^23 on.  That workspace
+                                (kernel K1s, 1.35x faster), which needs a pair-slot workspace — 1.7 GB at n = 2^20, beyond that
+                                720 B per body: 2.5 GB at 2^22, 10 GB at 2^24 (K1: 288 B per body).  That workspace
                                 is allocated by the FIRST nb_step / nb_accel, not by nb_create; if the device cannot give it
                                 (it would take more than 3/4 of the free memory) the step goes in batches that fit (below), and
                                 if even those do not, or hipMalloc fails, the context falls back to K1 for its lifetime;
@@ -74,9 +74,10 @@ typedef enum nb_config_flags {
 } nb_config_flags;
 /* fp32 modes, OR-ed into nb_config.flags: the caller's own limit for that workspace, in GiB (1..65535; 0 = none).  Within a
  * limit K1s steps in BATCHES of superblocks — several launches whose reducers add up a running force — instead of one launch:
- * memory for speed (n = 2^22: 26 GB in one launch, or 8 batches in 6.7 GB about 2 % slower).  Without a limit the library
- * does the same by itself when the fastest shape would take more than 3/4 of the free device memory; only when not even
- * batches of 16 superblocks fit does the context fall back to K1 */
+ * more launches for less memory, at no measurable cost (profiles/r05_workspace_cap_ab.txt).  The default is already frugal
+ * (one launch up to 2 GiB of slots — n = 2^20: 1.7 GB — then batches within 720 B per body: 2.5 GB at 2^22, 10 GB at 2^24);
+ * without a limit the library shrinks the batches by itself when even that would take more than 3/4 of the free device
+ * memory; only when not even batches of 16 superblocks fit (~600 B per body) does the context fall back to K1 */
 #define NB_CFG_WORKSPACE_GIB(g) (((g) & 0xffff) << 8)
 
 /* scenario drivers — the loops main() runs around run_step */

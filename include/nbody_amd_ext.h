@@ -109,10 +109,11 @@ int nb_plan_f32(const nb_launch_f32* a, int* targets_per_lane, int* j_split, int
 int64_t nb_workspace_bytes_f32(int64_t n_tgt, int acc64);
 /* workspace size with which a whole-system launch of n bodies runs K1s (source_path 3) in its FASTEST shape — a smaller one, down
  * to roughly 50 slots of 12 n bytes, still runs K1s, in batches of superblocks that fit it (about a percent slower per doubling
- * of the batch count); below that the launch falls to K1.  Three floats per body and
- * superblock round plus three (six with acc64) per workgroup of a superblock — 12 B x (n/8192 + 8) per body: 1.7 GB at
- * n = 2^20, 26 GB at 2^22; larger systems are stepped in batches of superblocks with a running force behind the slots: 52 GB
- * at 2^23 and 2^24, 107 GB at 2^26; 0 = K1s does not apply to this n (fewer than 49152 bodies, or no batch fits 128 GiB) */
+ * of the batch count); below that the launch falls to K1.  Up to 2 GiB one launch with a slot per superblock round — three
+ * floats per body and round plus three (six with acc64) per workgroup of a superblock: 12 B x (n/8192 + 16) per body, 1.8 GB at
+ * n = 2^20 — beyond that batches of 32 superblocks within 720 B per body: 2.5 GB at 2^22, 5 GB at 2^23, 10 GB at 2^24, 40 GB at
+ * 2^26 (rounds 1-4: a slot per round up to 32 GiB — 26 GB at 2^22 — then 52 GB; the smaller shapes measure 0.8 % FASTER);
+ * 0 = K1s does not apply to this n (fewer than 49152 bodies) */
 int64_t nb_workspace_bytes_sym_f32(int64_t n, int acc64);
 
 /* ---- K1s over several GPUs, for hosts that own the collectives themselves (one process per GPU: nbody_amd.distributed).
@@ -130,9 +131,10 @@ int nb_launch_pair_forces_f32(const nb_launch_f32* a, void* hip_stream);
 int nb_launch_kick_drift_f32(const nb_launch_f32* a, int parts, void* hip_stream);
 int64_t nb_workspace_bytes_shared_pairs_f32(int64_t n_src, int ranks, int acc64);
 /* the launch shape nb_launch_pair_forces_f32 uses for one rank of `ranks` on the CURRENT device (its compute-unit count picks the
- * workgroup count): 4096-body superblocks a rank owns, workgroups per superblock (the kernel's grid = their product) and the
- * sub-launches a rank's share goes out in (1 unless a slot per superblock would exceed the 64 GiB budget: configs[4] over 8
- * GPUs = 2).  NB_ERR_INVALID when the ranks cannot share the pairs (nb_workspace_bytes_shared_pairs_f32 answers 0).  What a
+ * workgroup count): 4096-body superblocks a rank owns, workgroups per superblock, and the sub-launches a rank's share goes out
+ * in (the grid of one launch = superblocks / sub-launches x workgroups per superblock; 1 sub-launch unless a slot per
+ * superblock would exceed 2 GiB / 720 B per body: configs[3] over 8 GPUs = 4 x 32 superblocks, configs[4] = 16 x 32).
+ * NB_ERR_INVALID when the ranks cannot share the pairs (nb_workspace_bytes_shared_pairs_f32 answers 0).  What a
  * host reports as its plan — bench.py — instead of re-deriving it (any pointer may be NULL) */
 int nb_plan_shared_pairs_f32(int64_t n_src, int ranks, int acc64, int* superblocks_per_rank, int* workgroups_per_superblock,
                              int* sub_launches);

@@ -148,7 +148,7 @@ F32Args f32_args(nb_context* c) {
     return a;
 }
 
-// K1s' pair-slot workspace, on the first step / accel that would use it (not in nb_create: 26 GB at n = 2^22 is a heavy
+// K1s' pair-slot workspace, on the first step / accel that would use it (not in nb_create: 1.7 GB at n = 2^20, 10 GB at 2^24 is a heavy
 // default for a context that may only hold state, and several contexts may share a GPU).  If the device cannot give it —
 // more than 3/4 of what is free, or hipMalloc fails — the context keeps K1's workspace (288 B per body, allocated at
 // creation) and evaluates every ordered pair for the rest of its life; nb_last_error(ctx) says so, no call fails.

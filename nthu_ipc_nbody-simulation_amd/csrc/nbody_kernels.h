@@ -58,8 +58,7 @@ constexpr int SYM_SB = SYM_WGS * 2 * SYM_P;        // superblock: 4096 bodies, t
 #endif
 constexpr long SYM_MIN_N = NB_SYM_MIN_N;           // 12 superblocks; below, the pair list is too short to fill the chip even cut into
                                                    // sub-unit chunks (N = 32768: 0.36 of peak against K1's 0.42; 49152: 0.57 against 0.46)
-constexpr size_t SYM_MAX_WORKSPACE = (size_t)128 << 30;  // partial-sum slots grow with n^2/8192 * 12 B: 1.6 GB at 2^20, 26 GB at 2^22,
-                                                         // 103 GB at 2^23 (and per GPU at 2^24 over 8) — of 288 GB
+constexpr size_t SYM_MAX_WORKSPACE = (size_t)128 << 30;  // absolute ceiling of a K1s workspace (what it takes by default: sym_batch_budget)
 struct F32SymShape {  // who computes what in one launch
     int B;         // superblocks covering the system
     int b0, nb;    // I-superblocks this launch owns: [b0, b0 + nb)   (one GPU: 0, B)
@@ -131,12 +130,33 @@ __host__ __device__ inline void sym_for_each_slot_of(const F32SymShape& s, bool 
 }
 F32SymShape sym_shape(long n, int n_cus, int b0 = 0, int nb = 0, int force_chunks = 0, int sb = SYM_SB);
 size_t sym_workspace_bytes(const F32SymShape& s, bool acc64);
-// One GPU: up to SYM_WHOLE_WORKSPACE of slots the whole system is ONE launch (a slot per round, B/2 of them).  Larger systems
-// go in batches of `nb` I-superblocks — each a launch like one rank of a multi-GPU step, a slot per I-superblock of the batch —
-// whose reducers add up a running force kept behind the slots; the last one runs the epilogue.  bytes = workspace needed.
-constexpr size_t SYM_WHOLE_WORKSPACE = (size_t)32 << 30;  // 26 GB at n = 2^22 is the last system taken in one launch
-constexpr size_t SYM_BATCH_WORKSPACE = (size_t)64 << 30;  // budget of a batched step: n = 2^23 -> 4 x 512 superblocks, 52 GB (103 GB
-                                                          // in one launch), 2^24 -> 16 x 256
+// How much workspace K1s takes by default (round 5: linear in n, no longer n^2).  A slot per superblock ROUND lets the whole
+// system go out as ONE launch — n^2/8192 x 12 B of slots: 1.7 GB at n = 2^20, 26 GB at 2^22, 103 GB at 2^23.  Rounds 1-4 did
+// that up to 32 GiB and cut larger systems into batches of I-superblocks within 64 GiB.  Measured this round (same box,
+// alternating, profiles/r05_workspace_cap_ab.txt): batches cost NOTHING — n = 2^22 in 32 batches of 32 superblocks (8
+// workgroups each: every launch still fills the chip) with 2.4 GB of slots steps in 2774.2 ms against 2771.7-2775.1 ms for the
+// one launch with 26 GB; every batch's reducer adds its slots to a running force (32 B per body and batch: 0.02 % of the
+// step).  So: one launch while its slots fit SYM_WHOLE_WORKSPACE (2 GiB: up to ~1.2e6 bodies, the shape every measurement at
+// the metric's N was made with), beyond that the largest batches within 720 B per body — 48 / 56 slots of 12 B (fp32 /
+// fp64 sums: 32 superblocks x 8 workgroups, or 16 x 16) + the running force: 3.0 GB at 2^22, 12 GB at 2^24, linear in n.
+// -DNB_SYM_WHOLE_GIB=32 -DNB_SYM_BATCH_FLOOR_GIB=64 rebuilds rounds 1-4's shapes for an A/B.
+#ifndef NB_SYM_WHOLE_GIB
+#define NB_SYM_WHOLE_GIB 2
+#endif
+#ifndef NB_SYM_BATCH_FLOOR_GIB
+#define NB_SYM_BATCH_FLOOR_GIB 0
+#endif
+constexpr size_t SYM_WHOLE_WORKSPACE = (size_t)NB_SYM_WHOLE_GIB << 30;
+constexpr size_t SYM_BYTES_PER_BODY = 720;
+inline size_t sym_batch_budget(long npad) {  // of a batched step, and of the sub-launches of one rank's share of a multi-GPU step
+    size_t b = (size_t)SYM_BYTES_PER_BODY * (size_t)npad;
+    if (b < SYM_WHOLE_WORKSPACE) b = SYM_WHOLE_WORKSPACE;
+    if (b < ((size_t)NB_SYM_BATCH_FLOOR_GIB << 30)) b = (size_t)NB_SYM_BATCH_FLOOR_GIB << 30;
+    return b;
+}
+// One GPU: larger systems go in batches of `nb` I-superblocks — each a launch like one rank of a multi-GPU step, a slot per
+// I-superblock of the batch — whose reducers add up a running force kept behind the slots; the last one runs the epilogue.
+// bytes = workspace needed.
 struct F32SymBatches {
     int nb = 0;       // I-superblocks per batch (= B when count == 1)
     int count = 0;    // 0: K1s does not apply (too small, or no batch fits SYM_MAX_WORKSPACE)
@@ -149,8 +169,9 @@ struct F32SymBatches {
 // even 16 superblocks per batch fit
 F32SymBatches sym_batches(long n, int n_cus, bool acc64, size_t budget = 0);
 // a launch that leaves a partial force (mode 2: one rank of a multi-GPU step): its I-superblocks go in sub-launches of
-// sym_sub_batch(s) superblocks when a slot for each of them would not fit SYM_BATCH_WORKSPACE (configs[4] over 8 GPUs: 512
-// superblocks per rank = 103 GB -> 2 x 256 = 52 GB); sym_partial_workspace_bytes = the workspace such a launch needs
+// sym_sub_batch(s) superblocks when a slot for each of them would not fit sym_batch_budget (configs[3] over 8 GPUs: 128
+// superblocks per rank = 6.6 GB -> 4 x 32 in 2.4 GB; configs[4]: 512 per rank = 103 GB -> 16 x 32 in 11 GB);
+// sym_partial_workspace_bytes = the workspace such a launch needs
 int sym_sub_batch(const F32SymShape& s, bool acc64);
 F32SymShape sym_sub_shape(const F32SymShape& s, int b0, int nb);  // superblocks [b0, b0 + nb) of launch s as a launch of their own
 size_t sym_partial_workspace_bytes(const F32SymShape& s, bool acc64);

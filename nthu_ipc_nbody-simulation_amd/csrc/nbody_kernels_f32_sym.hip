@@ -391,9 +391,10 @@ F32SymShape sym_sub_shape(const F32SymShape& s, int b0, int nb) {
 }
 
 int sym_sub_batch(const F32SymShape& s, bool acc64) {
-    if (sym_workspace_bytes(s, acc64) <= SYM_BATCH_WORKSPACE) return s.nb;
+    const size_t budget = sym_batch_budget(s.npad);
+    if (sym_workspace_bytes(s, acc64) <= budget) return s.nb;
     int nb = s.nb;
-    while (nb > 16 && sym_workspace_bytes(sym_sub_shape(s, s.b0, nb), acc64) > SYM_BATCH_WORKSPACE) nb = (nb + 1) / 2;
+    while (nb > 16 && sym_workspace_bytes(sym_sub_shape(s, s.b0, nb), acc64) > budget) nb = (nb + 1) / 2;
     return nb;
 }
 
@@ -447,6 +448,7 @@ F32SymBatches sym_batches(long n, int n_cus, bool acc64, size_t budget) {
     if (n < SYM_MIN_N) return k;
     const F32SymShape whole = sym_shape(n, n_cus);
     const size_t whole_budget = budget ? budget : SYM_WHOLE_WORKSPACE;
+    const size_t batch_budget = budget ? budget : sym_batch_budget(whole.npad);
     if (sym_workspace_bytes(whole, acc64) <= whole_budget) {
         k.nb = whole.B;
         k.count = 1;
@@ -470,9 +472,9 @@ F32SymBatches sym_batches(long n, int n_cus, bool acc64, size_t budget) {
         return true;
     };
     for (int nb = (whole.B / n_cus) * n_cus; nb >= n_cus; nb -= n_cus)
-        if (take(nb, budget ? budget : SYM_BATCH_WORKSPACE)) return k;
+        if (take(nb, batch_budget)) return k;
     for (int nb = n_cus / 2; nb >= 16; nb /= 2)
-        if (take(nb, budget ? budget : SYM_MAX_WORKSPACE)) return k;
+        if (take(nb, batch_budget)) return k;
     return k;  // count == 0: not even 16 superblocks per batch fit
 }
 

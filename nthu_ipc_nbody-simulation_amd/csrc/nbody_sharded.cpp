@@ -574,7 +574,7 @@ int create_impl(nb_sharded** out, const int* devices, int n_devices, int64_t n, 
         }
     }
     // Every unordered pair once (K1s) wants more memory than the ordered-pair step: pair slots (n^2-ish: 1.7 GB for one GPU at
-    // n = 2^20, 6.6 GB per GPU of 8 at 2^22, 52 GB at 2^24) and, with several GPUs, a partial force on all n bodies.  It is a
+    // n = 2^20, 2.4 GB per GPU of 8 at 2^22, 11 GB at 2^24) and, with several GPUs, a partial force on all n bodies.  It is a
     // preference, not a requirement: if any GPU cannot give it — more than 3/4 of its free memory, or hipMalloc fails — every
     // GPU gives back what it got and the system steps with ordered pairs (K1); `note` (nb_sharded_last_error after a
     // successful create) says so.  Ranks that share a GPU (copy exchange) see each other's allocations in the free figure.

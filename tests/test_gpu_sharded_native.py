@@ -278,9 +278,9 @@ def test_the_unordered_pair_step_is_a_preference_not_a_requirement(nb):
     pairs for every rank — create succeeds, `note` says why — instead of failing."""
     import torch
     c, syn = nb.capi, nb.synthetic
-    n = 1 << 21   # one GPU: 6.9 GB of pair slots; two ranks: 3.3 GB + 2 x 32 MB each
+    n = 1 << 21   # one GPU: 1.85 GB of pair slots (in batches; 6.9 GB in one launch); two ranks: 1.9 GB + 2 x 32 MB each
     free, _ = torch.cuda.mem_get_info(0)
-    hog = torch.empty(max(0, free - (5 << 30)), dtype=torch.uint8, device="cuda:0")  # leave 5 GB
+    hog = torch.empty(max(0, free - (2 << 30)), dtype=torch.uint8, device="cuda:0")  # leave 2 GB: 3/4 of it is less than either
     try:
         with c.Sharded(n, [0], c.NB_F32, G=syn.G, eps=syn.EPS, dt=1e-2) as sh:
             # one GPU holding the whole system keeps K1s: batches of superblocks that fit 3/4 of what is free (memory for speed)
