@@ -173,7 +173,12 @@ F32SymBatches sym_batches(long n, int n_cus, bool acc64, size_t budget = 0);
 // superblocks per rank = 6.6 GB -> 4 x 32 in 2.4 GB; configs[4]: 512 per rank = 103 GB -> 16 x 32 in 11 GB);
 // sym_partial_workspace_bytes = the workspace such a launch needs
 int sym_sub_batch(const F32SymShape& s, bool acc64);
-F32SymShape sym_sub_shape(const F32SymShape& s, int b0, int nb);  // superblocks [b0, b0 + nb) of launch s as a launch of their own
+// superblocks [b0, b0 + nb) of launch s as a launch of their own.  max_bytes > 0: with no more workgroups per superblock than its
+// slots fit into max_bytes (a short last sub-launch would otherwise be cut into up to 64 workgroups per superblock and want more
+// own / tail slots than the full-sized ones before it)
+F32SymShape sym_sub_shape(const F32SymShape& s, int b0, int nb, bool acc64 = false, size_t max_bytes = 0);
+// batch k of a one-GPU step that goes in kb.count batches (the same rule for its last, shorter batch)
+F32SymShape sym_batch_shape(long n, int n_cus, const F32SymBatches& kb, int k, bool acc64);
 size_t sym_partial_workspace_bytes(const F32SymShape& s, bool acc64);
 // mode 0: force + kick-drift of the whole system; 1: accelerations out; 2: this launch's partial force out (a.acc:
 // float4[n] / double4[n]) for the reduce-scatter of a multi-GPU step.  a.partial = the slot workspace.

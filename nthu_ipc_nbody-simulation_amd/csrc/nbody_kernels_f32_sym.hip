@@ -381,12 +381,17 @@ F32SymShape sym_shape(long n, int n_cus, int b0, int nb, int force_chunks, int s
     return s;
 }
 
-F32SymShape sym_sub_shape(const F32SymShape& s, int b0, int nb) {
+static void fit_chunks(F32SymShape& t, bool acc64, size_t max_bytes) {
+    while (max_bytes && t.chunks > 1 && sym_workspace_bytes(t, acc64) > max_bytes) --t.chunks;
+}
+
+F32SymShape sym_sub_shape(const F32SymShape& s, int b0, int nb, bool acc64, size_t max_bytes) {
     F32SymShape t = s;
     t.b0 = b0;
     t.nb = nb;
     t.by_super = 1;
     t.chunks = sym_choose_chunks(nb, s.B, s.cus, 0);
+    fit_chunks(t, acc64, max_bytes);
     return t;
 }
 
@@ -401,9 +406,7 @@ int sym_sub_batch(const F32SymShape& s, bool acc64) {
 size_t sym_partial_workspace_bytes(const F32SymShape& s, bool acc64) {
     const int nb = sym_sub_batch(s, acc64);
     if (nb >= s.nb) return sym_workspace_bytes(s, acc64);
-    const int last = s.nb % nb ? s.nb % nb : nb;
-    const size_t a = sym_workspace_bytes(sym_sub_shape(s, s.b0, nb), acc64), b = sym_workspace_bytes(sym_sub_shape(s, s.b0, last), acc64);
-    return a > b ? a : b;
+    return sym_workspace_bytes(sym_sub_shape(s, s.b0, nb), acc64);  // (a shorter last sub-launch is fitted into the same bytes)
 }
 
 size_t sym_workspace_bytes(const F32SymShape& s, bool acc64) {
@@ -433,9 +436,10 @@ int launch_f32_sym(const F32Args& a0, const F32SymShape& sh, bool acc64, int mod
     const int sub = mode == 2 ? sym_sub_batch(sh, acc64) : sh.nb;
     if (sub >= sh.nb) return launch_sym_pass(a, sh, acc64, mode, nullptr, stream);
     // a partial-force launch whose slots would not fit the budget: sub-launches, each adding to the partial force
+    const size_t fit = sym_workspace_bytes(sym_sub_shape(sh, sh.b0, sub), acc64);
     for (int b0 = sh.b0; b0 < sh.b0 + sh.nb; b0 += sub) {
         const int nb = b0 + sub <= sh.b0 + sh.nb ? sub : sh.b0 + sh.nb - b0;
-        if (int e = launch_sym_pass(a, sym_sub_shape(sh, b0, nb), acc64, 2, b0 > sh.b0 ? a.acc : nullptr, stream)) return e;
+        if (int e = launch_sym_pass(a, sym_sub_shape(sh, b0, nb, acc64, fit), acc64, 2, b0 > sh.b0 ? a.acc : nullptr, stream)) return e;
     }
     return (int)hipSuccess;
 }
@@ -458,11 +462,8 @@ F32SymBatches sym_batches(long n, int n_cus, bool acc64, size_t budget) {
     // the largest batch of whole rounds of workgroups (a multiple of the CU count; failing that a half, a quarter ... of it)
     // whose slots — of the first and of the smaller last batch, which may be cut into more chunks — fit the budget
     const size_t frec = acc64 ? sizeof(double4) : sizeof(float4);
-    auto bytes_of = [&](int nb) {
-        const int last = whole.B % nb ? whole.B % nb : nb;
-        const size_t a = sym_workspace_bytes(sym_shape(n, n_cus, 0, nb, 0), acc64);
-        const size_t b = sym_workspace_bytes(sym_shape(n, n_cus, 0, last, 0), acc64);
-        return (a > b ? a : b) + (size_t)whole.npad * frec;
+    auto bytes_of = [&](int nb) {  // (a shorter last batch is fitted into the same bytes: sym_batch_shape)
+        return sym_workspace_bytes(sym_shape(n, n_cus, 0, nb, 0), acc64) + (size_t)whole.npad * frec;
     };
     auto take = [&](int nb, size_t limit) {
         if (nb < 1 || nb >= whole.B || bytes_of(nb) > limit) return false;
@@ -478,6 +479,16 @@ F32SymBatches sym_batches(long n, int n_cus, bool acc64, size_t budget) {
     return k;  // count == 0: not even 16 superblocks per batch fit
 }
 
+F32SymShape sym_batch_shape(long n, int n_cus, const F32SymBatches& kb, int k, bool acc64) {
+    const int B = (int)((n + SB - 1) / SB);
+    const int b0 = k * kb.nb, nb = b0 + kb.nb <= B ? kb.nb : B - b0;
+    F32SymShape sh = sym_shape(n, n_cus, b0, nb, 0);
+    sh.by_super = 1;  // (a last batch of all B superblocks cannot happen: count > 1)
+    const size_t frec = acc64 ? sizeof(double4) : sizeof(float4);
+    fit_chunks(sh, acc64, kb.bytes - (size_t)sh.npad * frec);  // the running force sits behind the slots
+    return sh;
+}
+
 int launch_f32_sym_batched(const F32Args& a0, const F32SymBatches& kb, int n_cus, bool acc64, int mode, hipStream_t stream) {
     if (!a0.src || !a0.partial || a0.n_src <= 0 || kb.count < 1 || kb.nb < 1 || mode < 0 || mode > 1) return (int)hipErrorInvalidValue;
     if (a0.tgt_off != 0 || a0.n_tgt != a0.n_src) return (int)hipErrorInvalidValue;
@@ -490,9 +501,7 @@ int launch_f32_sym_batched(const F32Args& a0, const F32SymBatches& kb, int n_cus
     void* F = (char*)a.partial + (kb.bytes - (size_t)npad * frec);  // the running force, behind the slots of the largest batch
     void* user_acc = a.acc;
     for (int k = 0; k < kb.count; ++k) {
-        const int b0 = k * kb.nb, nb = b0 + kb.nb <= B ? kb.nb : B - b0;
-        F32SymShape sh = sym_shape(a.n_src, n_cus, b0, nb, 0);
-        sh.by_super = 1;  // (a last batch of all B superblocks cannot happen: count > 1)
+        const F32SymShape sh = sym_batch_shape(a.n_src, n_cus, kb, k, acc64);
         const bool last = k == kb.count - 1;
         a.acc = last ? user_acc : F;
         if (int e = launch_sym_pass(a, sh, acc64, last ? mode : 2, k ? F : nullptr, stream)) return e;

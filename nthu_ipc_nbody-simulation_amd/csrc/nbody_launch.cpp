@@ -203,12 +203,10 @@ static int selftest_pair_schedule(int64_t n, int n_cus, int ranks, int acc64, si
             const F32SymBatches kb = sym_batches(n, n_cus, a64, budget);
             if (kb.count < 1) return say("K1s does not apply to %ld bodies", n);
             if (budget && kb.bytes > budget) return say("the batches need %ld bytes, more than the budget of %ld", (long)kb.bytes, (long)budget);
-            const int B = (int)((n + SYM_SB - 1) / SYM_SB);
             if (kb.count == 1) launches.push_back(sym_shape(n, n_cus));
             else
                 for (int k = 0; k < kb.count; ++k) {
-                    const int b0 = k * kb.nb, nb = b0 + kb.nb <= B ? kb.nb : B - b0;
-                    launches.push_back(sym_shape(n, n_cus, b0, nb, 0));
+                    launches.push_back(sym_batch_shape(n, n_cus, kb, k, a64));
                     if (sym_workspace_bytes(launches.back(), a64) + (size_t)launches.back().npad * (a64 ? 32 : 16) > kb.bytes)
                         return say("batch %ld needs more workspace than sym_batches reports", k);
                 }
@@ -222,7 +220,8 @@ static int selftest_pair_schedule(int64_t n, int n_cus, int ranks, int acc64, si
                 if (sub >= mine.nb) launches.push_back(mine);
                 else
                     for (int b0 = mine.b0; b0 < mine.b0 + mine.nb; b0 += sub) {
-                        launches.push_back(sym_sub_shape(mine, b0, b0 + sub <= mine.b0 + mine.nb ? sub : mine.b0 + mine.nb - b0));
+                        launches.push_back(sym_sub_shape(mine, b0, b0 + sub <= mine.b0 + mine.nb ? sub : mine.b0 + mine.nb - b0, a64,
+                                                         sym_workspace_bytes(sym_sub_shape(mine, mine.b0, sub), a64)));
                         if (sym_workspace_bytes(launches.back(), a64) > sym_partial_workspace_bytes(mine, a64))
                             return say("a sub-launch of rank %ld needs more workspace than sym_partial_workspace_bytes reports", r);
                     }
