@@ -145,7 +145,7 @@ def test_symmetric_refusals_and_fallbacks(nb):
     stream = torch.cuda.current_stream().cuda_stream
     big = torch.empty(c.workspace_bytes_sym_f32(n), dtype=torch.uint8, device="cuda")
     small = torch.empty(c.workspace_bytes_f32(n), dtype=torch.uint8, device="cuda")
-    assert 50e9 < c.workspace_bytes_sym_f32(1 << 24) < 60e9  # 412 GB of slots in one launch: 16 batches of 256 superblocks
+    assert 9e9 < c.workspace_bytes_sym_f32(1 << 24) < 13e9  # 412 GB of slots in one launch: 128 batches of 32 superblocks within 720 B per body
     assert c.workspace_bytes_sym_f32(SB * 11) == 0 and c.workspace_bytes_sym_f32(1 << 28) == 0  # too small / no batch of superblocks fits 128 GiB
     for kw in (dict(workspace_ptr=small.data_ptr(), workspace_bytes=small.numel()),                      # workspace too small
                dict(workspace_ptr=big.data_ptr(), workspace_bytes=big.numel(), src_begin=0, src_end=n // 2),  # a source range
