@@ -287,12 +287,11 @@ def test_the_unordered_pair_step_is_a_preference_not_a_requirement(nb):
             assert sh.kernel_name() == "nbody_force_sym_f32<false>" and "batches of superblocks" in sh.note
         with c.Sharded(n, [0, 0], c.NB_F32, G=syn.G, eps=syn.EPS, dt=1e-2, exchange="copy") as sh:
             assert sh.kernel_name().startswith("nbody_force_f32<") and "3/4" in sh.note and "ordered pairs (K1) instead" in sh.note
-        del hog
-        torch.cuda.empty_cache()  # (the caching allocator would otherwise serve the next request from the block just freed)
-        hog = torch.empty(max(0, torch.cuda.mem_get_info(0)[0] - (1 << 30)), dtype=torch.uint8, device="cuda:0")  # leave 1 GB: K1's
+        hog2 = torch.empty(max(0, torch.cuda.mem_get_info(0)[0] - (1 << 30)), dtype=torch.uint8, device="cuda:0")  # leave 1 GB: K1's
         # 0.7 GB of state and slices fit, not even batches of 16 superblocks (1.2 GB) do — (copy exchange: RCCL wants memory too)
         with c.Sharded(n, [0], c.NB_F32, G=syn.G, eps=syn.EPS, dt=1e-2, exchange="copy") as sh:
             assert sh.kernel_name().startswith("nbody_force_f32<") and "ordered pairs (K1) instead" in sh.note
+        del hog2
     finally:
         del hog
         torch.cuda.empty_cache()
