@@ -1146,6 +1146,8 @@ def main():
         if args.time_box or args.steps > 200:  # sustained runs: a leg may take as long as the run is asked to
             args.leg_timeout = max(args.leg_timeout, 2 * args.time_box + 600)
             args.legs_budget = max(args.legs_budget, 2 * args.leg_timeout)
+        if world == 1 and args.host == "torch":
+            raise SystemExit("--host torch runs one rank per GPU: launch with python -m torch.distributed.run --nproc-per-node P")
         return orchestrate_torch(args, world) if world > 1 else orchestrate_native(args)
     if world > 1 and args.host == "native":
         raise SystemExit("--host native is ONE process for all GPUs: run it without a launcher")
