@@ -630,8 +630,8 @@ def main_native(args):
     if exchange not in NATIVE_EXCHANGES:
         raise SystemExit(f"--exchange {exchange}: the native host takes {', '.join(NATIVE_EXCHANGES)} "
                          f"(in_place/staged/ring belong to the torch host: launch with torch.distributed.run)")
-    if args.resume or args.checkpoint or args.conservation or args.dump_rows:
-        raise SystemExit("--resume/--checkpoint/--conservation/--dump-rows: single rank or the torch host")
+    if args.conservation or args.dump_rows:
+        raise SystemExit("--conservation/--dump-rows: single rank or the torch host")
     devices = [0] * P if exchange.endswith("one-gpu") else list(range(P))
     lib_exchange = exchange.split("-")[0]  # rccl | copy | host
     prec = capi.NB_F32_ACC64 if acc64 else capi.NB_F32
@@ -642,7 +642,14 @@ def main_native(args):
     except capi.NBodyError as e:  # no GPU (NB_ERR_NO_DEVICE), fewer than P GPUs, RCCL missing: fail loudly, no fallback
         raise SystemExit(f"bench.py --gpus {P} (native host, devices {devices}): {e}")
     q, v, m = synthetic.bodies(n)
-    sh.set_state(q, v, m)
+    first_step = 0
+    if args.resume:  # a checkpoint of this very run (nb_sharded_load_state refuses another n / precision / G / eps / dt)
+        try:
+            first_step = sh.load_state(args.resume)
+        except capi.NBodyError as e:
+            raise SystemExit(f"--resume {args.resume}: {e}")
+    else:
+        sh.set_state(q, v, m)
     del q, v
     info = sh.info()
     kname = sh.kernel_name()
@@ -653,14 +660,22 @@ def main_native(args):
     # ---- timed region: K steps, all GPUs idle on both sides (nb_sharded_step_profiled synchronises every stream before
     #      its first launch and after its last; the per-rank event pairs are created before its clock starts)
     chunk = args.report_every if args.report_every else 1024
+    every = args.checkpoint_every if (args.checkpoint and args.checkpoint_every) else 0
     kern = [0.0] * P
     steps_done = 0
+    ckpt_s = []
     t0 = time.perf_counter()
     while steps_done < args.steps:
         k = min(chunk, args.steps - steps_done, 1024)
+        if every:
+            k = min(k, every - steps_done % every)
         _, kms = sh.step_profiled(k)
         kern = [a + b * k for a, b in zip(kern, kms)]
         steps_done += k
+        if every and steps_done % every == 0:  # (inside the timed region, like the torch host's)
+            tc = time.perf_counter()
+            sh.save_state(args.checkpoint, first_step + args.warmup + steps_done)
+            ckpt_s.append(time.perf_counter() - tc)
         el = time.perf_counter() - t0
         if args.report_every and steps_done < args.steps:
             print(f"[bench] {steps_done}/{args.steps} steps, {el:.1f} s, "
@@ -709,6 +724,11 @@ def main_native(args):
     }
     if sh.note:
         out["shared_pairs_note"] = sh.note
+    if first_step:
+        out["resumed_from_step"] = first_step
+    if ckpt_s:
+        out["checkpoints"] = {"count": len(ckpt_s), "seconds_each": [round(x, 2) for x in ckpt_s],
+                              "bytes": os.path.getsize(args.checkpoint), "inside_timed_region": True}
     if exchange.endswith("one-gpu"):
         out["rehearsal"] = f"all {P} ranks on GPU 0 (they share the chip): the P > 1 host logic, not a {P}-GPU measurement"
     out["roofline"]["kernel_ms_detail"] = ("slowest rank's mean per step, HIP events on each rank's own compute stream "
@@ -771,6 +791,10 @@ def passthrough_args(args, steps=None, diagnostics=True, parity=None):
             a += ["--report-every", str(args.report_every)]
         if args.time_box:
             a += ["--time-box", str(args.time_box)]
+        if args.checkpoint:
+            a += ["--checkpoint", args.checkpoint, "--checkpoint-every", str(args.checkpoint_every)]
+        if args.resume:
+            a += ["--resume", args.resume]
     if args.no_parity_spot or not parity:
         a += ["--no-parity-spot"]
     if args.no_diagnostics or not diagnostics:
@@ -850,8 +874,8 @@ def orchestrate_native(args):
     `variants`, the overlap toggle, and the reference's own multi-GPU mode (`replicas`)."""
     t0 = time.perf_counter()
     log = lambda msg: print(f"[bench] {msg}", file=sys.stderr, flush=True)  # noqa: E731
-    if args.resume or args.checkpoint or args.conservation or args.dump_rows:
-        raise SystemExit("--resume/--checkpoint/--conservation/--dump-rows: single rank or the torch host")
+    if args.conservation or args.dump_rows:
+        raise SystemExit("--conservation/--dump-rows: single rank or the torch host")
     ndev = args.gpus if args.leg_program else probe_device_count()  # (a test's stand-in legs bring their own "devices")
     if ndev <= 0:  # no usable GPU at all: fail loudly, with the library's own words, no ladder (there is no CPU path)
         rc, out, err = run_process([sys.executable, os.path.abspath(__file__)] + passthrough_args(args) +

@@ -197,6 +197,12 @@ int nb_sharded_set_state(nb_sharded* s, const double* qx, const double* qy, cons
                          const double* vy, const double* vz, const double* m);
 int nb_sharded_get_state(nb_sharded* s, double* qx, double* qy, double* qz, double* vx, double* vy, double* vz);
 int nb_sharded_step(nb_sharded* s, int count); /* `count` run_steps of the whole system; returns with all GPUs idle */
+/* checkpoint / resume of a sharded run: ONE NBODYST2 state file for the whole system (the format of nb_save_state; q, v = the fp64
+ * masters or the widened fp32 state, m exactly as nb_sharded_set_state got it), written beside the previous one and renamed over
+ * it.  nb_sharded_load_state refuses a file whose n, precision, G, eps or dt differ from the system's; a resumed run continues
+ * bit for bit.  (The reference has no files, only its in-memory Problem-3 snapshot, hw5.cu:265-287.) */
+int nb_sharded_save_state(nb_sharded* s, const char* path, int step);
+int nb_sharded_load_state(nb_sharded* s, const char* path, int* step /* may be NULL */);
 /* as nb_sharded_step, and reports the host wall time per step in milliseconds (all GPUs idle on both sides) */
 int nb_sharded_step_timed(nb_sharded* s, int count, double* ms_per_step);
 /* as nb_sharded_step_timed, and additionally reports — per rank — the mean GPU time of one step's launch sequence

@@ -116,6 +116,8 @@ SYMBOLS = {
     "nb_sharded_set_state": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
     "nb_sharded_get_state": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _dp, _dp]),
     "nb_sharded_step": (C.c_int, [C.c_void_p, C.c_int]),
+    "nb_sharded_save_state": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "nb_sharded_load_state": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]),
     "nb_sharded_step_timed": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
     "nb_sharded_step_profiled": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_float)]),
     "nb_sharded_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int),
@@ -542,6 +544,16 @@ class Sharded:
 
     def step(self, count=1):
         self._check(lib().nb_sharded_step(self._h, count), "nb_sharded_step")
+
+    def save_state(self, path, step=0):
+        """One NBODYST2 checkpoint of the whole system (atomic replace)."""
+        self._check(lib().nb_sharded_save_state(self._h, os.fsencode(path), step), "nb_sharded_save_state")
+
+    def load_state(self, path):
+        """Resume from a checkpoint of the same system (n, precision, G, eps, dt must match) -> its step index."""
+        step = C.c_int()
+        self._check(lib().nb_sharded_load_state(self._h, os.fsencode(path), C.byref(step)), "nb_sharded_load_state")
+        return step.value
 
     def step_timed(self, count):
         ms = C.c_double()

@@ -135,6 +135,7 @@ struct nb_sharded {
     long awaited = 0;        // ... of which the first `awaited` are known to have finished
     bool dead = false;       // a wait timed out: the GPUs may still be busy with what was enqueued; nothing may be enqueued
     float4* host_stage[2] = {nullptr, nullptr};  // NB_SHARDED_HOST_EXCHANGE: pinned float4[n] per ping-pong array
+    std::vector<double> m_host;                  // the masses as nb_sharded_set_state got them (checkpoints carry them exactly)
     char err[512] = {0};
 };
 
@@ -682,6 +683,7 @@ int set_state_impl(nb_sharded* s, const double* qx, const double* qy, const doub
     s->cur = 0;
     s->gather_pending = false;
     s->have_state = true;
+    s->m_host.assign(m, m + N);
     return NB_OK;
 }
 
@@ -781,6 +783,64 @@ int nb_sharded_get_state(nb_sharded* s, double* qx, double* qy, double* qz, doub
     if (!s->have_state || s->dead) return NB_ERR_STATE;
     try {
         return get_state_impl(s, qx, qy, qz, vx, vy, vz);
+    } catch (...) {
+        return NB_ERR_NOMEM;
+    }
+}
+
+// ---- checkpoints of a sharded run (configs[4] runs for hours; the reference has only its in-memory Problem-3
+// snapshot, hw5.cu:265-287): ONE NBODYST2 file for the whole system, the same format nb_save_state writes and bin/hw5 reads
+int nb_sharded_save_state(nb_sharded* s, const char* path, int step) {
+    if (!s || !path) return NB_ERR_INVALID;
+    if (!s->have_state || s->dead) return NB_ERR_STATE;
+    try {
+        const size_t n = (size_t)s->n;
+        std::vector<double> buf(6 * n);
+        if (int rc = get_state_impl(s, &buf[0], &buf[n], &buf[2 * n], &buf[3 * n], &buf[4 * n], &buf[5 * n])) return rc;
+        nb_state_header h{};
+        h.n = s->n;
+        h.precision = s->precision;
+        h.step = step;
+        h.planet = h.asteroid = -1;
+        h.G = s->G;
+        h.eps = s->eps;
+        h.dt = s->dt;
+        const int rc = nb_write_state_file(path, &h, &buf[0], &buf[n], &buf[2 * n], &buf[3 * n], &buf[4 * n], &buf[5 * n],
+                                           s->m_host.data(), nullptr);
+        if (rc) snprintf(s->err, sizeof s->err, "nb_sharded_save_state: %s", nb_last_error(nullptr));
+        return rc;
+    } catch (...) {
+        return NB_ERR_NOMEM;
+    }
+}
+
+int nb_sharded_load_state(nb_sharded* s, const char* path, int* step) {
+    if (!s || !path) return NB_ERR_INVALID;
+    if (!s->ready || s->dead) return NB_ERR_STATE;
+    try {
+        nb_state_header h;
+        int rc = nb_read_state_file(path, &h, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        if (rc) {
+            snprintf(s->err, sizeof s->err, "nb_sharded_load_state: %s", nb_last_error(nullptr));
+            return rc;
+        }
+        // a checkpoint resumes the run it was taken from (as nb_load_state): same size, arithmetic and integration parameters
+        if (h.n != s->n || h.precision != s->precision || h.G != s->G || h.eps != s->eps || h.dt != s->dt) {
+            snprintf(s->err, sizeof s->err, "state file (n=%lld precision=%d G=%g eps=%g dt=%g) does not match the system (n=%lld "
+                     "precision=%d G=%g eps=%g dt=%g)", (long long)h.n, h.precision, h.G, h.eps, h.dt, (long long)s->n, s->precision,
+                     s->G, s->eps, s->dt);
+            return NB_ERR_INVALID;
+        }
+        const size_t n = (size_t)s->n;
+        std::vector<double> buf(7 * n);
+        rc = nb_read_state_file(path, &h, (int64_t)n, &buf[0], &buf[n], &buf[2 * n], &buf[3 * n], &buf[4 * n], &buf[5 * n], &buf[6 * n],
+                                nullptr);
+        if (rc) {
+            snprintf(s->err, sizeof s->err, "nb_sharded_load_state: %s", nb_last_error(nullptr));
+            return rc;
+        }
+        if (step) *step = h.step;
+        return set_state_impl(s, &buf[0], &buf[n], &buf[2 * n], &buf[3 * n], &buf[4 * n], &buf[5 * n], &buf[6 * n]);
     } catch (...) {
         return NB_ERR_NOMEM;
     }

@@ -336,3 +336,40 @@ def test_host_staged_exchange_follows_nb_step_and_the_oracle(nb, oracle, ranks, 
     with pytest.raises(c.NBodyError) as e:
         c.Sharded(n, [0, 0], prec, G=syn.G, eps=syn.EPS, dt=dt, exchange="host", overlap=True)
     assert e.value.code == c.NB_ERR_INVALID
+
+
+# ---------------------------------------------------------------- checkpoints of the native host
+
+@pytest.mark.parametrize("precision,n", [("NB_F32", 16384), ("NB_F32_ACC64", 16384), ("NB_F32", 1 << 17)])  # (2^17: the ranks share the pairs)
+def test_sharded_checkpoint_resume_is_bitwise(nb, tmp_path, precision, n):
+    """nb_sharded_save_state / nb_sharded_load_state: ONE NBODYST2 file for the whole system (configs[4] runs for
+    hours).  Four steps in one go against two steps, a checkpoint, a NEW system with another rank count resumed from it, two more
+    steps: bit for bit.  The file is a plain state file (nb_read_state_file reads it); one written under other parameters is refused."""
+    c, syn = nb.capi, nb.synthetic
+    prec = getattr(c, precision)
+    q, v, m = syn.bodies(n)
+    kw = dict(G=syn.G, eps=syn.EPS, dt=1e-2, exchange="copy")
+    with c.Sharded(n, [0, 0], prec, **kw) as sh:
+        sh.set_state(q, v, m)
+        sh.step(4)
+        q4, v4 = sh.get_state()
+    path = str(tmp_path / "ck.nbst")
+    with c.Sharded(n, [0, 0], prec, **kw) as sh:
+        sh.set_state(q, v, m)
+        sh.step(2)
+        sh.save_state(path, step=2)
+    hdr, qf, vf, mf, _ = c.read_state_file(path)
+    assert (hdr["n"], hdr["step"], hdr["precision"], hdr["dt"]) == (n, 2, prec, 1e-2) and np.array_equal(mf, m)
+    with c.Sharded(n, [0, 0], prec, **kw) as sh:   # the same rank count: every sum is cut at the same places
+        assert sh.load_state(path) == 2
+        q2, v2 = sh.get_state()
+        assert np.array_equal(q2, qf) and np.array_equal(v2, vf)
+        sh.step(2)
+        qr, vr = sh.get_state()
+    assert np.array_equal(qr, q4) and np.array_equal(vr, v4)
+    with c.Sharded(n, [0, 0], prec, G=syn.G, eps=syn.EPS, dt=2e-2, exchange="copy") as other:
+        with pytest.raises(c.NBodyError, match="does not match") as e:
+            other.load_state(path)
+        assert e.value.code == c.NB_ERR_INVALID
+    with c.Context(n, prec, 0, G=syn.G, eps=syn.EPS, dt=1e-2) as ctx:   # ... and an unsharded context resumes from it too
+        assert ctx.load_state(path) == 2
