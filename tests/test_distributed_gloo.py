@@ -262,3 +262,48 @@ def test_shard_range_and_cpu_refusal(nb):
     t = torch.zeros((8, 4))
     with pytest.raises(RuntimeError, match="no CPU compute path"):
         hip_compute()(t, t.clone(), t.clone(), 0, 8, 1e-6, 1e-4)
+
+
+def _run_disagreeing(rank, world, port, result_path):
+    """Rank 1 cannot share the pairs (no pair launches: as a rank whose device-local workspace query answered 0 would be), the
+    others can.  Every rank must end up with the ordered form — never a subset enqueueing the second collective."""
+    sys.path.insert(0, ROOT)
+    import nbody_amd  # noqa: F401
+    from nbody_amd import synthetic
+    from nbody_amd.distributed import ShardedSystem, shard_range
+    from oracle import oracle as O
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    lo, hi = shard_range(N, rank, world)
+    pos, vel = synthetic.body4_f32(N, lo, hi)
+    steps = None if rank == 1 else _oracle_pair_steps(synthetic.G, synthetic.EPS, N, world)
+    sysm = ShardedSystem(N, torch.from_numpy(pos), torch.from_numpy(vel), synthetic.EPS, 1e-2, torch.device("cpu"),
+                         compute=_oracle_compute(O, synthetic.G, synthetic.EPS), pair_steps=steps)
+    assert sysm.shared_pairs is False, "a rank-local refusal must switch EVERY rank to the ordered form"
+    for _ in range(STEPS):
+        sysm.step()
+    full = sysm.positions.clone()
+    vels = [torch.zeros_like(sysm.vel) for _ in range(world)]
+    dist.all_gather(vels, sysm.vel)
+    if rank == 0:
+        np.savez(result_path, pos=full.numpy(), vel=torch.cat(vels).numpy())
+    # asking for shared pairs explicitly where one rank cannot is an error ON EVERY RANK (nobody is left waiting in a collective)
+    try:
+        ShardedSystem(N, torch.from_numpy(pos), torch.from_numpy(vel), synthetic.EPS, 1e-2, torch.device("cpu"),
+                      compute=_oracle_compute(O, synthetic.G, synthetic.EPS), pair_steps=steps, shared_pairs=True)
+        raised = False
+    except ValueError:
+        raised = True
+    assert raised
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_agree_on_the_form_of_the_step(oracle, tmp_path):
+    """whether the step shares the pairs depends on device-local facts; the ranks settle it with an all_reduce(MIN).
+    Three ranks, one of which cannot: all run the ordered form and reproduce the one-rank trajectory bit for bit."""
+    one, three = str(tmp_path / "one.npz"), str(tmp_path / "three.npz")
+    _run(0, 1, 0, one)
+    # N = 512 bodies over 4 ranks (3 would not divide it)
+    mp.spawn(_run_disagreeing, args=(4, _free_port(), three), nprocs=4, join=True)
+    a, b = np.load(one), np.load(three)
+    assert np.array_equal(a["pos"], b["pos"]) and np.array_equal(a["vel"], b["vel"])
