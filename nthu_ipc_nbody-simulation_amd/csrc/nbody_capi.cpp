@@ -153,22 +153,36 @@ F32Args f32_args(nb_context* c) {
 // more than 3/4 of what is free, or hipMalloc fails — the context keeps K1's workspace (288 B per body, allocated at
 // creation) and evaluates every ordered pair for the rest of its life; nb_last_error(ctx) says so, no call fails.
 void ensure_sym_workspace(nb_context* c) {
-    if (!c->sym_bytes || c->sym_tried) return;
+    if (c->sym_tried) return;
     c->sym_tried = true;
+    // K1's source-slice workspace (k1_bytes: up to 66 records per body) is only needed when K1 runs: below SYM_MIN_N bodies it
+    // was allocated by nb_create; above, it is allocated here — and only if K1s' own workspace is not to be had
+    auto k1_workspace = [&]() {
+        if (c->partial || !c->k1_bytes) return;
+        if (hipMalloc(&c->partial, c->k1_bytes) != hipSuccess) {  // not fatal either: K1 then runs unsliced
+            (void)hipGetLastError();
+            c->partial = nullptr;
+            c->partial_slots = 0;
+            return;
+        }
+        c->partial_bytes = c->k1_bytes;
+    };
+    if (!c->sym_bytes) return k1_workspace();
     const bool acc64 = c->cfg.precision == NB_F32_ACC64;
-    size_t need = std::max(c->partial_bytes, c->sym_bytes);
+    size_t need = c->sym_bytes;
     size_t free_b = 0, total_b = 0;
     const bool known = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
     if (!known) (void)hipGetLastError();
     void* ws = nullptr;
     const char* why = nullptr;
     int batches = 1;
-    const size_t room = known ? (size_t)(0.75 * (double)(free_b + c->partial_bytes)) : need;
+    const size_t room = known ? (size_t)(0.75 * (double)free_b) : need;
     if (need > room) {
-        // the fastest shape does not fit: the largest batches of superblocks that do (memory for speed, a percent or two)
+        // the default shape does not fit: smaller batches of superblocks that do (more launches for less memory, at no
+        // measurable cost: profiles/r05_workspace_cap_ab.txt)
         const F32SymBatches kb = sym_batches(c->n, c->n_cus, acc64, room);
-        if (kb.count >= 1 && std::max(c->partial_bytes, kb.bytes) <= room) {
-            need = std::max(c->partial_bytes, kb.bytes);
+        if (kb.count >= 1 && kb.bytes <= room) {
+            need = kb.bytes;
             batches = kb.count;
         } else {
             why = "more than 3/4 of the free device memory even in batches of 16 superblocks";
@@ -183,13 +197,11 @@ void ensure_sym_workspace(nb_context* c) {
         snprintf(c->err, sizeof c->err, "note: the %.1f GB pair-slot workspace of the unordered-pair kernel (K1s) was not allocated (%s, "
                  "%.1f GB free): this context evaluates every ordered pair (K1) instead", need / 1e9, why, free_b / 1e9);
         c->sym_bytes = 0;
-        return;
+        return k1_workspace();
     }
-    if (need < std::max(c->partial_bytes, c->sym_bytes))
+    if (need < c->sym_bytes)
         snprintf(c->err, sizeof c->err, "note: %.1f GB free: the unordered-pair kernel (K1s) steps in %d batches of superblocks with a %.1f GB "
-                 "workspace instead of one launch with %.1f GB", free_b / 1e9, batches, need / 1e9, c->sym_bytes / 1e9);
-    (void)hipStreamSynchronize(c->stream);  // nothing in flight may still be reading the slice workspace
-    free_dev(c->partial);
+                 "workspace instead of its default %.1f GB", free_b / 1e9, batches, need / 1e9, c->sym_bytes / 1e9);
     c->partial = ws;
     c->partial_bytes = need;
     c->sym_bytes = need;
@@ -346,7 +358,7 @@ int nbi::create_context(nb_context** out, const nb_config* cfg, hipStream_t borr
             const size_t rec = cfg->precision == NB_F32_ACC64 ? sizeof(double4) : sizeof(float4);
             const long cap = (long)(((size_t)8 << 30) / (n * rec)) - 2;
             c->partial_slots = (int)std::max<long>(SLICES_PER_LAUNCH, std::min<long>(std::min<long>(js, MAX_SLICES_PER_LAUNCH), cap));
-            c->partial_bytes = (size_t)(c->partial_slots + 2) * n * rec;
+            c->k1_bytes = (size_t)(c->partial_slots + 2) * n * rec;
         }
         if (c->n >= SYM_MIN_N && !(cfg->flags & NB_CFG_ORDERED_PAIRS)) {
             // K1s: a slot per superblock round (1.6 GB at 2^20), in batches beyond 32 GiB of them — wanted, not yet allocated
@@ -356,7 +368,10 @@ int nbi::create_context(nb_context** out, const nb_config* cfg, hipStream_t borr
             if (cap && kb.count >= 1 && kb.bytes > cap) kb = sym_batches(c->n, c->n_cus, cfg->precision == NB_F32_ACC64, cap);
             if (kb.count >= 1 && kb.bytes <= SYM_MAX_WORKSPACE) c->sym_bytes = kb.bytes;
         }
-        if (c->partial_bytes) NB_HIP(c, hipMalloc(&c->partial, c->partial_bytes));
+        if (c->k1_bytes && !c->sym_bytes) {  // K1 is what this context will run: its slices now (a K1s context asks at its first step)
+            NB_HIP(c, hipMalloc(&c->partial, c->k1_bytes));
+            c->partial_bytes = c->k1_bytes;
+        }
         if (cfg->precision == NB_F32_ACC64) {
             NB_HIP(c, hipMalloc(&c->pos64, n * sizeof(double4)));
             NB_HIP(c, hipMalloc(&c->vel64, n * sizeof(double4)));

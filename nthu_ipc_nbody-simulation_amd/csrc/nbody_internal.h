@@ -81,6 +81,7 @@ struct nb_context {
                               // (larger) pair-slot workspace of the symmetric kernel K1s, which holds the slices too
     int partial_slots = 0;
     size_t partial_bytes = 0;
+    size_t k1_bytes = 0;      // what K1's source slices need ([2 + partial_slots][n] records; 0: the plan does not slice)
     size_t sym_bytes = 0;     // what K1s needs (0: does not apply, NB_CFG_ORDERED_PAIRS, or given up)
     bool sym_tried = false;   // the pair-slot workspace was asked for once (lazily: ensure_sym_workspace)
 };
