@@ -294,7 +294,8 @@ def test_context_workspace_is_lazy_optional_and_never_fatal(nb, oracle):
     ctx = c.Context(n, c.NB_F32, 0, G=syn.G, eps=syn.EPS, dt=1e-2)
     ctx.set_state(q, v, m)
     u1 = used()
-    assert u1 - u0 < 0.2e9, u1 - u0                       # positions x2, velocities, accel scratch: no workspace of either kernel yet
+    assert u1 - u0 < 0.3e9, u1 - u0                       # positions x2, velocities, accel scratch (84 MB; a process's first allocations
+                                                          # bring runtime pools with them): no workspace of either kernel yet
     assert ctx.kernel_name() == "nbody_force_sym_f32<false>"   # asks for the slots, like the first step
     u2 = used()
     assert 1.2e9 < u2 - u1 < 2.2e9, u2 - u1
