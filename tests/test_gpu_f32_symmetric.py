@@ -289,6 +289,7 @@ def test_context_workspace_is_lazy_optional_and_never_fatal(nb, oracle):
     n = 1 << 20
     q, v, m = syn.bodies(n)
     torch.cuda.synchronize()
+    torch.cuda.empty_cache()  # (blocks cached by earlier tests would serve the big allocations below without taking device memory)
     used = lambda: torch.cuda.mem_get_info(0)[1] - torch.cuda.mem_get_info(0)[0]  # noqa: E731  (device-wide, not torch's)
     u0 = used()
     ctx = c.Context(n, c.NB_F32, 0, G=syn.G, eps=syn.EPS, dt=1e-2)
@@ -324,6 +325,7 @@ def test_context_workspace_is_lazy_optional_and_never_fatal(nb, oracle):
     # a GPU with 1.2 GB to spare: the library does the same by itself (3/4 of what is free) and says so
     ctx = c.Context(n, c.NB_F32, 0, G=syn.G, eps=syn.EPS, dt=1e-2)
     ctx.set_state(q, v, m)
+    torch.cuda.empty_cache()
     hog = torch.empty(max(0, torch.cuda.mem_get_info(0)[0] - int(1.2 * (1 << 30))), dtype=torch.uint8, device="cuda:0")
     hog2 = None
     try:

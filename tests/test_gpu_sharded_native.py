@@ -279,6 +279,7 @@ def test_the_unordered_pair_step_is_a_preference_not_a_requirement(nb):
     import torch
     c, syn = nb.capi, nb.synthetic
     n = 1 << 21   # one GPU: 1.85 GB of pair slots (in batches; 6.9 GB in one launch); two ranks: 1.9 GB + 2 x 32 MB each
+    torch.cuda.empty_cache()  # (blocks cached by earlier tests would serve the big allocation below without taking device memory)
     free, _ = torch.cuda.mem_get_info(0)
     hog = torch.empty(max(0, free - (2 << 30)), dtype=torch.uint8, device="cuda:0")  # leave 2 GB: 3/4 of it is less than either
     try:
