@@ -267,3 +267,21 @@ def test_launcher_spelling_survives_refused_nccl_legs(nb):
         assert leg["seconds"] < 120, leg  # stopped early, not at the 240 s limit
     assert r["leg"] == "native_shared_pairs_copy_one_gpu" and r["host"] == "native" and r["parity_spot"]["ok"] and "rehearsal" in r
     assert time.perf_counter() - t0 < 400
+
+
+def test_native_legs_checkpoint_and_resume(nb, tmp_path):
+    """`bench.py --gpus P --checkpoint f --checkpoint-every K` / `--resume f` through the native legs (nb_sharded_save_state /
+    nb_sharded_load_state): the checkpoints are written inside the timed region and said to be; a second run resumes from the
+    last one and still proves itself against the oracle."""
+    ck = str(tmp_path / "run.nbst")
+    common = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--exchange", "copy-one-gpu", "--bodies", "65536",
+              "--no-diagnostics"]
+    p = subprocess.run(common + ["--steps", "4", "--warmup", "1", "--checkpoint", ck, "--checkpoint-every", "2"],
+                       capture_output=True, text=True, timeout=600, env=_env(), cwd=ROOT)
+    r = _line(p)
+    assert r["checkpoints"]["count"] == 2 and r["checkpoints"]["inside_timed_region"] and r["checkpoints"]["bytes"] == 64 + 65536 * 57
+    assert nb.capi.state_file_info(ck) == (65536, nb.capi.NB_F32, 5)  # warm-up + 4 steps
+    p = subprocess.run(common + ["--steps", "2", "--warmup", "0", "--resume", ck], capture_output=True, text=True, timeout=600,
+                       env=_env(), cwd=ROOT)
+    r = _line(p)
+    assert r["resumed_from_step"] == 5 and r["steps"] == 2 and r["parity_spot"]["ok"]
