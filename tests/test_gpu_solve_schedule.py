@@ -383,3 +383,28 @@ def test_whole_program_under_host_asan(nb, case, devices, handoff, tmp_path):
     p = subprocess.run([exe, case_path(case, "in"), out], capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0 and "AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr, p.stderr[-2000:]
     assert open(out).read() == read_golden(case)[4]
+
+
+@pytest.mark.parametrize("case,devices,handoff", [("b30", "0,0", ""), ("b60", "0,0,0", ""), ("b200", "0,0", "host")])
+def test_whole_program_under_host_tsan(nb, case, devices, handoff, tmp_path):
+    """bin/tsan/hw5 (`make tsan`): the same program with ThreadSanitizer on the host code (the reference's known races —
+    the unsynchronised read of gravity_device_id, hw5.cu:491, and `cost < missile_cost` tested outside the lock, hw5.cu:512 — are
+    what this looks for in OUR host: nb_solve drives every device slot from its own host thread).  The ROCm runtime is not
+    instrumented; what TSan sees inside libamdhip64 / libhsa-runtime64 is suppressed (bench/tsan.supp), anything located in
+    libnbody_amd.so or hw5 is a failure.  Golden output."""
+    exe = os.path.join(ROOT, "bin", "tsan", "hw5")
+    if not os.path.exists(exe):
+        pytest.skip("bin/tsan/hw5 not built (make tsan)")
+    out = str(tmp_path / "out")
+    supp = os.path.join(ROOT, "bench", "tsan.supp")
+    env = dict(os.environ, NB_DEVICES=devices, NB_HW5_CLEAN_EXIT="1",
+               TSAN_OPTIONS=f"suppressions={supp} halt_on_error=0 report_signal_unsafe=0 exitcode=0")
+    if handoff:
+        env["NB_SOLVE_HANDOFF"] = handoff
+    p = subprocess.run([exe, case_path(case, "in"), out], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    ours = [ln for ln in p.stderr.splitlines() if ln.startswith("SUMMARY: ThreadSanitizer") and
+            ("libnbody_amd" in ln or "/hw5" in ln or "nbody_" in ln)]
+    assert not ours, "\n".join(ours)
+    assert "WARNING: ThreadSanitizer" not in p.stderr, p.stderr[-3000:]   # (with the runtime's own reports suppressed: none at all)
+    assert open(out).read() == read_golden(case)[4]
