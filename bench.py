@@ -1507,6 +1507,14 @@ def main():
                                          traffic, traffic_source, live, valu_busy, reduce_share, shared_pairs=shared)
         if out["roofline"]["traffic_detail"]:
             out["roofline"]["traffic_detail"]["algorithmic"] = 56 * n  # 16N + 12N read, 12N + 16N written
+        if world == 1 and kname.startswith("nbody_force_sym_f32"):
+            # the workspace behind that traffic: what the timed launches used, and what the library takes by default at the
+            # sizes of BASELINE configs[3] / [4] (round 5: one launch up to 2 GiB of slots, then batches within 720 B per body)
+            out["roofline"]["workspace"] = {
+                "bytes": workspace_bytes(n, n, acc64, args.targets_per_lane, args.j_split, args.source_path, args.wg_size),
+                "bytes_per_body_beyond_2GiB": 720,
+                "default_bytes_by_n": {str(k): capi.workspace_bytes_sym_f32(k, acc64) for k in (1 << 20, 1 << 22, 1 << 24)},
+                "note": "pair slots of K1s (+ the running force of a batched step); rounds 1-4 took 26 GB at 2^22 and 52 GB at 2^24"}
         if lds is not None:
             out["lds_path"] = lds
         if sgpr is not None:

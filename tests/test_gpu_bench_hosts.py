@@ -149,6 +149,8 @@ def test_single_gpu_line_reports_the_lds_kernel_and_step_traffic(nb):
     a64, f64 = r["acc64_path"], r["f64_path"]
     assert a64["kernel"] == "nbody_force_sym_f32<true>" and a64["parity"]["ok"] and a64["parity"]["tol"] == 1e-6 and 0 < a64["frac"] < 1
     assert f64["dtype"] == "f64" and f64["peak"] == 78.6 and f64["parity"]["ok"] and f64["parity"]["tol"] == 1e-12 and 0 < f64["frac"] < 1
+    w = r["roofline"]["workspace"]
+    assert w["bytes"] < 2.2e9 and w["default_bytes_by_n"]["4194304"] < 3.5e9 and w["default_bytes_by_n"]["16777216"] < 13e9
     assert r["roofline"]["flop_per_pair"] == 20 and r["roofline"]["flop_per_pair_executed"] == 13
     assert r["roofline"]["frac_executed"] == pytest.approx(r["roofline"]["frac"] * 13 / 20)
     live = r["roofline"]["live_pmc"]
