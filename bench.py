@@ -897,7 +897,8 @@ def orchestrate_native(args):
         k_ab = min(5, max(2, args.steps))
         win = legs[chosen]
         todo = [lg for lg in legs[chosen + 1:] if not lg.get("skip")]
-        if not args.overlap and args.bodies // args.gpus % 256 == 0:  # the two-phase step that hides the all-gather (ordered pairs)
+        if not args.overlap and args.bodies // args.gpus % 256 == 0 and not win["exchange"].startswith("host"):
+            # the two-phase step that hides the all-gather (ordered pairs; the host-staged exchange has no overlapped form)
             todo.append({"name": "ordered_pairs_" + win["exchange"].replace("-", "_") + "_overlap",
                          "argv": ["--host", "native", "--exchange", win["exchange"], "--ordered-pairs", "--overlap"]})
         for lg in todo:
