@@ -76,6 +76,9 @@ struct nb_context {
     double4* pos64 = nullptr;
     double4* vel64 = nullptr;
     void* acc32 = nullptr;
+    void* pinned = nullptr;                        // two pinned staging halves (nb_set_state / nb_get_state of the fp32 modes)
+    size_t pin_half = 0;                           // ... of this many bytes each (<= 16 MiB)
+    hipEvent_t pin_ev[2] = {nullptr, nullptr};     // ... and the event that says a half's copies are done
     void* partial = nullptr;  // workspace: source slices [2 + partial_slots][n] float4 (double4 for ACC64) — allocated by
                               // nb_create — or, from the first nb_step / nb_accel of a system of SYM_MIN_N bodies or more, the
                               // (larger) pair-slot workspace of the symmetric kernel K1s, which holds the slices too
