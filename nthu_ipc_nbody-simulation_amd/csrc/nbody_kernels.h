@@ -315,8 +315,8 @@ int plan_f64_large_slices(int n, int n_cus);
 // (register sums, LDS image, slots) in fp64.  Taken for eps > 0 when a.sym_slots (the slot workspace, sym64_workspace_bytes)
 // is given.
 constexpr int SYM64_SB = 2048;
-constexpr size_t SYM64_MAX_WORKSPACE = (size_t)8 << 30;  // 0.4 GB at n = 2^18, 6.5 GB at 2^20
-size_t sym64_workspace_bytes(int n, int n_cus);  // 0: not applicable (fewer than 16 superblocks, or beyond the cap)
+constexpr size_t SYM64_MAX_WORKSPACE = (size_t)64 << 30;  // ceiling; by default 0.42 GB at n = 2^18 (one launch), then 1440 B per body
+size_t sym64_workspace_bytes(int n, int n_cus);  // 0: not applicable (fewer than 16 superblocks of 2048 bodies)
 int launch_f64_large_sym(const F64LargeArgs& a, int n_cus, hipStream_t stream);
 
 // K3: whole scenario of a small system (n <= SMALL_N_MAX) in ONE persistent single-workgroup launch

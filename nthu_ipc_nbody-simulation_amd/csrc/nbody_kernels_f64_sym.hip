@@ -151,18 +151,24 @@ __global__ __launch_bounds__(WGS, 1) void nbody_force_sym_f64(F64LargeArgs a, F3
     }
 }
 
-template <bool ACCEL_ONLY>
-__global__ __launch_bounds__(WG) void nbody_reduce_sym_f64(F64LargeArgs a, F32SymShape sh) {
+// MODE 0: kick-drift; 1: accelerations out; 2: this launch's sums out as a running force F[3][npad] (a step that goes in
+// batches of superblocks: every batch's reducer adds its slots to F, the last one runs the epilogue from the total).
+// `carry` = F of the batches before (may alias the MODE 2 output), or null.
+template <int MODE>
+__global__ __launch_bounds__(WG) void nbody_reduce_sym_f64(F64LargeArgs a, F32SymShape sh, const double* carry, double* running) {
     const int i = blockIdx.x * WG + threadIdx.x, n = a.n;
     if (i >= n) return;
     const double* ws = a.sym_slots + i;
     const long plane = sh.npad;
     double ax = 0, ay = 0, az = 0;
+    if (carry) { ax = carry[i]; ay = carry[plane + i]; az = carry[2 * plane + i]; }
     sym_for_each_slot_of(sh, false, i / SB, [&](long slot) {
         const double* p = ws + slot * 3 * plane;
         ax += p[0]; ay += p[plane]; az += p[2 * plane];
     });
-    if (ACCEL_ONLY) {
+    if (MODE == 2) {
+        running[i] = ax; running[plane + i] = ay; running[2 * plane + i] = az;
+    } else if (MODE == 1) {
         a.acc_out[i] = ax; a.acc_out[n + i] = ay; a.acc_out[2 * (size_t)n + i] = az;
     } else {  // kick, drift (nbody.cc:76-88), non-contracted like K2 and K1-f64
         const double vx = __dadd_rn(a.v[i], __dmul_rn(ax, a.dt));
@@ -179,23 +185,90 @@ __global__ __launch_bounds__(WG) void nbody_reduce_sym_f64(F64LargeArgs a, F32Sy
 __global__ void nbody_gm_f64(const double* __restrict__ m, const double* __restrict__ coef, double* __restrict__ gm, int n,
                              double fst, double G);
 
-size_t sym64_workspace_bytes(int n, int n_cus) {
-    if (n < 16 * SB) return 0;
-    const F32SymShape s = sym_shape(n, n_cus, 0, 0, 0, SB);
-    const size_t bytes = (size_t)sym_total_slots(s, false) * (size_t)s.npad * 3 * sizeof(double);
-    return bytes <= SYM64_MAX_WORKSPACE ? bytes : 0;
+// ---- workspace and batches: as the fp32 kernel's since round 5 (nbody_kernels.h: sym_batch_budget) — one launch with a slot per
+// superblock round while that fits 2 GiB (n <= ~6e5: 0.42 GB at n = 2^18), beyond it batches of I-superblocks (a slot per
+// superblock of the batch, by_super) within 1440 B per body whose reducers add up a running force F[3][npad] kept behind the
+// slots.  Rounds 4's cap of 8 GiB for the one-launch shape (n <= 1.1e6, K1-f64 beyond: 1.5x slower) is gone.
+namespace {
+
+constexpr size_t SYM64_BYTES_PER_BODY = 1440;  // 56 slots of 3 doubles + the running force
+size_t shape_bytes64(const F32SymShape& s) { return (size_t)sym_total_slots(s, false) * (size_t)s.npad * 3 * sizeof(double); }
+
+struct Sym64Batches {
+    int nb = 0, count = 0;  // count == 0: K1s-f64 does not apply
+    size_t bytes = 0;
+};
+
+Sym64Batches sym64_batches(int n, int n_cus) {
+    Sym64Batches k{};
+    if (n < 16 * SB) return k;
+    const F32SymShape whole = sym_shape(n, n_cus, 0, 0, 0, SB);
+    if (shape_bytes64(whole) <= SYM_WHOLE_WORKSPACE) {
+        k.nb = whole.B;
+        k.count = 1;
+        k.bytes = shape_bytes64(whole);
+        return k;
+    }
+    size_t budget = SYM64_BYTES_PER_BODY * (size_t)whole.npad;
+    if (budget < SYM_WHOLE_WORKSPACE) budget = SYM_WHOLE_WORKSPACE;
+    const size_t force = (size_t)whole.npad * 3 * sizeof(double);
+    auto take = [&](int nb) {
+        if (nb < 1 || nb >= whole.B) return false;
+        const size_t b = shape_bytes64(sym_shape(n, n_cus, 0, nb, 0, SB)) + force;
+        if (b > budget || b > SYM64_MAX_WORKSPACE) return false;
+        k.nb = nb;
+        k.count = (whole.B + nb - 1) / nb;
+        k.bytes = b;
+        return true;
+    };
+    for (int nb = (whole.B / n_cus) * n_cus; nb >= n_cus; nb -= n_cus)
+        if (take(nb)) return k;
+    for (int nb = n_cus / 2; nb >= 16; nb /= 2)
+        if (take(nb)) return k;
+    return k;
 }
+
+F32SymShape sym64_batch_shape(int n, int n_cus, const Sym64Batches& kb, int k) {
+    const int B = (n + SB - 1) / SB;
+    const int b0 = k * kb.nb, nb = b0 + kb.nb <= B ? kb.nb : B - b0;
+    F32SymShape sh = sym_shape(n, n_cus, b0, nb, 0, SB);
+    sh.by_super = 1;
+    const size_t room = kb.bytes - (size_t)sh.npad * 3 * sizeof(double);  // a shorter last batch: no more workgroups per superblock
+    while (sh.chunks > 1 && shape_bytes64(sh) > room) --sh.chunks;        // than its slots fit into the same bytes
+    return sh;
+}
+
+}  // namespace
+
+size_t sym64_workspace_bytes(int n, int n_cus) { return sym64_batches(n, n_cus).bytes; }
 
 int launch_f64_large_sym(const F64LargeArgs& a, int n_cus, hipStream_t stream) {
     if (!a.sym_slots || !a.gm || !(a.eps2 >= F64_EPS2_MIN) || a.n < 16 * SB) return (int)hipErrorInvalidValue;
-    const F32SymShape sh = sym_shape(a.n, n_cus, 0, 0, 0, SB);
+    const Sym64Batches kb = sym64_batches(a.n, n_cus);
+    if (kb.count < 1) return (int)hipErrorInvalidValue;
     const unsigned b1 = (unsigned)((a.n + WG - 1) / WG);
     hipLaunchKernelGGL(nbody_gm_f64, dim3(b1), dim3(WG), 0, stream, a.m, a.coef, a.gm, a.n, a.fst, a.G);
-    hipLaunchKernelGGL(nbody_force_sym_f64, dim3((unsigned)(sh.nb * sh.chunks)), dim3(WGS), 0, stream, a, sh);
-    if (hipError_t e = hipGetLastError()) return (int)e;
-    if (a.acc_out) hipLaunchKernelGGL(nbody_reduce_sym_f64<true>, dim3(b1), dim3(WG), 0, stream, a, sh);
-    else hipLaunchKernelGGL(nbody_reduce_sym_f64<false>, dim3(b1), dim3(WG), 0, stream, a, sh);
-    return (int)hipGetLastError();
+    if (kb.count == 1) {
+        const F32SymShape sh = sym_shape(a.n, n_cus, 0, 0, 0, SB);
+        hipLaunchKernelGGL(nbody_force_sym_f64, dim3((unsigned)(sh.nb * sh.chunks)), dim3(WGS), 0, stream, a, sh);
+        if (hipError_t e = hipGetLastError()) return (int)e;
+        if (a.acc_out) hipLaunchKernelGGL(nbody_reduce_sym_f64<1>, dim3(b1), dim3(WG), 0, stream, a, sh, (const double*)nullptr, (double*)nullptr);
+        else hipLaunchKernelGGL(nbody_reduce_sym_f64<0>, dim3(b1), dim3(WG), 0, stream, a, sh, (const double*)nullptr, (double*)nullptr);
+        return (int)hipGetLastError();
+    }
+    const long npad = (long)((a.n + SB - 1) / SB) * SB;
+    double* F = a.sym_slots + (kb.bytes / sizeof(double) - (size_t)npad * 3);  // the running force, behind the slots of the largest batch
+    for (int k = 0; k < kb.count; ++k) {
+        const F32SymShape sh = sym64_batch_shape(a.n, n_cus, kb, k);
+        hipLaunchKernelGGL(nbody_force_sym_f64, dim3((unsigned)(sh.nb * sh.chunks)), dim3(WGS), 0, stream, a, sh);
+        if (hipError_t e = hipGetLastError()) return (int)e;
+        const double* carry = k ? F : nullptr;
+        if (k + 1 < kb.count) hipLaunchKernelGGL(nbody_reduce_sym_f64<2>, dim3(b1), dim3(WG), 0, stream, a, sh, carry, F);
+        else if (a.acc_out) hipLaunchKernelGGL(nbody_reduce_sym_f64<1>, dim3(b1), dim3(WG), 0, stream, a, sh, carry, (double*)nullptr);
+        else hipLaunchKernelGGL(nbody_reduce_sym_f64<0>, dim3(b1), dim3(WG), 0, stream, a, sh, carry, (double*)nullptr);
+        if (hipError_t e = hipGetLastError()) return (int)e;
+    }
+    return (int)hipSuccess;
 }
 
 }  // namespace nbk

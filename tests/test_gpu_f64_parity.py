@@ -265,7 +265,9 @@ def test_large_n_fp64_kernel(nb, oracle, n, eps):
         assert np.isfinite(q).all() and np.isfinite(v).all()
 
 
-@pytest.mark.parametrize("n", [16 * 2048, 17 * 2048 + 77, 40 * 2048 + 5])
+@pytest.mark.parametrize("n", [16 * 2048, 17 * 2048 + 77, 40 * 2048 + 5,
+                               (1 << 20) + 123])  # > 2 GiB of slots in one launch: 9 batches of 64 superblocks (round 5; until
+                                                  # round 4 systems beyond 1.1e6 bodies fell back to K1-f64, 1.5x slower)
 def test_large_n_fp64_symmetric_kernel(nb, oracle, n):
     """From 16 superblocks of 2048 bodies on (and eps > 0) NB_F64 contexts run K1s-f64: every unordered pair once, the
     sources travelling through the wave, fp64 throughout (csrc/nbody_kernels_f64_sym.hip).  Accelerations of rows from the
