@@ -87,4 +87,5 @@ bench/ubench/valu_rate: bench/ubench/valu_rate.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
 
 clean:
+	rm -rf bin/asan bin/tsan
 	rm -f $(LIB) $(STAMPLIB) bin/hw5 bin/nbody_bench bin/nbconv hw5 bench/ubench/valu_rate bench/ubench/force_variants bench/ubench/launch_rate bench/ubench/sym_force bench/debug/startup_probe
