@@ -50,11 +50,11 @@ def main():
         multi = k % 3 == 2
         if multi:
             ranks = int(rng.integers(2, 9))
-            n = ranks * int(rng.integers(max(2, -(-12 // ranks)), 12)) * SB
+            n = ranks * int(rng.integers(max(2, -(-9 // ranks)), 12)) * SB
             what = f"{ranks} ranks"
         else:
-            n = int(rng.integers(12 * SB, 80 * SB)) - int(rng.integers(0, SB)) * int(rng.integers(2))
-            n = max(n, 49152)
+            n = int(rng.integers(9 * SB + SB, 80 * SB)) - int(rng.integers(0, SB)) * int(rng.integers(2))
+            n = max(n, 36864)
             chunks = int(rng.choice([0, 0, 1, 2, 3, 5, 8]))
             what = f"chunks {chunks}"
         pos, _ = syn.body4_f32(n)

@@ -54,10 +54,12 @@ constexpr int MAX_JSPLIT = 1024;       // source slices per step (processed SLIC
 constexpr int SYM_P = 4, SYM_WGS = 512;            // packed target pairs per lane, threads per workgroup (8 waves)
 constexpr int SYM_SB = SYM_WGS * 2 * SYM_P;        // superblock: 4096 bodies, the targets one workgroup holds in registers
 #ifndef NB_SYM_MIN_N
-#define NB_SYM_MIN_N 49152
+#define NB_SYM_MIN_N 36864
 #endif
-constexpr long SYM_MIN_N = NB_SYM_MIN_N;           // 12 superblocks; below, the pair list is too short to fill the chip even cut into
-                                                   // sub-unit chunks (N = 32768: 0.36 of peak against K1's 0.42; 49152: 0.57 against 0.46)
+constexpr long SYM_MIN_N = NB_SYM_MIN_N;           // 9 superblocks.  K1s has a floor of ~0.33 ms per step (a workgroup does at least 8 tile
+                                                   // phases), K1 grows with n^2: measured round 5 (bench/small_n_sym_ab.py,
+                                                   // profiles/r05_small_n_sym_ab.txt) K1 wins by 18 % at 32768 bodies, K1s by 26 % at 36864,
+                                                   // 37 % at 40960, 31 % at 45056 (rounds 3-4 started K1s at 49152)
 constexpr size_t SYM_MAX_WORKSPACE = (size_t)128 << 30;  // absolute ceiling of a K1s workspace (what it takes by default: sym_batch_budget)
 struct F32SymShape {  // who computes what in one launch
     int B;         // superblocks covering the system
@@ -147,7 +149,9 @@ size_t sym_workspace_bytes(const F32SymShape& s, bool acc64);
 #define NB_SYM_BATCH_FLOOR_GIB 0
 #endif
 constexpr size_t SYM_WHOLE_WORKSPACE = (size_t)NB_SYM_WHOLE_GIB << 30;
-constexpr size_t SYM_BYTES_PER_BODY = 720;
+constexpr size_t SYM_BYTES_PER_BODY = 832;  // the BUDGET: 64 slots + the running force + margin.  What a 256-CU part then takes is 592 B
+                                            // (fp32 sums: 48 slots) / 704 B (fp64 sums: 56 slots) per body — the "720 B per body" of the
+                                            // documentation; 304 CUs need 62 slots with fp64 sums (found by the hypothesis self-test)
 inline size_t sym_batch_budget(long npad) {  // of a batched step, and of the sub-launches of one rank's share of a multi-GPU step
     size_t b = (size_t)SYM_BYTES_PER_BODY * (size_t)npad;
     if (b < SYM_WHOLE_WORKSPACE) b = SYM_WHOLE_WORKSPACE;

@@ -31,7 +31,9 @@ def _launch(nb, torch, src, n, acc64, source_path, accel=None, j_split=0, out=No
     return ws
 
 
-@pytest.mark.parametrize("n,chunks", [(12 * SB, 0),          # the smallest system K1s takes: 7 work units per superblock cut into
+@pytest.mark.parametrize("n,chunks", [(9 * SB, 0),           # the smallest system K1s takes (round 5: 36864 bodies; B = 9, odd)
+                                      (10 * SB - 100, 0),    # B = 10, even, ragged
+                                      (12 * SB, 0),          # rounds 3-4's smallest: 7 work units per superblock cut into
                                                              # sub-unit chunks (>= 8 of a unit's 32 tile phases each)
                                       (16 * SB + 3, 0),      # B = 17, odd, ragged
                                       (64 * SB, 0),          # B = 64: even, the half round B/2 for b < 32
@@ -77,7 +79,7 @@ def test_symmetric_accelerations_vs_oracle_and_k1(nb, oracle, n, chunks, acc64):
 
 
 def test_symmetric_is_bitwise_reproducible_and_is_what_a_context_runs(nb, oracle):
-    """No atomics anywhere: two launches give identical bits; nb_accel / nb_step of a context with >= 49152 bodies pick
+    """No atomics anywhere: two launches give identical bits; nb_accel / nb_step of a context with >= 36864 bodies pick
     K1s by themselves (the workspace is sized for it at nb_create) and give exactly the raw launch's numbers."""
     import torch
     c, syn = nb.capi, nb.synthetic
