@@ -68,7 +68,9 @@ def test_symmetric_accelerations_vs_oracle_and_k1(nb, oracle, n, chunks, acc64):
     tol = TOL_ACC64 if acc64 else TOL_F32
     err = (np.abs(a1[rows].T - ref).max(axis=0) / s).max()
     assert err < tol, err
-    assert err < (5e-7 if not acc64 else 2e-7), err  # what it actually delivers, with room (measured 3e-8 / 1e-8 at 2^20)
+    # what it actually delivers, with room (measured 3e-8 / 1e-8 at 2^20; the 1 ulp of v_rsq_f32 does not average out over the
+    # few thousand sources of the smallest systems: 2.4e-7 at 40860 bodies with fp64 sums)
+    assert err < (5e-7 if not acc64 else (4e-7 if n < 12 * SB else 2e-7)), err
     # every body against K1 (every ordered pair): two summation orders of the same terms
     scale = np.abs(a2).max()
     assert np.abs(a1 - a2).max() < 2e-5 * scale, np.abs(a1 - a2).max() / scale
@@ -148,7 +150,7 @@ def test_symmetric_refusals_and_fallbacks(nb):
     big = torch.empty(c.workspace_bytes_sym_f32(n), dtype=torch.uint8, device="cuda")
     small = torch.empty(c.workspace_bytes_f32(n), dtype=torch.uint8, device="cuda")
     assert 9e9 < c.workspace_bytes_sym_f32(1 << 24) < 13e9  # 412 GB of slots in one launch: 128 batches of 32 superblocks within 720 B per body
-    assert c.workspace_bytes_sym_f32(SB * 11) == 0 and c.workspace_bytes_sym_f32(1 << 28) == 0  # too small / no batch of superblocks fits 128 GiB
+    assert c.workspace_bytes_sym_f32(SB * 8) == 0 and c.workspace_bytes_sym_f32(1 << 28) == 0  # too small / no batch of superblocks fits 128 GiB
     for kw in (dict(workspace_ptr=small.data_ptr(), workspace_bytes=small.numel()),                      # workspace too small
                dict(workspace_ptr=big.data_ptr(), workspace_bytes=big.numel(), src_begin=0, src_end=n // 2),  # a source range
                dict(workspace_ptr=big.data_ptr(), workspace_bytes=big.numel(), tgt_ptr=src.data_ptr())):  # a target block
