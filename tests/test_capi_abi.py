@@ -347,8 +347,12 @@ def test_pair_schedule_of_the_symmetric_kernel_on_shapes_no_box_here_can_run(nb)
     @settings(max_examples=40, deadline=None)
     @given(st.integers(2, 8), st.integers(4, 96), st.sampled_from([64, 256, 304]), st.booleans())
     def several_gpus(ranks, per_rank, cus, acc64):
-        if ranks * per_rank * SB >= 36864:
-            c.selftest_pair_schedule(ranks * per_rank * SB, cus, ranks, acc64)
+        n = ranks * per_rank * SB
+        if n >= 36864 and n * n >= 1.1e9 * ranks:  # (below: a rank's K1 step beats its K1s share, the ranks do not share the pairs)
+            c.selftest_pair_schedule(n, cus, ranks, acc64)
+        else:
+            with pytest.raises(c.NBodyError, match="cannot share"):
+                c.selftest_pair_schedule(n, cus, ranks, acc64)
 
     @settings(max_examples=60, deadline=None)
     @given(st.integers(9, 1100), st.integers(0, SB - 1), st.sampled_from([104, 256, 304]), st.booleans(), st.floats(0.02, 1.0))
