@@ -119,7 +119,8 @@ int64_t nb_workspace_bytes_sym_f32(int64_t n, int acc64);
 /* ---- K1s over several GPUs, for hosts that own the collectives themselves (one process per GPU: nbody_amd.distributed).
  * The GPUs share the UNORDERED pairs of the system: rank r = tgt_off / n_tgt of P = n_src / n_tgt takes the 4096-body
  * superblocks of its shard against the half of the system behind each.  Needs whole superblocks per shard
- * (n_src % (P * 4096) == 0) and n_src >= 36864: nb_workspace_bytes_shared_pairs_f32 answers 0 otherwise (use the ordered
+ * (n_src % (P * 4096) == 0), n_src >= 36864 and n_src^2 / P >= 1.1e9 (below, a rank's ordered-pair step is faster than its share):
+ * nb_workspace_bytes_shared_pairs_f32 answers 0 otherwise (use the ordered
  * launches above).  Per step and rank:
  *   nb_launch_pair_forces_f32   a->acc = float4[n_src] (double4 with acc64): this rank's partial force on ALL bodies
  *   reduce-scatter (sum) of a->acc over the ranks -> the force on the rank's own shard
