@@ -134,6 +134,63 @@ def cpu_baseline_all_cores(n_total, rows=2048):
                       f"of the same input ({pairs:.3g} pairs, {dt:.1f} s)"}
 
 
+class PowerSampler:
+    """Socket power and shader clock of ONE GPU during the timed region, read from the amdgpu hwmon files of the card with this PCI
+    bus id (power1_input in microwatts, power1_cap, freq1_input in Hz) every 0.2 s by a host thread — file reads only, no GPU call,
+    never raises.  The kernel is compute-bound and runs into the socket's power cap: this is the driver-visible form of
+    profiles/r04b_power_and_clock.txt (rocm-smi by hand): what the chip drew and what clock it held while `value` was measured."""
+
+    def __init__(self, pci_bus_id, period=0.2):
+        import glob
+        import threading
+        self.dir, self.samples, self.period = None, [], period
+        want = pci_bus_id.lower()
+        for d in glob.glob("/sys/class/drm/card*/device"):
+            try:
+                if os.path.realpath(d).lower().endswith(want):
+                    hw = glob.glob(os.path.join(d, "hwmon", "hwmon*"))
+                    if hw and os.path.exists(os.path.join(hw[0], "power1_input")):
+                        self.dir = hw[0]
+                        break
+            except OSError:
+                pass
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True) if self.dir else None
+
+    def _read(self, name):
+        try:
+            with open(os.path.join(self.dir, name)) as f:
+                return float(f.read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            p, f = self._read("power1_input"), self._read("freq1_input")
+            if p is not None:
+                self.samples.append((p * 1e-6, (f or 0.0) * 1e-6))
+            self._stop.wait(self.period)
+
+    def start(self):
+        if self._thread:
+            self._thread.start()
+        return self
+
+    def stop(self):
+        if not self._thread:
+            return None
+        self._stop.set()
+        self._thread.join(timeout=2)
+        if not self.samples:
+            return None
+        w = [a for a, _ in self.samples]
+        mhz = [b for _, b in self.samples if b > 0]
+        cap = self._read("power1_cap")
+        return {"mean_w": sum(w) / len(w), "max_w": max(w), "cap_w": cap * 1e-6 if cap else None,
+                "sclk_mhz_mean": sum(mhz) / len(mhz) if mhz else None, "sclk_mhz_min": min(mhz) if mhz else None,
+                "samples": len(w), "source": "amdgpu hwmon (power1_input, freq1_input) of this GPU, every %.1f s during the timed region" % self.period}
+
+
 def load_traffic(n_bodies, world, kernel, j_split):
     """HBM bytes per step of the force + reducer launches (None when the committed profile predates the reducer being
     counted), and the VALU-busy fraction, from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, written by
@@ -1251,6 +1308,14 @@ def main():
         sysm.step()
     barrier()
     kern_ms.clear()
+    power = None
+    if world == 1:
+        try:
+            pr_ = torch.cuda.get_device_properties(dev_index)
+            power = PowerSampler(f"{getattr(pr_, 'pci_domain_id', 0):04x}:{getattr(pr_, 'pci_bus_id', 0):02x}:"
+                                 f"{getattr(pr_, 'pci_device_id', 0):02x}.0").start()
+        except Exception:  # noqa: BLE001
+            power = None
     t0 = time.perf_counter()
     steps_done = 0
     ckpt_s = []
@@ -1276,6 +1341,7 @@ def main():
                 break
     barrier()
     wall = time.perf_counter() - t0
+    power = power.stop() if power is not None else None
     args.steps = steps_done
     if world > 1:
         t = torch.tensor([wall], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
@@ -1506,6 +1572,8 @@ def main():
         r = out["roofline"]
         out["roofline"] = roofline_block(r["achieved"], kname, r["kernel_ms"], r["targets_per_lane"], jsp, r["wg_size"], acc64,
                                          traffic, traffic_source, live, valu_busy, reduce_share, shared_pairs=shared)
+        if power:
+            out["roofline"]["power"] = power
         if out["roofline"]["traffic_detail"]:
             out["roofline"]["traffic_detail"]["algorithmic"] = 56 * n  # 16N + 12N read, 12N + 16N written
         if world == 1 and kname.startswith("nbody_force_sym_f32"):

@@ -153,6 +153,9 @@ def test_single_gpu_line_reports_the_lds_kernel_and_step_traffic(nb):
     assert w["bytes"] < 2.2e9 and w["default_bytes_by_n"]["4194304"] < 3.5e9 and w["default_bytes_by_n"]["16777216"] < 13e9
     assert r["roofline"]["flop_per_pair"] == 20 and r["roofline"]["flop_per_pair_executed"] == 13
     assert r["roofline"]["frac_executed"] == pytest.approx(r["roofline"]["frac"] * 13 / 20)
+    pw = r["roofline"].get("power")  # amdgpu hwmon of this GPU, sampled during the timed region; absent where sysfs hides it
+    if pw:
+        assert pw["samples"] >= 1 and 50 < pw["mean_w"] <= pw["max_w"] < 2000 and (pw["sclk_mhz_min"] or 1) <= (pw["sclk_mhz_mean"] or 1) < 2600
     live = r["roofline"]["live_pmc"]
     if live and "error" not in live:  # rocprofv3 present: bytes of force kernel + reducer = the launches kernel_ms spans
         assert live["force"]["hbm_bytes"] > 0 and live["reducer"]["hbm_bytes"] > 0
