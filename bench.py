@@ -721,6 +721,13 @@ def main_native(args):
     kern = [0.0] * P
     steps_done = 0
     ckpt_s = []
+    samplers = {}  # one per distinct GPU of the run: what each socket drew and the clock it held during the timed region
+    for r in ranks:
+        if r["pci_bus_id"] not in samplers:
+            try:
+                samplers[r["pci_bus_id"]] = PowerSampler(r["pci_bus_id"]).start()
+            except Exception:  # noqa: BLE001  (evidence, never a reason to fail the measurement)
+                pass
     t0 = time.perf_counter()
     while steps_done < args.steps:
         k = min(chunk, args.steps - steps_done, 1024)
@@ -740,6 +747,7 @@ def main_native(args):
             if args.time_box and el > args.time_box:
                 break
     wall = time.perf_counter() - t0
+    power = {bus: smp.stop() for bus, smp in samplers.items()}
     kern = [x / steps_done for x in kern]
     per = info["targets_per_device"]
     k_ms = max(kern)  # the slowest rank prices the roofline
@@ -779,6 +787,9 @@ def main_native(args):
         "kernel_ms_per_rank": kern,
         "non_kernel_ms_per_step": wall / steps_done * 1e3 - k_ms,
     }
+    if any(power.values()):
+        out["roofline"]["power_per_gpu"] = {bus: ({k: pw[k] for k in ("mean_w", "max_w", "cap_w", "sclk_mhz_mean", "sclk_mhz_min", "samples")}
+                                                  if pw else None) for bus, pw in power.items()}
     if sh.note:
         out["shared_pairs_note"] = sh.note
     if first_step:
@@ -1308,14 +1319,12 @@ def main():
         sysm.step()
     barrier()
     kern_ms.clear()
-    power = None
-    if world == 1:
-        try:
-            pr_ = torch.cuda.get_device_properties(dev_index)
-            power = PowerSampler(f"{getattr(pr_, 'pci_domain_id', 0):04x}:{getattr(pr_, 'pci_bus_id', 0):02x}:"
-                                 f"{getattr(pr_, 'pci_device_id', 0):02x}.0").start()
-        except Exception:  # noqa: BLE001
-            power = None
+    try:  # every rank samples its own GPU (world > 1: reported per rank in `ranks.per_rank[].power`, rank 0's also in `roofline.power`)
+        pr_ = torch.cuda.get_device_properties(dev_index)
+        power = PowerSampler(f"{getattr(pr_, 'pci_domain_id', 0):04x}:{getattr(pr_, 'pci_bus_id', 0):02x}:"
+                             f"{getattr(pr_, 'pci_device_id', 0):02x}.0").start()
+    except Exception:  # noqa: BLE001  (evidence, never a reason to fail the measurement)
+        power = None
     t0 = time.perf_counter()
     steps_done = 0
     ckpt_s = []
@@ -1367,6 +1376,8 @@ def main():
                   "pci_bus_id": f"{getattr(pr, 'pci_domain_id', 0):04x}:{getattr(pr, 'pci_bus_id', 0):02x}:"
                                 f"{getattr(pr, 'pci_device_id', 0):02x}.0",
                   "compute_units": pr.multi_processor_count, "first_target": lo, "targets": hi - lo, "kernel_ms": k_ms}
+            if power:
+                me["power"] = {k: power[k] for k in ("mean_w", "max_w", "cap_w", "sclk_mhz_mean", "sclk_mhz_min", "samples")}
             ids = [None] * world
             dist.all_gather_object(ids, me, group=ctl)
             rank_ids, kern_per_rank = ids, [r["kernel_ms"] for r in ids]

@@ -56,6 +56,9 @@ def test_native_host_line_without_a_launcher(nb):
     assert rk["count"] == 2 and rk["distinct_devices"] == 1 and rk["exchange"] == "copy"
     assert [x["first_target"] for x in rk["per_rank"]] == [0, 65536] and all(x["targets"] == 65536 for x in rk["per_rank"])
     assert all(len(x["uuid"]) == 32 and x["pci_bus_id"] and x["name"] for x in rk["per_rank"])
+    pw = r["roofline"].get("power_per_gpu")  # one entry per distinct GPU (amdgpu hwmon by PCI bus id); absent where sysfs hides it
+    if pw:
+        assert list(pw) == [rk["per_rank"][0]["pci_bus_id"]] and all(v is None or v["samples"] >= 1 for v in pw.values())
     # per-rank kernel time from HIP events on each rank's stream; the slowest rank prices the roofline
     assert len(r["kernel_ms_per_rank"]) == 2 and all(k > 0 for k in r["kernel_ms_per_rank"])
     assert r["roofline"]["kernel_ms"] == max(r["kernel_ms_per_rank"]) and 0 < r["roofline"]["frac"] < 1
