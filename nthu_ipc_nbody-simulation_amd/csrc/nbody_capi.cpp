@@ -228,7 +228,8 @@ void ensure_sym_workspace(nb_context* c) {
 // could be had, else K1
 F32Plan context_plan_f32(nb_context* c) {
     ensure_sym_workspace(c);
-    F32Plan plan = plan_f32(c->n, c->n, c->n_cus, 0, 0, c->partial != nullptr);
+    F32Plan plan = plan_f32(c->n, c->n, c->n_cus, 0, 0, c->partial != nullptr, 0, 0,
+                            c->partial_slots > 0 ? c->partial_slots : MAX_SLICES_PER_LAUNCH);
     if (c->sym_bytes)
         (void)plan_symmetric(plan, c->n, c->n, true, c->partial_bytes, c->cfg.precision == NB_F32_ACC64, c->n_cus, 0, 0);
     return plan;

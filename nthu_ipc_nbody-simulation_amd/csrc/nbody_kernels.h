@@ -212,7 +212,7 @@ bool plan_symmetric(F32Plan& p, long n_tgt, long n_src, bool whole, size_t works
                     int source_path, int force_chunks);
 // source_path: 0 = auto (SGPR), 1 = LDS tile, 2 = SGPR (3 = K1s, see plan_symmetric) ; force_wg: 0 = auto
 F32Plan plan_f32(long n_tgt, long n_src, int n_cus, int force_tpl, int force_js, bool have_workspace,
-                 int source_path = 0, int force_wg = 0);
+                 int source_path = 0, int force_wg = 0, int max_slices = MAX_SLICES_PER_LAUNCH);
 int launch_f32(const F32Args& a, const F32Plan& plan, bool acc64, bool accel_only, hipStream_t stream);  // hipError_t
 const char* kernel_name_f32(const F32Plan& plan, bool acc64, bool accel_only);
 

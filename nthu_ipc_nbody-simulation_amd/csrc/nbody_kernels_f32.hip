@@ -371,8 +371,32 @@ const char* kernel_name_f32(const F32Plan& plan, bool acc64, bool accel_only) {
 //  * without a workspace (no partial sums possible): one 1024-thread workgroup per CU, R = 4, whole source range,
 //    a barrier per 256 sources to keep the CU's waves on the same lines (55.6 %);
 //  * small systems: 256-thread workgroups, R = 4 or 2;  LDS path: 256 threads (one source per thread per tile).
+// Source slices of a WHOLE small system (n_tgt == n_src < 131072: 256-thread workgroups of 1024 targets, SGPR-fed), round 5.
+// Every slice count 1..64 was measured at 31 sizes from 1024 to 126976 bodies (bench/k1_small_n_model.py,
+// profiles/r05_k1_small_n_model.txt) and a two-parameter model of the launch reproduces the best choice within 9 % at every one
+// of them (exactly at 26): a workgroup that meets t source tiles costs 0.66 + t tile-times (prologue + epilogue = 0.66 of a
+// tile), and a CU that carries k such workgroups at once runs each 1 + 0.7 (k - 1) times slower — an extra co-resident
+// workgroup is cheaper than a second round, a half-filled extra round is not.  Rounds 2-4 took 16 slices at all of these
+// sizes: up to 50 % slower at 6144-10240 and 20480-26624 bodies, 2-3x slower below 4096.  `max_slices`: what one launch's
+// workspace holds (a second launch is outside the model).
+static long small_system_slices(long bx, long ntiles, int n_cus, long max_slices) {
+    long best_js = 1;
+    double best = 1e300;
+    for (long js = 1; js <= max_slices && js <= ntiles; ++js) {
+        const long t = (ntiles + js - 1) / js, eff = (ntiles + t - 1) / t;
+        if (eff != js) continue;  // the same cut as `eff` slices with empty workgroups behind it
+        const long k = (bx * eff + n_cus - 1) / n_cus;
+        const double cost = (1.0 + 0.7 * (double)(k - 1)) * (0.66 + (double)t);
+        if (cost < best) {  // ties: the smaller count
+            best = cost;
+            best_js = js;
+        }
+    }
+    return best_js;
+}
+
 F32Plan plan_f32(long n_tgt, long n_src, int n_cus, int force_tpl, int force_js, bool have_workspace, int source_path,
-                 int force_wg) {
+                 int force_wg, int max_slices) {
     F32Plan p;
     p.sgpr_sources = source_path != 1;
     const long ntiles = (n_src + TILE - 1) / TILE;
@@ -412,6 +436,9 @@ F32Plan plan_f32(long n_tgt, long n_src, int n_cus, int force_tpl, int force_js,
             if (n_tgt < 4096L * 32) {
                 while (js < 16 && js * 2 <= ntiles && (ntiles >= 16 || js * 2 * 2 <= ntiles)) js <<= 1;
                 if (n_src < 4096L * 32 && js > SLICES_PER_LAUNCH) js = SLICES_PER_LAUNCH;  // (measured for n_src = n_tgt)
+                // a whole system on the SGPR path: the measured model above instead of the fixed 16
+                if (p.sgpr_sources && wg == 256 && n_src == n_tgt && n_cus > 0)
+                    js = small_system_slices(bx, ntiles, n_cus, max_slices >= SLICES_PER_LAUNCH ? max_slices : SLICES_PER_LAUNCH);
             }
         }
     }

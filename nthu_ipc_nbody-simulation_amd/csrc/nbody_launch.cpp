@@ -51,7 +51,7 @@ static F32Plan resolve_plan(const nb_launch_f32* a) {
     // slices are planned for the sources this launch covers (a phase of a step covers a sub-range)
     const long n_cover = (a->src_begin || a->src_end) ? std::max<long>(1, a->src_end - a->src_begin) : a->n_src;
     F32Plan p = plan_f32(a->n_tgt, n_cover, cus, a->targets_per_lane, a->j_split, a->workspace != nullptr,
-                         a->source_path, a->wg_size);
+                         a->source_path, a->wg_size, workspace_slots(a));  // (a small whole system: slices one launch can hold)
     // the caller's workspace must hold SLICES_PER_LAUNCH partial records + running sum + compensation per target
     if (workspace_slots(a) < SLICES_PER_LAUNCH) p.j_split = 1;
     // K1s (every unordered pair once): the whole system in one launch and a workspace of nb_workspace_bytes_sym_f32

@@ -41,6 +41,20 @@ def test_accel_f32_small_and_ragged(nb, oracle, n):
     assert err < TOL_F32, (n, err)
 
 
+@pytest.mark.parametrize("n,slices", [(1536, 6), (3584, 14), (6144, 24), (10240 + 5, 21), (22528, 22), (24576, 32), (34816 - 300, 15)])
+def test_small_whole_systems_take_the_slices_the_model_picks(nb, oracle, n, slices):
+    """Round 5: a whole system below K1s' threshold cuts its sources by the measured co-residency model (plan_f32,
+    profiles/r05_k1_small_n_model.txt), not into a fixed 16 slices — ragged last tiles and slice counts that do not divide the
+    tiles included.  Every row against the oracle, in both arithmetic modes; the slice count itself on a 256-CU device."""
+    import torch
+    if torch.cuda.get_device_properties(0).multi_processor_count == 256:
+        assert nb.capi.plan_f32(n, n, workspace_bytes=66 * n * 16)[1] == slices
+    err, _, _ = _accel_err(nb, oracle, n, nb.capi.NB_F32)
+    assert err < TOL_F32, (n, err)
+    err, _, _ = _accel_err(nb, oracle, n, nb.capi.NB_F32_ACC64)
+    assert err < TOL_ACC64, (n, err)
+
+
 @pytest.mark.parametrize("n", [257, 4096, 16384 + 77])
 def test_accel_f32_acc64(nb, oracle, n):
     err, _, _ = _accel_err(nb, oracle, n, nb.capi.NB_F32_ACC64)

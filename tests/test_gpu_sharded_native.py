@@ -36,7 +36,8 @@ def test_one_device_equals_nb_step_bitwise(nb, precision, n):
     assert ms > 0 and info["devices"] == 1 and info["targets_per_device"] == n
     acc64 = prec == c.NB_F32_ACC64  # (from 36864 bodies on both pick K1s, which nb_create / nb_sharded_create size the workspace for)
     assert (info["targets_per_lane"], info["j_split"], info["wg_size"]) == \
-        c.plan_f32(n, n, acc64, workspace_bytes=c.workspace_bytes_sym_f32(n, acc64) or c.workspace_bytes_f32(n, acc64))
+        c.plan_f32(n, n, acc64, workspace_bytes=c.workspace_bytes_sym_f32(n, acc64) or c.workspace_bytes_f32(n, acc64) // 18 * 66)
+    # (below K1s' threshold both hosts give K1 room for up to 64 slices in one launch: 66 records per body, not the minimum 18)
     assert np.abs(q1 - q).max() > 1e-6
 
 
