@@ -356,14 +356,15 @@ int nbi::create_context(nb_context** out, const nb_config* cfg, hipStream_t borr
         c->ctl_host = (F64Ctl*)((char*)c->host_arena + 232);
         c->split = cfg->f64_split > 0 ? cfg->f64_split : auto_split_f64(c->n, c->n_cus);
         const int large_min = cfg->f64_large_min > 0 ? cfg->f64_large_min : F64_LARGE_MIN;
-        if (c->n >= large_min) {  // plain steps of a large fp64 system go through K1-f64
+        // every unordered pair once (K1s-f64) where its slots are affordable and eps > 0 (the self pair then adds +0): from 16384
+        // bodies on (SYM64_MIN_SB superblocks) unless the caller moved the threshold of the large path himself
+        const bool sym64 = cfg->eps * cfg->eps >= F64_EPS2_MIN && sym64_workspace_bytes(c->n, c->n_cus) > 0;
+        if (c->n >= large_min || (cfg->f64_large_min <= 0 && sym64)) {  // plain steps of a large fp64 system: K1s-f64, else K1-f64
             c->slices_large = plan_f64_large_slices(c->n, c->n_cus);
             NB_HIP(c, hipMalloc(&c->gm_large, n * sizeof(double)));
             if (c->slices_large > 1)
                 NB_HIP(c, hipMalloc(&c->partial_large, (size_t)c->slices_large * 3 * n * sizeof(double)));
-            // every unordered pair once (K1s-f64) where its slots are affordable and eps > 0 (the self pair then adds +0)
-            if (cfg->eps * cfg->eps >= F64_EPS2_MIN && sym64_workspace_bytes(c->n, c->n_cus) > 0)
-                NB_HIP(c, hipMalloc(&c->sym64_slots, sym64_workspace_bytes(c->n, c->n_cus)));
+            if (sym64) NB_HIP(c, hipMalloc(&c->sym64_slots, sym64_workspace_bytes(c->n, c->n_cus)));
         }
     } else {
         NB_HIP(c, hipMalloc(&c->pos[0], n * sizeof(float4)));

@@ -319,8 +319,16 @@ int plan_f64_large_slices(int n, int n_cus);
 // (register sums, LDS image, slots) in fp64.  Taken for eps > 0 when a.sym_slots (the slot workspace, sym64_workspace_bytes)
 // is given.
 constexpr int SYM64_SB = 2048;
+#ifndef NB_SYM64_MIN_SB
+#define NB_SYM64_MIN_SB 8
+#endif
+// K1s-f64 from this many superblocks on: 8 = 16384 bodies since round 5 (rounds 4: 16).  Measured with an A/B build
+// (-DNB_SYM64_MIN_SB=4, bench/f64_mid_n_sweep.py, profiles/r05_f64_mid_n_sweep.txt): K1s-f64 has a floor of ~0.21 ms per step
+// (few workgroups) and passes the per-step kernel K2 between 14336 and 16384 bodies — 0.218 ms against 0.231 at 16384, 0.294
+// against 0.50 at 24576, 0.42 against 0.80 at 30720
+constexpr int SYM64_MIN_SB = NB_SYM64_MIN_SB;
 constexpr size_t SYM64_MAX_WORKSPACE = (size_t)64 << 30;  // ceiling; by default 0.42 GB at n = 2^18 (one launch), then 1440 B per body
-size_t sym64_workspace_bytes(int n, int n_cus);  // 0: not applicable (fewer than 16 superblocks of 2048 bodies)
+size_t sym64_workspace_bytes(int n, int n_cus);  // 0: not applicable (fewer than SYM64_MIN_SB superblocks of 2048 bodies)
 int launch_f64_large_sym(const F64LargeArgs& a, int n_cus, hipStream_t stream);
 
 // K3: whole scenario of a small system (n <= SMALL_N_MAX) in ONE persistent single-workgroup launch

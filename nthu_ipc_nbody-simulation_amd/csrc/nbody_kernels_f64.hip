@@ -766,6 +766,10 @@ int launch_f64(const F64Args& a, int S, hipStream_t stream) {
 int auto_split_f64(int n, int n_cus) {
     // beyond the testcase sizes the launch is compute-bound instead: give every SIMD ~4 waves of fp64 work
     long want = (long)n_cus * K2_WG * (n > K2_TILE ? 8 : 1);
+    // round 5 (bench/f64_mid_n_sweep.py, profiles/r05_f64_mid_n_sweep.txt): between the testcase sizes and K1s-f64's threshold one
+    // doubling less is 4-13 % faster (6144 / 8192 bodies: S = 32, not 64; 12288: 16, not 32); from 16384 on the old bound stays the
+    // better one for the eps = 0 systems that still come here (28672: S = 16 is 10 % ahead of 8)
+    if (n > K2_TILE && n < 16384) want = want * 5 / 8;
     int S = 1;
     while (S < 64 && (long)n * S * 2 <= want) S <<= 1;
     return S;

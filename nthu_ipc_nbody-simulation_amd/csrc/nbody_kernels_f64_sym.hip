@@ -201,7 +201,7 @@ struct Sym64Batches {
 
 Sym64Batches sym64_batches(int n, int n_cus) {
     Sym64Batches k{};
-    if (n < 16 * SB) return k;
+    if (n < SYM64_MIN_SB * SB) return k;
     const F32SymShape whole = sym_shape(n, n_cus, 0, 0, 0, SB);
     if (shape_bytes64(whole) <= SYM_WHOLE_WORKSPACE) {
         k.nb = whole.B;
@@ -243,7 +243,7 @@ F32SymShape sym64_batch_shape(int n, int n_cus, const Sym64Batches& kb, int k) {
 size_t sym64_workspace_bytes(int n, int n_cus) { return sym64_batches(n, n_cus).bytes; }
 
 int launch_f64_large_sym(const F64LargeArgs& a, int n_cus, hipStream_t stream) {
-    if (!a.sym_slots || !a.gm || !(a.eps2 >= F64_EPS2_MIN) || a.n < 16 * SB) return (int)hipErrorInvalidValue;
+    if (!a.sym_slots || !a.gm || !(a.eps2 >= F64_EPS2_MIN) || a.n < SYM64_MIN_SB * SB) return (int)hipErrorInvalidValue;
     const Sym64Batches kb = sym64_batches(a.n, n_cus);
     if (kb.count < 1) return (int)hipErrorInvalidValue;
     const unsigned b1 = (unsigned)((a.n + WG - 1) / WG);

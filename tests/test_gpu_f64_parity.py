@@ -233,9 +233,9 @@ def test_persistent_engine_full_scenarios_b20(nb, oracle):
         big.run_scenario(nb.capi.NB_SCN_MIN_DIST, 0, 1, last_step=10, engine=2)  # n > 128: refused
 
 
-@pytest.mark.parametrize("n,eps", [(2049, 1e-3), (5000, 1e-3), (3000, 0.0), (20000, 1e-3)])
+@pytest.mark.parametrize("n,eps", [(2049, 1e-3), (5000, 1e-3), (3000, 0.0), (20000, 0.0), (20000, 1e-3)])  # (the last: K1s-f64 since round 5)
 def test_large_n_fp64_kernel(nb, oracle, n, eps):
-    """Large systems in NB_F64 go through K1-f64 (SGPR-fed, sliced, reducer; by default from 32768 bodies, forced here
+    """Large systems in NB_F64 go through K1-f64 (SGPR-fed, sliced, reducer; by default from 32768 bodies where K1s-f64 does not apply, forced here
     from 1024): accelerations and two steps vs the oracle, with `device` bodies (time-varying masses) present, ragged
     n, and eps = 0 (explicit self-pair exclusion)."""
     rng = np.random.default_rng(n)
@@ -265,11 +265,12 @@ def test_large_n_fp64_kernel(nb, oracle, n, eps):
         assert np.isfinite(q).all() and np.isfinite(v).all()
 
 
-@pytest.mark.parametrize("n", [16 * 2048, 17 * 2048 + 77, 40 * 2048 + 5,
+@pytest.mark.parametrize("n", [8 * 2048, 9 * 2048 + 77, 11 * 2048 - 1,  # round 5: from 8 superblocks on (16384 bodies; 16 until round 4)
+                               16 * 2048, 17 * 2048 + 77, 40 * 2048 + 5,
                                (1 << 20) + 123])  # > 2 GiB of slots in one launch: 9 batches of 64 superblocks (round 5; until
                                                   # round 4 systems beyond 1.1e6 bodies fell back to K1-f64, 1.5x slower)
 def test_large_n_fp64_symmetric_kernel(nb, oracle, n):
-    """From 16 superblocks of 2048 bodies on (and eps > 0) NB_F64 contexts run K1s-f64: every unordered pair once, the
+    """From 8 superblocks of 2048 bodies on (and eps > 0) NB_F64 contexts run K1s-f64: every unordered pair once, the
     sources travelling through the wave, fp64 throughout (csrc/nbody_kernels_f64_sym.hip).  Accelerations of rows from the
     first, a middle and the ragged last superblock and two steps (non-contracted kick-drift) against the oracle, with `device`
     bodies (time-varying masses) present; two launches give identical bits; sum m a cancels."""
