@@ -1185,7 +1185,7 @@ def main():
     ap.add_argument("--targets-per-lane", type=int, default=0)
     ap.add_argument("--j-split", type=int, default=0)
     ap.add_argument("--source-path", type=int, default=0, help="0 auto, 1 LDS tile, 2 SGPR/scalar loads (both: every ordered "
-                    "pair), 3 every unordered pair once (K1s; auto picks it for a whole system of >= 36864 bodies on one GPU)")
+                    "pair), 3 every unordered pair once (K1s; auto picks it for a whole system of >= 28672 bodies on one GPU)")
     ap.add_argument("--wg-size", type=int, default=0, help="0 auto, 256, 512 (with --targets-per-lane 8), 1024 (4)")
     ap.add_argument("--overlap", action="store_true", help="multi-GPU: two-phase step, own-shard sources while the "
                     "all-gather of the other shards is in flight (SURVEY 8(f)-3); default off, see overlap_ab in the JSON")

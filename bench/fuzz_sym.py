@@ -51,10 +51,12 @@ def main():
         if multi:
             ranks = int(rng.integers(2, 9))
             n = ranks * int(rng.integers(max(2, -(-9 // ranks)), 12)) * SB
+            while n * n < 1.1e9 * ranks:  # (below that the ranks do not share the pairs: include/nbody_amd_ext.h)
+                n += ranks * SB
             what = f"{ranks} ranks"
         else:
-            n = int(rng.integers(9 * SB + SB, 80 * SB)) - int(rng.integers(0, SB)) * int(rng.integers(2))
-            n = max(n, 36864)
+            n = int(rng.integers(7 * SB, 80 * SB)) - int(rng.integers(0, SB)) * int(rng.integers(2))
+            n = max(n, 28672)
             chunks = int(rng.choice([0, 0, 1, 2, 3, 5, 8]))
             what = f"chunks {chunks}"
         pos, _ = syn.body4_f32(n)

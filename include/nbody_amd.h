@@ -64,7 +64,7 @@ typedef struct nb_config {
 } nb_config;
 typedef enum nb_config_flags {
     NB_CFG_ORDERED_PAIRS = 1 /* fp32 modes: nb_step / nb_accel evaluate every ORDERED pair (kernel K1, 0.3-1 KB of workspace per
-                                body) even where the default applies.  Default from 36864 bodies on: every UNORDERED pair once
+                                body) even where the default applies.  Default from 28672 bodies on: every UNORDERED pair once
                                 (kernel K1s, 1.35x faster), which needs a pair-slot workspace — 1.7 GB at n = 2^20, beyond that
                                 720 B per body: 2.5 GB at 2^22, 10 GB at 2^24 (K1's source slices: 288-1056 B per body).  That workspace
                                 is allocated by the FIRST nb_step / nb_accel, not by nb_create; if the device cannot give it

@@ -40,7 +40,7 @@ int nb_solve_ex(int n, int planet, int asteroid, const double* qx, const double*
                 const int* devices, int n_devices, const nb_solve_options* options /* NULL = defaults */, nb_answer* out);
 
 /* symbol name of the force kernel nb_step / nb_accel of this fp32 context launch (for matching rocprofv3 rows, and to see
- * whether the context runs K1s or — NB_CFG_ORDERED_PAIRS, fewer than 36864 bodies, or its pair-slot workspace could not be
+ * whether the context runs K1s or — NB_CFG_ORDERED_PAIRS, fewer than 28672 bodies, or its pair-slot workspace could not be
  * had — K1).  Asks for the workspace like the first step would; "" for NB_F64 contexts */
 const char* nb_context_kernel_name(nb_context* ctx);
 
@@ -80,7 +80,7 @@ typedef struct nb_launch_f32 {
     int32_t source_path;      /* 0 = auto; 1 = sources through the LDS tile; 2 = sources through scalar loads/SGPRs (both: every
                                  ORDERED pair, kernel K1); 3 = every UNORDERED pair once, Newton's third law (kernel K1s: the
                                  sources travel through the wave by DPP rotation) — needs the whole system in this one launch
-                                 (n_tgt == n_src, tgt_off 0, phase WHOLE), n_src >= 36864 and a workspace of
+                                 (n_tgt == n_src, tgt_off 0, phase WHOLE), n_src >= 28672 and a workspace of
                                  nb_workspace_bytes_sym_f32(); auto picks it whenever that holds and nothing else is forced;
                                  j_split then = workgroups per 4096-body superblock (0 = auto) */
     int32_t wg_size;          /* 0 = auto; 256, 512 (targets_per_lane 8) or 1024 (targets_per_lane 4) */
@@ -113,13 +113,13 @@ int64_t nb_workspace_bytes_f32(int64_t n_tgt, int acc64);
  * floats per body and round plus three (six with acc64) per workgroup of a superblock: 12 B x (n/8192 + 16) per body, 1.8 GB at
  * n = 2^20 — beyond that batches of 32 superblocks within 720 B per body: 2.5 GB at 2^22, 5 GB at 2^23, 10 GB at 2^24, 40 GB at
  * 2^26 (rounds 1-4: a slot per round up to 32 GiB — 26 GB at 2^22 — then 52 GB; the smaller shapes measure 0.8 % FASTER);
- * 0 = K1s does not apply to this n (fewer than 36864 bodies) */
+ * 0 = K1s does not apply to this n (fewer than 28672 bodies) */
 int64_t nb_workspace_bytes_sym_f32(int64_t n, int acc64);
 
 /* ---- K1s over several GPUs, for hosts that own the collectives themselves (one process per GPU: nbody_amd.distributed).
  * The GPUs share the UNORDERED pairs of the system: rank r = tgt_off / n_tgt of P = n_src / n_tgt takes the 4096-body
  * superblocks of its shard against the half of the system behind each.  Needs whole superblocks per shard
- * (n_src % (P * 4096) == 0), n_src >= 36864 and n_src^2 / P >= 1.1e9 (below, a rank's ordered-pair step is faster than its share):
+ * (n_src % (P * 4096) == 0), n_src >= 28672 and n_src^2 / P >= 1.1e9 (below, a rank's ordered-pair step is faster than its share):
  * nb_workspace_bytes_shared_pairs_f32 answers 0 otherwise (use the ordered
  * launches above).  Per step and rank:
  *   nb_launch_pair_forces_f32   a->acc = float4[n_src] (double4 with acc64): this rank's partial force on ALL bodies
@@ -154,7 +154,7 @@ int nb_selftest_pair_schedule_within(int64_t n, int n_cus, int acc64, int64_t wo
  * The reference's only multi-GPU use is task parallelism (hw5.cu:564-567,587-588); this is the data-parallel scheme of
  * GPU r owns targets [r*n/P, (r+1)*n/P) (velocities, fp64 masters), every GPU holds all positions twice
  * (ping-pong float4[n] {x,y,z,G*m}).  Per step and GPU, on its own stream:
- *   default (whole 4096-body superblocks per shard, n >= 36864, no overlap): its share of the UNORDERED pairs of the system
+ *   default (whole 4096-body superblocks per shard, n >= 28672, no overlap): its share of the UNORDERED pairs of the system
  *     (kernel K1s) -> a partial force on all n bodies -> ONE ncclReduceScatter (sum) to the shard owners -> kick-drift;
  *   otherwise / NB_SHARDED_ORDERED_PAIRS: every ordered pair of its own targets with the kick-drift fused (kernel K1);
  *   then ONE in-place ncclAllGather(sendbuff = recvbuff + r*4n/P, ncclFloat) of the positions.
@@ -170,7 +170,7 @@ typedef struct nb_sharded nb_sharded;
                                 sharing a GPU, each with its own streams and arrays — which is how a one-GPU box executes the
                                 P > 1 host logic (tests/test_gpu_sharded_native.py) */
 #define NB_SHARDED_ORDERED_PAIRS 4 /* every GPU evaluates every ordered pair of its targets (kernel K1) even where the default
-                                applies: when every shard is a whole number of 4096-body superblocks, n >= 36864 and the step is
+                                applies: when every shard is a whole number of 4096-body superblocks, n >= 28672 and the step is
                                 not overlapped, the GPUs share the UNORDERED pairs of the system instead (kernel K1s: GPU r takes
                                 the superblocks of its shard against the half of the system behind each), which leaves every GPU
                                 with a partial force on all n bodies — one reduce-scatter per step (ncclReduceScatter, or peer

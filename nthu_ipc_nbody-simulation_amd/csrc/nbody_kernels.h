@@ -54,12 +54,13 @@ constexpr int MAX_JSPLIT = 1024;       // source slices per step (processed SLIC
 constexpr int SYM_P = 4, SYM_WGS = 512;            // packed target pairs per lane, threads per workgroup (8 waves)
 constexpr int SYM_SB = SYM_WGS * 2 * SYM_P;        // superblock: 4096 bodies, the targets one workgroup holds in registers
 #ifndef NB_SYM_MIN_N
-#define NB_SYM_MIN_N 36864
+#define NB_SYM_MIN_N 28672
 #endif
-constexpr long SYM_MIN_N = NB_SYM_MIN_N;           // 9 superblocks.  K1s has a floor of ~0.33 ms per step (a workgroup does at least 8 tile
-                                                   // phases), K1 grows with n^2: measured round 5 (bench/small_n_sym_ab.py,
-                                                   // profiles/r05_small_n_sym_ab.txt) K1 wins by 18 % at 32768 bodies, K1s by 26 % at 36864,
-                                                   // 37 % at 40960, 31 % at 45056 (rounds 3-4 started K1s at 49152)
+constexpr long SYM_MIN_N = NB_SYM_MIN_N;           // 7 superblocks.  K1s has a floor per step (a workgroup does at least SYM_MIN_PHASES tile
+                                                   // phases of ~42 us), K1 grows with n^2.  Round 5, with 8 phases (floor 0.33 ms): K1 wins by
+                                                   // 18 % at 32768 bodies, K1s by 26 % at 36864 (profiles/r05_small_n_sym_ab.txt; rounds 3-4 started
+                                                   // K1s at 49152); with 4 phases (floor 0.18 ms, profiles/r05_sym_min_phases_ab.txt) and K1's
+                                                   // modelled slices: K1 wins by 20 % at 24499, K1s by 22 % at 28672, 24 % at 32768, 33 % at 36864
 constexpr size_t SYM_MAX_WORKSPACE = (size_t)128 << 30;  // absolute ceiling of a K1s workspace (what it takes by default: sym_batch_budget)
 struct F32SymShape {  // who computes what in one launch
     int B;         // superblocks covering the system
@@ -80,6 +81,15 @@ __host__ __device__ inline int sym_total_slots(const F32SymShape& s, bool acc64)
 
 // ---- the pair schedule, shared by the force kernel, the reducer and the host-side self-test (nb_selftest_pair_schedule)
 constexpr int SYM_NT = SYM_SB / 128;  // tile phases of one work unit (a wave meets one 128-source tile per phase)
+#ifndef NB_SYM_MIN_PHASES
+#define NB_SYM_MIN_PHASES 4
+#endif
+// tile phases a workgroup executes at least: bounds the workgroups per superblock, i.e. how well a system of few superblocks fills the
+// chip.  8 until round 5 (a quarter of a work unit); the pair schedule holds for any value (a workgroup has at most one piece that does
+// not start its round whatever its length: nb_selftest_pair_schedule, builds with 4 and 2) and 4 measures 24 % faster at 36864
+// bodies (0.342 -> 0.277 ms: 0.51 -> 0.63 of peak), 32 % for K1s-f64 at 16384, the same from 40960 on; 2 adds nothing where K1s is
+// used (profiles/r05_sym_min_phases_ab.txt)
+constexpr int SYM_MIN_PHASES = NB_SYM_MIN_PHASES;
 // rounds of I-superblock b: J = b + r (mod B), r = 1 .. (B-1)/2, plus r = B/2 for the lower half when B is even
 __host__ __device__ inline int sym_rounds(int B, int b) { return (B - 1) / 2 + ((B % 2 == 0 && b < B / 2) ? 1 : 0); }
 // the phases [q_lo, q_hi) of superblock b's work (unit u = q / SYM_NT: 0 = the diagonal block, r = round r) that

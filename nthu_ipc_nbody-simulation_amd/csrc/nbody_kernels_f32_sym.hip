@@ -353,7 +353,7 @@ bool plan_symmetric(F32Plan& p, long n_tgt, long n_src, bool whole, size_t works
 static int sym_choose_chunks(int nb, int B, int n_cus, int force_chunks) {
     // a chunk holds at least 8 tile phases (a quarter of a work unit): every chunk then has at most one piece that does not
     // start its round — the one its tail slot is for
-    const int c_max = (int)((long)SYM_NT * (1 + B / 2) / 8);
+    const int c_max = (int)((long)SYM_NT * (1 + B / 2) / SYM_MIN_PHASES);
     int c = force_chunks;
     if (c <= 0) {
         double best = 1e30;

@@ -66,7 +66,7 @@ static F32Plan resolve_plan(const nb_launch_f32* a) {
 static int refuse_unmet_symmetric(const nb_launch_f32* a, const F32Plan& p) {
     if (a->source_path == 3 && !p.symmetric)
         return set_error(NB_ERR_INVALID, "source_path 3 (every unordered pair once) needs the whole system in one launch "
-                         "(n_tgt == n_src, tgt_off 0, no phases), n_src >= 36864 and a workspace of nb_workspace_bytes_sym_f32");
+                         "(n_tgt == n_src, tgt_off 0, no phases), n_src >= 28672 and a workspace of nb_workspace_bytes_sym_f32");
     return NB_OK;
 }
 
@@ -138,7 +138,7 @@ int nb_launch_pair_forces_f32(const nb_launch_f32* a, void* hip_stream) {
     if (!a || !a->src || !a->acc || !a->workspace || !(a->eps2 >= F32_EPS2_MIN) || a->tgt || a->phase != NB_PHASE_WHOLE || a->src_begin ||
         a->src_end || !shared_pairs_shape(a, &sh))
         return set_error(NB_ERR_INVALID, "nb_launch_pair_forces_f32: the shard must be whole 4096-body superblocks of a system of "
-                         ">= 36864 bodies (n_src = ranks * n_tgt, tgt_off = rank * n_tgt), with acc and a workspace");
+                         ">= 28672 bodies (n_src = ranks * n_tgt, tgt_off = rank * n_tgt), with acc and a workspace");
     if ((size_t)a->workspace_bytes < sym_partial_workspace_bytes(sh, a->acc64 != 0))
         return set_error(NB_ERR_INVALID, "nb_launch_pair_forces_f32: workspace smaller than nb_workspace_bytes_shared_pairs_f32");
     hipError_t e = (hipError_t)launch_f32_sym(to_args(a), sh, a->acc64 != 0, 2, (hipStream_t)hip_stream);

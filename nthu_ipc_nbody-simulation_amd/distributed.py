@@ -27,7 +27,7 @@ whose positions do not fit twice on one device, parity-tested against the all-ga
 evaluated once, by the rank that owns the earlier of its two 4096-body superblocks (cyclically), with the symmetric kernel
 K1s (capi.launch_pair_forces_f32).  A rank then holds a partial force on ALL N bodies: per step ONE reduce-scatter (sum) of
 float4[N] hands every shard owner its total, the owner kicks and drifts (capi.launch_kick_drift_f32), and the all-gather of
-positions follows as before.  Needs whole superblocks per shard (N % (4096 P) == 0) and N >= 36864; K1s reaches ~0.79 of
+positions follows as before.  Needs whole superblocks per shard (N % (4096 P) == 0) and N >= 28672; K1s reaches ~0.79 of
 the fp32 peak per GPU where the ordered-pair kernel K1 reaches ~0.59.
 
 torch is used for device memory, the stream and the collective only; the arithmetic is the HIP kernel behind
@@ -151,7 +151,7 @@ class ShardedSystem:
         can = self._all_ranks(can, device)
         if shared_pairs and not can:
             raise ValueError("shared_pairs needs >= 2 ranks, HIP tensors, the all-gather exchange without overlap, "
-                             "n % (4096 * world) == 0 and n >= 36864 — on EVERY rank")
+                             "n % (4096 * world) == 0 and n >= 28672 — on EVERY rank")
         self.shared_pairs = can if shared_pairs is None else bool(shared_pairs)
         self.shared_pairs_note = None
         if self.shared_pairs and shared_pairs is None and dist.get_backend(group) == "nccl":

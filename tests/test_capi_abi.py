@@ -336,31 +336,31 @@ def test_pair_schedule_of_the_symmetric_kernel_on_shapes_no_box_here_can_run(nb)
     with pytest.raises(c.NBodyError, match="cannot share"):
         c.selftest_pair_schedule(1 << 15, 256, 2)         # too few bodies
     with pytest.raises(c.NBodyError, match="does not apply"):
-        c.selftest_pair_schedule(36863, 256, 1)
+        c.selftest_pair_schedule(28671, 256, 1)
 
     @settings(max_examples=60, deadline=None)
-    @given(st.integers(9, 700), st.integers(0, SB - 1), st.sampled_from([64, 104, 228, 256, 304]), st.booleans())
+    @given(st.integers(7, 700), st.integers(0, SB - 1), st.sampled_from([64, 104, 228, 256, 304]), st.booleans())
     def one_gpu(blocks, ragged, cus, acc64):
-        if blocks * SB - ragged >= 36864:  # (below that K1s does not apply and the self-test says so)
+        if blocks * SB - ragged >= 28672:  # (below that K1s does not apply and the self-test says so)
             c.selftest_pair_schedule(blocks * SB - ragged, cus, 1, acc64)
 
     @settings(max_examples=40, deadline=None)
     @given(st.integers(2, 8), st.integers(4, 96), st.sampled_from([64, 256, 304]), st.booleans())
     def several_gpus(ranks, per_rank, cus, acc64):
         n = ranks * per_rank * SB
-        if n >= 36864 and n * n >= 1.1e9 * ranks:  # (below: a rank's K1 step beats its K1s share, the ranks do not share the pairs)
+        if n >= 28672 and n * n >= 1.1e9 * ranks:  # (below: a rank's K1 step beats its K1s share, the ranks do not share the pairs)
             c.selftest_pair_schedule(n, cus, ranks, acc64)
         else:
             with pytest.raises(c.NBodyError, match="cannot share"):
                 c.selftest_pair_schedule(n, cus, ranks, acc64)
 
     @settings(max_examples=60, deadline=None)
-    @given(st.integers(9, 1100), st.integers(0, SB - 1), st.sampled_from([104, 256, 304]), st.booleans(), st.floats(0.02, 1.0))
+    @given(st.integers(7, 1100), st.integers(0, SB - 1), st.sampled_from([104, 256, 304]), st.booleans(), st.floats(0.02, 1.0))
     def one_gpu_within_a_budget(blocks, ragged, cus, acc64, share):
         """A workspace smaller than the fastest shape wants (NB_CFG_WORKSPACE_GIB, a raw launch's workspace, a device short of
         memory): batches of superblocks — every pair once, within the budget, or an honest "does not apply"."""
         n = blocks * SB - ragged
-        if n < 36864:
+        if n < 28672:
             return
         full = c.workspace_bytes_sym_f32(n, acc64)
         if full <= 0:

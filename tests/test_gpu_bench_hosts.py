@@ -139,7 +139,7 @@ def test_single_gpu_line_reports_the_lds_kernel_and_step_traffic(nb):
                         "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=_env(), cwd=ROOT)
     r = _line(p)
     assert r["n_gpus"] == 1 and r["host"] == "single" and r["parity_spot"]["ok"]
-    # a whole system of >= 36864 bodies on one GPU: K1s (every unordered pair once) is what is timed; the two kernels that
+    # a whole system of >= 28672 bodies on one GPU: K1s (every unordered pair once) is what is timed; the two kernels that
     # evaluate every ordered pair are measured beside it by the same run
     assert r["roofline"]["kernel"] == "nbody_force_sym_f32<false>" and r["roofline"]["pair_evaluation"].startswith("each unordered")
     assert r["roofline"]["kernel_ms_spans"] == ["nbody_force_sym_f32<false>", "nbody_reduce_sym_f32<false, 0>"]

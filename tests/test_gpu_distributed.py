@@ -143,7 +143,7 @@ def test_ranks_on_one_gpu_match_single_acc64(nb, oracle, tmp_path, world):
 
 @pytest.mark.parametrize("world,acc64", [(2, False), (4, True)])
 def test_ranks_sharing_the_unordered_pairs_match_single(nb, oracle, tmp_path, world, acc64):
-    """shared_pairs (the default from 36864 bodies on, whole 4096-body superblocks per shard): every rank runs K1s on its
+    """shared_pairs (the default from 28672 bodies on, whole 4096-body superblocks per shard): every rank runs K1s on its
     share of the UNORDERED pairs, the partial forces on all N bodies are summed to their owners (reduce-scatter; through
     host memory in this gloo rehearsal), the owner kicks and drifts.  Two steps of N = 2^18 against the one-rank run (K1s on
     the whole system) and the first step's velocities against oracle rows of every shard."""

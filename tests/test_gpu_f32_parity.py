@@ -41,7 +41,7 @@ def test_accel_f32_small_and_ragged(nb, oracle, n):
     assert err < TOL_F32, (n, err)
 
 
-@pytest.mark.parametrize("n,slices", [(1536, 6), (3584, 14), (6144, 24), (10240 + 5, 21), (22528, 22), (24576, 32), (34816 - 300, 15)])
+@pytest.mark.parametrize("n,slices", [(1536, 6), (3584, 14), (6144, 24), (10240 + 5, 21), (22528, 22), (24576, 32), (28672 - 300, 16)])  # (from 28672 bodies on a context runs K1s)
 def test_small_whole_systems_take_the_slices_the_model_picks(nb, oracle, n, slices):
     """Round 5: a whole system below K1s' threshold cuts its sources by the measured co-residency model (plan_f32,
     profiles/r05_k1_small_n_model.txt), not into a fixed 16 slices — ragged last tiles and slice counts that do not divide the

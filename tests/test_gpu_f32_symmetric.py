@@ -31,10 +31,12 @@ def _launch(nb, torch, src, n, acc64, source_path, accel=None, j_split=0, out=No
     return ws
 
 
-@pytest.mark.parametrize("n,chunks", [(9 * SB, 0),           # the smallest system K1s takes (round 5: 36864 bodies; B = 9, odd)
+@pytest.mark.parametrize("n,chunks", [(7 * SB, 0),           # the smallest system K1s takes (end of round 5: 28672 bodies; B = 7, 32 workgroups each)
+                                      (8 * SB - 1234, 0),    # B = 8, ragged: 4-phase pieces, several cuts inside one round
+                                      (9 * SB, 0),           # (the threshold of mid-round 5: 36864 bodies; B = 9, odd)
                                       (10 * SB - 100, 0),    # B = 10, even, ragged
                                       (12 * SB, 0),          # rounds 3-4's smallest: 7 work units per superblock cut into
-                                                             # sub-unit chunks (>= 8 of a unit's 32 tile phases each)
+                                                             # sub-unit chunks (>= 4 of a unit's 32 tile phases each; 8 until round 5)
                                       (16 * SB + 3, 0),      # B = 17, odd, ragged
                                       (64 * SB, 0),          # B = 64: even, the half round B/2 for b < 32
                                       (65 * SB + 77, 0),     # B = 66 with a ragged last superblock (4019 bodies missing)
@@ -81,7 +83,7 @@ def test_symmetric_accelerations_vs_oracle_and_k1(nb, oracle, n, chunks, acc64):
 
 
 def test_symmetric_is_bitwise_reproducible_and_is_what_a_context_runs(nb, oracle):
-    """No atomics anywhere: two launches give identical bits; nb_accel / nb_step of a context with >= 36864 bodies pick
+    """No atomics anywhere: two launches give identical bits; nb_accel / nb_step of a context with >= 28672 bodies pick
     K1s by themselves (the workspace is sized for it at nb_create) and give exactly the raw launch's numbers."""
     import torch
     c, syn = nb.capi, nb.synthetic
@@ -150,7 +152,7 @@ def test_symmetric_refusals_and_fallbacks(nb):
     big = torch.empty(c.workspace_bytes_sym_f32(n), dtype=torch.uint8, device="cuda")
     small = torch.empty(c.workspace_bytes_f32(n), dtype=torch.uint8, device="cuda")
     assert 9e9 < c.workspace_bytes_sym_f32(1 << 24) < 13e9  # 412 GB of slots in one launch: 128 batches of 32 superblocks within 720 B per body
-    assert c.workspace_bytes_sym_f32(SB * 8) == 0 and c.workspace_bytes_sym_f32(1 << 28) == 0  # too small / no batch of superblocks fits 128 GiB
+    assert c.workspace_bytes_sym_f32(SB * 7 - 1) == 0 and c.workspace_bytes_sym_f32(SB * 7) > 0 and c.workspace_bytes_sym_f32(1 << 28) == 0  # too small / no batch of superblocks fits 128 GiB
     for kw in (dict(workspace_ptr=small.data_ptr(), workspace_bytes=small.numel()),                      # workspace too small
                dict(workspace_ptr=big.data_ptr(), workspace_bytes=big.numel(), src_begin=0, src_end=n // 2),  # a source range
                dict(workspace_ptr=big.data_ptr(), workspace_bytes=big.numel(), tgt_ptr=src.data_ptr())):  # a target block

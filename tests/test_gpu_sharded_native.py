@@ -34,7 +34,7 @@ def test_one_device_equals_nb_step_bitwise(nb, precision, n):
         info = sh.info()
     assert np.array_equal(q0, q1) and np.array_equal(v0, v1)
     assert ms > 0 and info["devices"] == 1 and info["targets_per_device"] == n
-    acc64 = prec == c.NB_F32_ACC64  # (from 36864 bodies on both pick K1s, which nb_create / nb_sharded_create size the workspace for)
+    acc64 = prec == c.NB_F32_ACC64  # (from 28672 bodies on both pick K1s, which nb_create / nb_sharded_create size the workspace for)
     assert (info["targets_per_lane"], info["j_split"], info["wg_size"]) == \
         c.plan_f32(n, n, acc64, workspace_bytes=c.workspace_bytes_sym_f32(n, acc64) or c.workspace_bytes_f32(n, acc64) // 18 * 66)
     # (below K1s' threshold both hosts give K1 room for up to 64 slices in one launch: 66 records per body, not the minimum 18)
@@ -91,7 +91,7 @@ def test_ranks_sharing_one_gpu_follow_nb_step_and_the_oracle(nb, oracle, ranks, 
 @pytest.mark.parametrize("precision", ["NB_F32", "NB_F32_ACC64"])
 @pytest.mark.parametrize("ranks", [2, 4])
 def test_ranks_share_the_unordered_pairs(nb, oracle, ranks, precision):
-    """From 36864 bodies on (whole 4096-body superblocks per shard, step not overlapped) the GPUs share the UNORDERED pairs
+    """From 28672 bodies on (whole 4096-body superblocks per shard, step not overlapped) the GPUs share the UNORDERED pairs
     of the system: K1s per rank on the superblocks of its shard, the partial forces on all bodies reduce-scattered to the
     shard owners (copy exchange here: peer copies + an ordered sum in the kick-drift kernel), then the all-gather.  One
     step against oracle rows of every shard, three against nb_step (K1s on one GPU) and against the ordered-pair form."""
