@@ -13,6 +13,10 @@ import nbody_amd  # noqa: E402,F401
 from nbody_amd import capi as c, synthetic as syn  # noqa: E402
 
 CUS = torch.cuda.get_device_properties(0).multi_processor_count
+RANKS = 1  # --ranks P: the step of ONE rank of P (targets = the first n / P bodies, sources = all n): does the model hold for shards?
+if len(sys.argv) > 2 and sys.argv[1] == "--ranks":
+    RANKS = int(sys.argv[2])
+    del sys.argv[1:3]
 SIZES = [int(a) for a in sys.argv[1:]] or list(range(4096, 36864 + 1, 2048))
 
 
@@ -30,9 +34,11 @@ for n in SIZES:
     out = torch.zeros_like(src)
     v = torch.from_numpy(vel).cuda()
     stream = torch.cuda.current_stream().cuda_stream
-    ws = torch.empty(66 * n * 16, dtype=torch.uint8, device="cuda")  # room for 64 slices in one launch
-    auto = c.plan_f32(n, n, False, 0, 0, ws.numel(), 2)
-    blocks, ntiles = -(-n // 1024), -(-n // 256)
+    per = n // RANKS
+    v = v[:per].contiguous()
+    ws = torch.empty(66 * per * 16, dtype=torch.uint8, device="cuda")  # room for 64 slices in one launch
+    auto = c.plan_f32(n, per, False, 0, 0, ws.numel(), 2)
+    blocks, ntiles = -(-per // 1024), -(-n // 256)
     res = {}
     seen = {}
     for js in [0] + list(range(1, min(64, ntiles) + 1)):
@@ -41,7 +47,7 @@ for n in SIZES:
             if t in seen:
                 continue
             seen[t] = js
-        step = lambda: c.launch_f32(src.data_ptr(), out.data_ptr(), n, 0, n, syn.EPS ** 2, syn.DT, stream, vel_ptr=v.data_ptr(),  # noqa: E731
+        step = lambda: c.launch_f32(src.data_ptr(), out.data_ptr(), n, 0, per, syn.EPS ** 2, syn.DT, stream, vel_ptr=v.data_ptr(),  # noqa: E731
                                     source_path=2, j_split=js, workspace_ptr=ws.data_ptr(), workspace_bytes=ws.numel())
         best = 1e9
         for rnd in range(3):
@@ -57,7 +63,7 @@ for n in SIZES:
         res[js] = best
     table[n] = (blocks, ntiles, auto[1], res)
     b = min((k for k in res if k), key=res.get)
-    print(f"n = {n:6d}  {blocks:2d} blocks {ntiles:3d} tiles  plan {auto[1]:2d} slices {res[0]:.4f} ms  best {b:2d} slices {res[b]:.4f} ms "
+    print(f"n = {n:6d}{'' if RANKS == 1 else ' / %d ranks' % RANKS}  {blocks:2d} blocks {ntiles:3d} tiles  plan {auto[1]:2d} slices {res[0]:.4f} ms  best {b:2d} slices {res[b]:.4f} ms "
           f"(plan {100 * (res[0] / res[b] - 1):+.0f} %)   " + " ".join(f"{k}:{t:.4f}" for k, t in res.items() if k), flush=True)
 
 

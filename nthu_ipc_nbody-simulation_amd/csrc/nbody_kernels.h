@@ -61,6 +61,10 @@ constexpr long SYM_MIN_N = NB_SYM_MIN_N;           // 7 superblocks.  K1s has a 
                                                    // 18 % at 32768 bodies, K1s by 26 % at 36864 (profiles/r05_small_n_sym_ab.txt; rounds 3-4 started
                                                    // K1s at 49152); with 4 phases (floor 0.18 ms, profiles/r05_sym_min_phases_ab.txt) and K1's
                                                    // modelled slices: K1 wins by 20 % at 24499, K1s by 22 % at 28672, 24 % at 32768, 33 % at 36864
+#ifndef NB_SYM_SHARE_MIN
+#define NB_SYM_SHARE_MIN 1.1e9
+#endif
+constexpr double SYM_SHARE_MIN_N2_PER_RANK = NB_SYM_SHARE_MIN;  // several GPUs share the unordered pairs from n^2 / P >= this on (sym_sharded_ok)
 constexpr size_t SYM_MAX_WORKSPACE = (size_t)128 << 30;  // absolute ceiling of a K1s workspace (what it takes by default: sym_batch_budget)
 struct F32SymShape {  // who computes what in one launch
     int B;         // superblocks covering the system

@@ -371,7 +371,7 @@ const char* kernel_name_f32(const F32Plan& plan, bool acc64, bool accel_only) {
 //  * without a workspace (no partial sums possible): one 1024-thread workgroup per CU, R = 4, whole source range,
 //    a barrier per 256 sources to keep the CU's waves on the same lines (55.6 %);
 //  * small systems: 256-thread workgroups, R = 4 or 2;  LDS path: 256 threads (one source per thread per tile).
-// Source slices of a WHOLE small system (n_tgt == n_src < 131072: 256-thread workgroups of 1024 targets, SGPR-fed), round 5.
+// Source slices of a small system or shard (n_tgt < 131072: 256-thread workgroups of 1024 targets, SGPR-fed), round 5.
 // Every slice count 1..64 was measured at 31 sizes from 1024 to 126976 bodies (bench/k1_small_n_model.py,
 // profiles/r05_k1_small_n_model.txt) and a two-parameter model of the launch reproduces the best choice within 9 % at every one
 // of them (exactly at 26): a workgroup that meets t source tiles costs 0.66 + t tile-times (prologue + epilogue = 0.66 of a
@@ -436,9 +436,13 @@ F32Plan plan_f32(long n_tgt, long n_src, int n_cus, int force_tpl, int force_js,
             if (n_tgt < 4096L * 32) {
                 while (js < 16 && js * 2 <= ntiles && (ntiles >= 16 || js * 2 * 2 <= ntiles)) js <<= 1;
                 if (n_src < 4096L * 32 && js > SLICES_PER_LAUNCH) js = SLICES_PER_LAUNCH;  // (measured for n_src = n_tgt)
-                // a whole system on the SGPR path: the measured model above instead of the fixed 16
-                if (p.sgpr_sources && wg == 256 && n_src == n_tgt && n_cus > 0)
-                    js = small_system_slices(bx, ntiles, n_cus, max_slices >= SLICES_PER_LAUNCH ? max_slices : SLICES_PER_LAUNCH);
+                // the SGPR path: the measured model above instead of the fixed 16 (whole systems) / powers of two (shards: a
+                // rank of 2, 4, 8 of 32768 .. 524288 bodies measured the same way, the same two parameters within 3 % of the best
+                // where the old rule was up to 2x off — 65536 / 8: 0.30 -> 0.15 ms, 81920 / 4: 0.65 -> 0.41; profiles/
+                // r05_k1_small_n_model.txt).  Slices stay L2-sized (<= 512 tiles), which one launch of 64 can do up to 8.4e6 sources.
+                const long slots = max_slices >= SLICES_PER_LAUNCH ? max_slices : SLICES_PER_LAUNCH;
+                if (p.sgpr_sources && wg == 256 && n_cus > 0 && ntiles <= 512L * slots)
+                    js = small_system_slices(bx, ntiles, n_cus, slots);
             }
         }
     }

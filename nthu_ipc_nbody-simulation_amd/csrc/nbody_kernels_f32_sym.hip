@@ -523,7 +523,7 @@ bool sym_sharded_ok(long n, int P, int n_cus, bool acc64, F32SymShape* shape_of_
     // a rank's share of K1s has the same floor as a whole launch (~0.33 ms: a workgroup does at least 8 tile phases) while its K1
     // step shrinks with n^2 / P: measured per rank (bench/shard_pairs_ab.py, profiles/r05_small_n_sym_ab.txt) K1 wins at
     // n = 65536 over 8 and over 4 ranks and at 40960 over 2, K1s at 98304 / 8, 81920 / 4, 49152 / 2: the crossover is n^2 / P ~ 1.1e9
-    if ((double)n * (double)n < 1.1e9 * (double)P) return false;
+    if ((double)n * (double)n < SYM_SHARE_MIN_N2_PER_RANK * (double)P) return false;
     const int B = (int)(n / SYM_SB);
     const F32SymShape s = sym_shape(n, n_cus, 0, B / P, 0);
     if (sym_partial_workspace_bytes(s, acc64) > SYM_MAX_WORKSPACE) return false;
