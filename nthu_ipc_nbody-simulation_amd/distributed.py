@@ -55,8 +55,9 @@ def workspace_bytes(n_src, n_tgt, acc64=False, targets_per_lane=0, j_split=0, so
     js/16 of each (N = 2^20 over 8 ranks, 64 slices: 29.7 instead of 30.5 ms per step and rank,
     profiles/r03_shard_slots.txt), within `cap` bytes."""
     base = capi.workspace_bytes_f32(n_tgt, acc64)
-    _, js, _ = capi.plan_f32(n_src, n_tgt, acc64, targets_per_lane, j_split, base, source_path, wg_size)
     rec = base // 18
+    # (asked with room for 64 slices: a small shard's slice count is chosen within what ONE launch's workspace holds)
+    _, js, _ = capi.plan_f32(n_src, n_tgt, acc64, targets_per_lane, j_split, 66 * rec, source_path, wg_size)
     slots = max(16, min(64, js, cap // rec - 2))
     sliced = (slots + 2) * rec
     if n_src == n_tgt and source_path in (0, 3):  # one rank holds the whole system: room for K1s' pair slots
