@@ -98,6 +98,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _same_to_fp32_rounding(a, b):
+    """Two fp32 trajectories of the same system whose launches sum in different orders: all but a handful of bodies within an
+    ulp or two, the handful (closest neighbour rounded the other way) within the amplification bound."""
+    dq, dv = np.abs(a["pos"] - b["pos"]).max(axis=1), np.abs(a["vel"] - b["vel"]).max(axis=1)
+    assert np.quantile(dq, 0.999) < 2.5e-7 and np.quantile(dv, 0.999) < 2e-6, (np.quantile(dq, 0.999), np.quantile(dv, 0.999))
+    assert dq.max() < 5e-6 and dv.max() < 2e-4, (dq.max(), dv.max())
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_ranks_on_one_gpu_match_single(nb, tmp_path, world):
     port = _free_port()
@@ -105,8 +113,11 @@ def test_ranks_on_one_gpu_match_single(nb, tmp_path, world):
     mp.spawn(_run, args=(1, 0, one), nprocs=1, join=True)
     mp.spawn(_run, args=(world, port, two), nprocs=world, join=True)
     a, b = np.load(one), np.load(two)
-    # the sharded launch may pick another register blocking / source split: equal to fp32 rounding, not bitwise
-    assert np.abs(a["pos"] - b["pos"]).max() < 5e-7 and np.abs(a["vel"] - b["vel"]).max() < 1e-5
+    # the sharded launch may pick another register blocking / source split: equal to fp32 rounding, not bitwise.  Nearly every body
+    # agrees to an ulp; a body whose closest neighbour's fp32 position rounded the other way in an earlier step sees a force that
+    # differs by up to G*m/eps^3 * 6e-8 ~ 4e-3, i.e. 4e-5 per step in v at dt = 1e-2 (the same trajectory-level effect the
+    # fp64-accumulate test below spells out) — bounded, and rare
+    _same_to_fp32_rounding(a, b)
     p0, _ = nb.synthetic.body4_f32(N)
     assert np.abs(b["pos"][:, :3] - p0[:, :3]).max() > 1e-6 and np.array_equal(b["pos"][:, 3], p0[:, 3])
 
@@ -155,7 +166,7 @@ def test_ranks_sharing_the_unordered_pairs_match_single(nb, oracle, tmp_path, wo
     if acc64:
         assert np.abs(a["pos64"] - b["pos64"])[:, :3].max() < 1e-9 and np.abs(a["vel"] - b["vel"]).max() < 1e-7
     else:
-        assert np.abs(a["pos"] - b["pos"]).max() < 5e-7 and np.abs(a["vel"] - b["vel"]).max() < 1e-5
+        _same_to_fp32_rounding(a, b)
     # the first of the two steps against the oracle, rows from every shard
     c = {"vel": b["vel_first"]}
     syn = nb.synthetic
@@ -197,7 +208,7 @@ def test_overlapped_step_on_one_gpu_matches_single(nb, tmp_path, world, acc64):
     if acc64:
         assert np.abs(a["pos64"] - b["pos64"])[:, :3].max() < 1e-9 and np.abs(a["vel"] - b["vel"]).max() < 1e-7
     else:
-        assert np.abs(a["pos"] - b["pos"]).max() < 5e-7 and np.abs(a["vel"] - b["vel"]).max() < 1e-5
+        _same_to_fp32_rounding(a, b)
     p0, _ = nb.synthetic.body4_f32(N)
     assert np.abs(b["pos"][:, :3] - p0[:, :3]).max() > 1e-6 and np.array_equal(b["pos"][:, 3], p0[:, 3])
 
@@ -214,7 +225,7 @@ def test_ring_pass_on_one_gpu_matches_single(nb, tmp_path, world, acc64):
     if acc64:
         assert np.abs(a["pos64"] - b["pos64"])[:, :3].max() < 1e-9 and np.abs(a["vel"] - b["vel"]).max() < 1e-7
     else:
-        assert np.abs(a["pos"] - b["pos"]).max() < 5e-7 and np.abs(a["vel"] - b["vel"]).max() < 1e-5
+        _same_to_fp32_rounding(a, b)
     p0, _ = nb.synthetic.body4_f32(N)
     assert np.abs(b["pos"][:, :3] - p0[:, :3]).max() > 1e-6 and np.array_equal(b["pos"][:, 3], p0[:, 3])
 
