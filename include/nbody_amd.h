@@ -55,7 +55,7 @@ typedef struct nb_config {
     int32_t n;         /* bodies */
     int32_t precision; /* nb_precision */
     int32_t device;    /* HIP device ordinal */
-    int32_t f64_large_min; /* NB_F64: from this many bodies on, nb_step/nb_accel use the large-n kernel; 0 = default (16384 with eps > 0: every unordered pair once; 32768 otherwise) */
+    int32_t f64_large_min; /* NB_F64: from this many bodies on, nb_step/nb_accel use the large-n kernel; 0 = default (12288 with eps > 0: every unordered pair once; 32768 otherwise) */
     int32_t f64_split;     /* NB_F64: lanes of a wave that share one target in the step kernel; 0 = auto, else a power of two <= 64 */
     int32_t flags;         /* nb_config_flags, 0 = defaults (ABI 3 carried a measurement knob here, ABI 4 required 0) */
     double G;   /* 6.674e-11 */

@@ -356,7 +356,7 @@ int nbi::create_context(nb_context** out, const nb_config* cfg, hipStream_t borr
         c->ctl_host = (F64Ctl*)((char*)c->host_arena + 232);
         c->split = cfg->f64_split > 0 ? cfg->f64_split : auto_split_f64(c->n, c->n_cus);
         const int large_min = cfg->f64_large_min > 0 ? cfg->f64_large_min : F64_LARGE_MIN;
-        // every unordered pair once (K1s-f64) where its slots are affordable and eps > 0 (the self pair then adds +0): from 16384
+        // every unordered pair once (K1s-f64) where its slots are affordable and eps > 0 (the self pair then adds +0): from 12288
         // bodies on (SYM64_MIN_SB superblocks) unless the caller moved the threshold of the large path himself
         const bool sym64 = cfg->eps * cfg->eps >= F64_EPS2_MIN && sym64_workspace_bytes(c->n, c->n_cus) > 0;
         if (c->n >= large_min || (cfg->f64_large_min <= 0 && sym64)) {  // plain steps of a large fp64 system: K1s-f64, else K1-f64

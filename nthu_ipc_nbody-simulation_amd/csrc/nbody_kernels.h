@@ -334,9 +334,11 @@ int plan_f64_large_slices(int n, int n_cus);
 // is given.
 constexpr int SYM64_SB = 2048;
 #ifndef NB_SYM64_MIN_SB
-#define NB_SYM64_MIN_SB 8
+#define NB_SYM64_MIN_SB 6
 #endif
-// K1s-f64 from this many superblocks on: 8 = 16384 bodies since round 5 (rounds 4: 16).  Measured with an A/B build
+// K1s-f64 from this many superblocks on: 6 = 12288 bodies since the end of round 5 (round 4: 16; mid-round 5, with workgroups of at
+// least 8 tile phases: 8).  With 4-phase workgroups (A/B build, profiles/r05_f64_mid_n_sweep.txt, last table): 12288 bodies 0.128 ms
+// against K2's best 0.137, 14336 0.130 against 0.194, 10240 0.122 against 0.105 (K2 wins).  Mid-round, measured with an A/B build
 // (-DNB_SYM64_MIN_SB=4, bench/f64_mid_n_sweep.py, profiles/r05_f64_mid_n_sweep.txt): K1s-f64 has a floor of ~0.21 ms per step
 // (few workgroups) and passes the per-step kernel K2 between 14336 and 16384 bodies — 0.218 ms against 0.231 at 16384, 0.294
 // against 0.50 at 24576, 0.42 against 0.80 at 30720

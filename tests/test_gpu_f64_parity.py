@@ -265,12 +265,12 @@ def test_large_n_fp64_kernel(nb, oracle, n, eps):
         assert np.isfinite(q).all() and np.isfinite(v).all()
 
 
-@pytest.mark.parametrize("n", [8 * 2048, 9 * 2048 + 77, 11 * 2048 - 1,  # round 5: from 8 superblocks on (16384 bodies; 16 until round 4)
+@pytest.mark.parametrize("n", [6 * 2048, 7 * 2048 - 5, 8 * 2048, 9 * 2048 + 77, 11 * 2048 - 1,  # round 5: from 6 superblocks on (12288 bodies; 16 until round 4)
                                16 * 2048, 17 * 2048 + 77, 40 * 2048 + 5,
                                (1 << 20) + 123])  # > 2 GiB of slots in one launch: 9 batches of 64 superblocks (round 5; until
                                                   # round 4 systems beyond 1.1e6 bodies fell back to K1-f64, 1.5x slower)
 def test_large_n_fp64_symmetric_kernel(nb, oracle, n):
-    """From 8 superblocks of 2048 bodies on (and eps > 0) NB_F64 contexts run K1s-f64: every unordered pair once, the
+    """From 6 superblocks of 2048 bodies on (and eps > 0) NB_F64 contexts run K1s-f64: every unordered pair once, the
     sources travelling through the wave, fp64 throughout (csrc/nbody_kernels_f64_sym.hip).  Accelerations of rows from the
     first, a middle and the ragged last superblock and two steps (non-contracted kick-drift) against the oracle, with `device`
     bodies (time-varying masses) present; two launches give identical bits; sum m a cancels."""
