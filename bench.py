@@ -140,12 +140,12 @@ class PowerSampler:
     never raises.  The kernel is compute-bound and runs into the socket's power cap: this is the driver-visible form of
     profiles/r04b_power_and_clock.txt (rocm-smi by hand): what the chip drew and what clock it held while `value` was measured."""
 
-    def __init__(self, pci_bus_id, period=0.2):
+    def __init__(self, pci_bus_id, period=0.2, root="/sys/class/drm"):
         import glob
         import threading
         self.dir, self.samples, self.period = None, [], period
         want = pci_bus_id.lower()
-        for d in glob.glob("/sys/class/drm/card*/device"):
+        for d in glob.glob(os.path.join(root, "card*", "device")):
             try:
                 if os.path.realpath(d).lower().endswith(want):
                     hw = glob.glob(os.path.join(d, "hwmon", "hwmon*"))

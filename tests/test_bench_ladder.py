@@ -188,3 +188,29 @@ def test_leg_lists_for_the_requests_a_user_can_make():
         bench.native_legs(A(exchange="ring"), 8)
     with pytest.raises(SystemExit):
         bench.native_legs(A(exchange="host", overlap=True), 8)
+
+
+def test_power_sampler_reads_the_hwmon_files_of_the_card_with_this_bus_id(tmp_path):
+    """bench.py's `roofline.power`: the amdgpu hwmon files of the GPU with the line's PCI bus id, found through the card's
+    device symlink; another card's files are not read; a box without them (or with unreadable ones) yields None, never an error."""
+    import time
+
+    import bench
+    for k, (bus, watts, mhz) in enumerate([("0000:05:00.0", 700, 2100), ("0000:85:00.0", 1300, 2280)]):
+        dev = tmp_path / "pci" / bus
+        hw = dev / "hwmon" / f"hwmon{k}"
+        hw.mkdir(parents=True)
+        (hw / "power1_input").write_text(f"{watts * 1000000}\n")
+        (hw / "power1_cap").write_text("1400000000\n")
+        (hw / "freq1_input").write_text(f"{mhz * 1000000}\n")
+        card = tmp_path / "drm" / f"card{k}"
+        card.mkdir(parents=True)
+        os.symlink(dev, card / "device")
+    smp = bench.PowerSampler("0000:85:00.0", period=0.01, root=str(tmp_path / "drm")).start()
+    time.sleep(0.1)
+    r = smp.stop()
+    assert r["samples"] >= 2 and r["mean_w"] == r["max_w"] == 1300.0 and r["cap_w"] == 1400.0
+    assert r["sclk_mhz_mean"] == r["sclk_mhz_min"] == 2280.0
+    assert bench.PowerSampler("0000:99:00.0", root=str(tmp_path / "drm")).start().stop() is None  # no such card
+    (tmp_path / "pci" / "0000:05:00.0" / "hwmon" / "hwmon0" / "power1_input").write_text("garbage\n")
+    assert bench.PowerSampler("0000:05:00.0", period=0.01, root=str(tmp_path / "drm")).start().stop() is None  # unreadable: no samples
