@@ -379,6 +379,9 @@ const char* kernel_name_f32(const F32Plan& plan, bool acc64, bool accel_only) {
 // workgroup is cheaper than a second round, a half-filled extra round is not.  Rounds 2-4 took 16 slices at all of these
 // sizes: up to 50 % slower at 6144-10240 and 20480-26624 bodies, 2-3x slower below 4096.  `max_slices`: what one launch's
 // workspace holds (a second launch is outside the model).
+#ifndef NB_K1_SLICE_MODEL
+#define NB_K1_SLICE_MODEL 1  // 0: rounds 2-5's rule (16 slices / a power of two) — the A/B build of bench/debug/acc64_small_n_plan_ab.py
+#endif
 static long small_system_slices(long bx, long ntiles, int n_cus, long max_slices) {
     long best_js = 1;
     double best = 1e300;
@@ -441,7 +444,7 @@ F32Plan plan_f32(long n_tgt, long n_src, int n_cus, int force_tpl, int force_js,
                 // where the old rule was up to 2x off — 65536 / 8: 0.30 -> 0.15 ms, 81920 / 4: 0.65 -> 0.41; profiles/
                 // r05_k1_small_n_model.txt).  Slices stay L2-sized (<= 512 tiles), which one launch of 64 can do up to 8.4e6 sources.
                 const long slots = max_slices >= SLICES_PER_LAUNCH ? max_slices : SLICES_PER_LAUNCH;
-                if (p.sgpr_sources && wg == 256 && n_cus > 0 && ntiles <= 512L * slots)
+                if (NB_K1_SLICE_MODEL && p.sgpr_sources && wg == 256 && n_cus > 0 && ntiles <= 512L * slots)
                     js = small_system_slices(bx, ntiles, n_cus, slots);
             }
         }
