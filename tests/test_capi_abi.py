@@ -433,3 +433,28 @@ def test_slices_of_small_whole_systems_follow_the_measured_model(nb):
     assert c.plan_f32(40960, 20480, workspace_bytes=66 * 20480 * 16) == (4, 23, 256)
     assert c.plan_f32(131072, 16384, workspace_bytes=18 * 16384 * 16) == (4, 16, 256)
     assert c.plan_f32(1 << 20, 1 << 20, workspace_bytes=18 * (1 << 20) * 16, j_split=8) == (8, 8, 512)
+
+
+def test_planned_slices_always_fit_one_launch_of_the_workspace_given(nb):
+    """plan_f32 over random shapes (host logic): whatever the model or the older rules pick, a small system's or shard's slice count is at
+    least 1, at most one slice per source tile, and — on the 256-thread SGPR path the model covers — at most what ONE launch's workspace
+    holds, so that the step stays one force launch + one reducer; without a workspace there are no slices; a forced count is kept."""
+    from hypothesis import given, settings, strategies as st
+    c = nb.capi
+
+    @settings(max_examples=300, deadline=None)
+    @given(st.integers(1, 131071), st.integers(1, 16), st.sampled_from([0, 17, 18, 34, 50, 66, 200]), st.booleans())
+    def check(n_tgt, ranks, records, acc64):
+        n_src = n_tgt * ranks
+        rec = 32 if acc64 else 16
+        tpl, js, wg = c.plan_f32(n_src, n_tgt, acc64, workspace_bytes=records * n_tgt * rec)
+        ntiles = -(-n_src // 256)
+        assert js >= 1 and js <= max(1, ntiles) and tpl in (2, 4, 8) and wg in (256, 512, 1024)
+        if records < 18:
+            assert js == 1  # fewer than 16 partial-sum slots: no slices
+        elif wg == 256 and n_src <= 8_000_000:
+            assert js <= min(records - 2, 64), (n_tgt, ranks, records, js)
+        if records >= 18 and ntiles >= 4:
+            assert c.plan_f32(n_src, n_tgt, acc64, j_split=3, workspace_bytes=records * n_tgt * rec)[1] == 3
+
+    check()
